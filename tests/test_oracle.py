@@ -1,0 +1,141 @@
+"""CPU: the oracle restatements against the committed golden vectors (made by oracle/gen_golden.py
+from transformers / torch, the libraries the reference calls on its hot path)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import adamw_ref, ctc_ref, logmel_ref
+from oracle import w2v2_ref as R
+from conftest import ctc_case_names
+
+
+def test_ctc_oracle_vs_torch(gold):
+    z = gold("ctc_cases.npz")
+    for name in ctc_case_names(z):
+        g = lambda k: z[f"{name}/{k}"]
+        loss, grad, nll = ctc_ref.ctc_loss_and_grad(g("logits"), g("labels"), g("in_lens"), 0,
+                                                     str(g("reduction")), bool(g("zero_inf")))
+        assert abs(loss - float(g("loss64"))) <= 1e-9 * max(1.0, abs(float(g("loss64")))), name
+        assert np.abs(grad - g("grad64")).max() < 1e-9, name
+        # torch's fp32 lattice (what the reference runs) within fp32 log-domain rounding
+        assert abs(loss - float(g("loss"))) <= 1e-4 * max(1.0, abs(loss)), name
+        assert np.abs(grad - g("grad")).max() <= 2e-3 * np.abs(grad).max() + 1e-7, name
+
+
+def test_ctc_infeasible_is_zeroed(gold):
+    z = gold("ctc_cases.npz")
+    loss, grad, nll = ctc_ref.ctc_loss_and_grad(z["infeasible/logits"], z["infeasible/labels"], z["infeasible/in_lens"])
+    assert nll[0] == 0.0 and np.all(grad[0] == 0.0) and nll[1] > 0
+    loss2, _, nll2 = ctc_ref.ctc_loss_and_grad(z["infeasible/logits"], z["infeasible/labels"], z["infeasible/in_lens"],
+                                               zero_infinity=False)
+    assert np.isinf(loss2)
+
+
+def test_normalize_lengths_labels(gold):
+    z = gold("features.npz")
+    waves = [z[f"wave{i}"] for i in range(4)]
+    out = R.zero_mean_unit_var_norm(waves)
+    assert np.abs(out - z["input_values"]).max() < 1e-5
+    assert (out[1, 2500:] == 0).all()
+    assert (R.conv_out_lengths(R.W2V2Config(), z["len_T"]) == z["len_F"]).all()
+    assert int(R.conv_out_lengths(R.W2V2Config(), 160000)) == 499
+    assert (R.pad_labels([[5, 6, 7, 8], [9], [10, 11]]) == z["labels_padded"]).all()
+
+
+def test_specaug_indices(gold):
+    z = gold("specaug.npz")
+    for i, (B, S) in enumerate(((4, 499), (3, 499), (2, 49))):
+        lens = list(z[f"lens{i}"])
+        m = R.compute_mask_indices((B, S), 0.05, 10, None if i == 0 else lens, 2, rng=np.random.RandomState(100 + i))
+        assert (m == z[f"mask{i}"]).all()
+
+
+def test_greedy_decode(gold):
+    z = gold("greedy.npz")
+    vocab = [str(v) for v in z["vocab"]]
+    onehot = np.eye(32, dtype=np.float32)[z["ids"]]
+    mine = [" ".join(R.ids_to_text(x, vocab).split()) for x in R.greedy_ctc_ids(onehot)]
+    assert mine == [" ".join(str(t).split()) for t in z["text"]]
+
+
+def test_logmel(gold):
+    z = gold("logmel.npz")
+    assert np.abs(logmel_ref.mel_filters() - z["filters"]).max() < 1e-6
+    m = logmel_ref.log_mel(z["wave"])
+    assert m.shape == (80, 3000)
+    assert np.abs(m[:, ::7] - z["mel_stride7"]).max() < 1e-4
+    assert np.abs(m[:, :40] - z["mel_head"]).max() < 1e-4
+
+
+def test_logmel_bonjour(gold):
+    import wave
+    z = gold("logmel.npz")
+    with wave.open(os.path.join(os.path.dirname(__file__), "golden", "bonjour.wav")) as f:
+        pcm = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+    assert np.abs(logmel_ref.log_mel(pcm)[:, :130] - z["bonjour_mel_head"]).max() < 1e-4
+
+
+def test_adamw_clip_schedule(gold):
+    z = gold("adamw.npz")
+    for wd in (0.0, 0.01):
+        p, m, v = z["p0"].copy(), np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+        for i, g in enumerate(z["grads"]):
+            tot, coef = adamw_ref.clip_coef([g], 1.0)
+            assert abs(tot - z[f"norm_wd{wd}"][i]) < 1e-3 * tot
+            p, m, v = adamw_ref.adamw_step(p, g * np.float32(coef), m, v, i + 1,
+                                           adamw_ref.linear_warmup_lr(1e-4, i, 2, 10), weight_decay=wd)
+            assert np.abs(p - z[f"p_wd{wd}"][i]).max() < 1e-6
+    # lr values pinned by the reference's own golden (tests/expected/train_transformers/trainer_state.json:12-13,27-28)
+    assert abs(adamw_ref.linear_warmup_lr(1e-4, 1, 500, 10000) - 2e-7) < 1e-12
+    assert abs(adamw_ref.linear_warmup_lr(1e-4, 2, 500, 10000) - 4e-7) < 1e-12
+
+
+def _check_model(z, cfg, seed, lens, mask, tol_logits=2e-4):
+    p = R.init_params(cfg, seed)
+    loss, logits, grads = R.loss_and_grads(p, cfg, torch.tensor(z["x"]), lens, torch.tensor(z["labels"]),
+                                           mask_time_indices=mask)
+    assert abs(loss.item() - float(z["loss"])) < 2e-4 * max(1, abs(float(z["loss"])))
+    assert np.abs(logits.numpy() - z["logits"]).max() < tol_logits
+    gk = [k for k in z.files if k.startswith("grad/")]
+    floor = 1e-3 * max(np.abs(z[k]).max() for k in gk)
+    for k in gk:
+        e = np.abs(grads[k[5:]].numpy() - z[k]).max() / max(np.abs(z[k]).max(), floor)
+        assert e < 5e-3, (k, e)
+    return p
+
+
+def test_w2v2_tiny_vs_hf(gold):
+    z = gold("w2v2_tiny.npz")
+    cfg = R.W2V2Config.tiny().deterministic()
+    p = _check_model(z, cfg, 69, None, torch.tensor(z["mask"]))
+    st = {}
+    R.forward(p, cfg, torch.tensor(z["x"]), None, None, mask_time_indices=torch.tensor(z["mask"]), stages=st)
+    for k in z.files:
+        if k.startswith("stage/"):
+            assert np.abs(st[k[6:]].detach().numpy() - z[k]).max() < 1e-4, k
+
+
+def test_w2v2_tiny_xlsr_vs_hf(gold):
+    z = gold("w2v2_tiny_xlsr.npz")
+    cfg = R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True).deterministic()
+    _check_model(z, cfg, 70, list(z["lens"]), None)
+
+
+def test_w2v2_base_vs_hf(gold):
+    from oracle.gen_golden import base_inputs
+    z = gold("w2v2_base.npz")
+    x, labels = base_inputs()
+    assert np.abs(x[:, :64] - z["x_head"]).max() < 1e-6 and (labels == z["labels"]).all()
+    cfg = R.W2V2Config.base().deterministic()
+    p = R.init_params(cfg, 69)
+    assert sum(t.numel() for t in p.values()) == 94396320
+    torch.set_num_threads(os.cpu_count())
+    loss, logits, grads = R.loss_and_grads(p, cfg, torch.tensor(x), None, torch.tensor(labels))
+    assert logits.shape == (2, 499, 32)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * float(z["loss"])
+    assert np.abs(logits.numpy() - z["logits"]).max() < 2e-4
+    for n, nr, hd in zip(z["grad_names"], z["grad_norms"], z["grad_heads"]):
+        g = grads[str(n)].numpy()
+        assert abs(np.sqrt((g.astype(np.float64) ** 2).sum()) - nr) <= 2e-3 * nr + 1e-7, n
