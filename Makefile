@@ -1,0 +1,29 @@
+# Builds libssak_hip.so (hand-written HIP kernels for gfx950 + the C ABI of include/ssak_hip.h).
+# `make` cross-compiles without a GPU; the .so is built in-tree so that it travels with the snapshot.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := ssak_amd/csrc
+OBJ := build/obj
+LIB := ssak_amd/lib/libssak_hip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -ffp-contract=fast
+SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
+OBJS := $(patsubst $(CSRC)/%,$(OBJ)/%.o,$(SRCS))
+
+all: $(LIB)
+
+$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h include/ssak_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/%.cpp.o: $(CSRC)/%.cpp include/ssak_hip.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $(LIB))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(LIB)
+
+.PHONY: all clean

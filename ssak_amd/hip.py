@@ -1,0 +1,129 @@
+"""ctypes binding of ``libssak_hip.so`` (C ABI: ``include/ssak_hip.h``).
+
+torch is used here only as plumbing: device buffers (``tensor.data_ptr()``) and the current HIP stream.
+Every wrapper raises ``RuntimeError`` when the library reports a launch failure and ``ValueError`` when
+it rejects the arguments -- the exception types the reference's Python call sites would see.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_kmajor", C.c_int), ("b_kmajor", C.c_int),
+                ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long), ("nb1", C.c_int), ("nb2", C.c_int),
+                ("sa1", C.c_long), ("sa2", C.c_long), ("sb1", C.c_long), ("sb2", C.c_long), ("sc1", C.c_long),
+                ("sc2", C.c_long), ("alpha", C.c_float), ("epilogue", C.c_int), ("out_f32", C.c_int),
+                ("accumulate", C.c_int), ("split_k", C.c_int)]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
+                          "ssak_amd has no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    sig = {
+        "ssak_version": (i32, []),
+        "ssak_last_error": (C.c_char_p, []),
+        "ssak_wave_normalize_workspace_bytes": (sz, [i32, i32]),
+        "ssak_wave_normalize": (i32, [vp, vp, i32, i32, vp, vp, vp, sz, vp]),
+        "ssak_ctc_workspace_bytes": (sz, [i32, i32, i32, i32]),
+        "ssak_ctc_loss_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]),
+        "ssak_ctc_greedy_decode": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+SSAK_OK, SSAK_ERR_INVALID, SSAK_ERR_LAUNCH, SSAK_ERR_STATE = 0, -1, -2, -3
+EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD = 0, 1, 2
+REDUCTION = {"sum": 0, "mean": 1}
+
+
+def check(rc: int):
+    if rc == SSAK_OK:
+        return
+    msg = lib.ssak_last_error().decode()
+    if rc == SSAK_ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(f"libssak_hip status {rc}: {msg}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes: int, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------ op wrappers (tensors in, tensors out)
+def wave_normalize(x: torch.Tensor, lens: torch.Tensor | None = None, return_mask: bool = False):
+    """[B,T] fp32 raw samples -> normalised [B,T] fp32 (+ int32 attention mask)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    B, T = x.shape
+    out = torch.empty_like(x)
+    mask = torch.empty((B, T), dtype=torch.int32, device=x.device) if return_mask else None
+    if lens is not None:
+        lens = lens.to(device=x.device, dtype=torch.int32).contiguous()
+    ws = _ws(lib.ssak_wave_normalize_workspace_bytes(B, T), x.device)
+    check(lib.ssak_wave_normalize(ptr(x), ptr(lens), B, T, ptr(out), ptr(mask), ptr(ws), ws.numel(), stream()))
+    return (out, mask) if return_mask else out
+
+
+def ctc_loss(logits: torch.Tensor, in_lens: torch.Tensor | None, labels: torch.Tensor, blank: int = 0,
+             reduction: str = "mean", zero_infinity: bool = True, grad_scale: float = 1.0, want_grad: bool = True):
+    """logits [B,F,V] fp32, labels [B,L] (negative = pad) -> (loss[1], nll[B], dlogits[B,F,V] | None)."""
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 3 and logits.is_contiguous()
+    B, F, V = logits.shape
+    labels = labels.to(device=logits.device, dtype=torch.int32).contiguous()
+    if labels.numel() and int(labels.max()) >= V:
+        raise ValueError(f"Label values must be <= vocab_size: {V}")  # modeling_wav2vec2.py:1686-1687
+    Lmax = labels.shape[1]
+    if in_lens is not None:
+        in_lens = in_lens.to(device=logits.device, dtype=torch.int32).contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    nll = torch.empty(B, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits) if want_grad else None
+    ws = _ws(lib.ssak_ctc_workspace_bytes(B, F, V, Lmax), logits.device)
+    check(lib.ssak_ctc_loss_fwd_bwd(ptr(logits), ptr(in_lens), ptr(labels), B, F, V, Lmax, blank, REDUCTION[reduction],
+                                    int(zero_infinity), float(grad_scale), ptr(loss), ptr(nll), ptr(grad), ptr(ws),
+                                    ws.numel(), stream()))
+    return loss, nll, grad
+
+
+def ctc_greedy_decode(logits: torch.Tensor, in_lens: torch.Tensor | None = None, blank: int = 0):
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 3 and logits.is_contiguous()
+    B, F, V = logits.shape
+    if in_lens is not None:
+        in_lens = in_lens.to(device=logits.device, dtype=torch.int32).contiguous()
+    ids = torch.empty((B, F), dtype=torch.int32, device=logits.device)
+    n = torch.empty(B, dtype=torch.int32, device=logits.device)
+    check(lib.ssak_ctc_greedy_decode(ptr(logits), ptr(in_lens), B, F, V, blank, ptr(ids), ptr(n), stream()))
+    return ids, n
+
+
+def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
+         sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
+         accumulate=False, split_k=1):
+    """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h)."""
+    d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
+                 sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k)
+    ws = _ws(split_k * nb1 * nb2 * M * N * 4, A.device) if split_k > 1 else None
+    check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
+                             0 if ws is None else ws.numel(), stream()))
+    return C_out

@@ -1,0 +1,227 @@
+"""GPU parity tests (through the C ABI) for the stand-alone kernels: CTC, normalise, greedy decode, GEMM."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ctc_case_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    import ssak_amd.hip as h
+    return h
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+# ------------------------------------------------------------------ CTC
+def test_ctc_golden_cases(hip, gold):
+    """Every golden case (torch F.ctc_loss fp32 + its fp64 run) and the float64 oracle.
+    Tolerance: fp32 log-domain lattice -> 2e-4 relative on the loss, 2e-3 of max|grad| on the gradient
+    (torch's own fp32 kernel sits at the same distance from the fp64 result)."""
+    from oracle import ctc_ref
+    z = gold("ctc_cases.npz")
+    for name in ctc_case_names(z):
+        g = lambda k: z[f"{name}/{k}"]
+        red = str(g("reduction"))
+        loss, nll, grad = hip.ctc_loss(_dev(g("logits")), _dev(g("in_lens")), _dev(g("labels")), 0, red, bool(g("zero_inf")))
+        o_loss, o_grad, o_nll = ctc_ref.ctc_loss_and_grad(g("logits"), g("labels"), g("in_lens"), 0, red, bool(g("zero_inf")))
+        assert abs(loss.item() - o_loss) <= 2e-4 * max(1.0, abs(o_loss)), (name, loss.item(), o_loss)
+        assert abs(loss.item() - float(g("loss"))) <= 2e-4 * max(1.0, abs(o_loss)), name
+        assert np.abs(nll.cpu().numpy() - o_nll).max() <= 2e-4 * max(1.0, np.abs(o_nll).max()), name
+        err = np.abs(grad.cpu().numpy() - o_grad).max()
+        assert err <= 2e-3 * np.abs(o_grad).max() + 1e-7, (name, err)
+
+
+def test_ctc_edge_cases(hip):
+    from oracle import ctc_ref
+    rng = np.random.default_rng(0)
+    # infeasible without zero_infinity -> inf loss; label == V raises like the reference
+    logits = rng.standard_normal((2, 6, 5)).astype(np.float32)
+    labels = np.array([[1, 1, 1, 1], [2, -100, -100, -100]])
+    loss, nll, grad = hip.ctc_loss(_dev(logits), None, _dev(labels), 0, "sum", False)
+    assert torch.isinf(loss).item() and torch.isinf(nll[0]).item() and torch.isfinite(nll[1]).item()
+    with pytest.raises(ValueError):
+        hip.ctc_loss(_dev(logits), None, _dev(np.array([[5], [1]])), 0)
+    # large vocabulary (Whisper-sized head) and long label sequences (S > 256 states)
+    B, F, V = 3, 300, 51
+    logits = rng.standard_normal((B, F, V)).astype(np.float32)
+    labels = np.full((B, 140), -100)
+    for b, n in enumerate((140, 129, 5)):
+        labels[b, :n] = rng.integers(1, V, n)
+    in_lens = np.array([300, 290, 17], np.int32)
+    loss, nll, grad = hip.ctc_loss(_dev(logits), _dev(in_lens), _dev(labels), 0, "mean", True)
+    o_loss, o_grad, o_nll = ctc_ref.ctc_loss_and_grad(logits, labels, in_lens, 0, "mean", True)
+    assert abs(loss.item() - o_loss) <= 2e-4 * abs(o_loss)
+    assert np.abs(grad.cpu().numpy() - o_grad).max() <= 2e-3 * np.abs(o_grad).max()
+    assert (grad[2, 17:] == 0).all()
+
+
+def test_ctc_full_size_properties(hip):
+    """BASELINE shape (B=32, F=499, V=32, L in [60,120]): size-independent properties.
+    Rows of d loss/d logits sum to zero (softmax minus a posterior), gradient is zero past in_len, and
+    the loss is invariant to a per-frame shift of the logits."""
+    rng = np.random.default_rng(1)
+    B, F, V = 32, 499, 32
+    logits = _dev(rng.standard_normal((B, F, V)).astype(np.float32))
+    labels = np.full((B, 120), -100)
+    for b in range(B):
+        n = rng.integers(60, 121)
+        labels[b, :n] = rng.integers(1, V, n)
+    loss, nll, grad = hip.ctc_loss(logits, None, _dev(labels), 0, "mean", True)
+    assert torch.isfinite(loss).item() and (nll > 0).all()
+    assert grad.sum(-1).abs().max().item() < 1e-5
+    shift = _dev(rng.standard_normal((B, F, 1)).astype(np.float32))
+    loss2, _, _ = hip.ctc_loss((logits + shift).contiguous(), None, _dev(labels), 0, "mean", True)
+    assert abs(loss.item() - loss2.item()) < 2e-4 * abs(loss.item())
+
+
+def test_greedy_decode(hip, gold):
+    from oracle import w2v2_ref as R
+    z = gold("greedy.npz")
+    onehot = np.eye(32, dtype=np.float32)[z["ids"]]
+    ids, n = hip.ctc_greedy_decode(_dev(onehot), None, 0)
+    want = R.greedy_ctc_ids(onehot)
+    got = [ids[b, :n[b]].cpu().tolist() for b in range(len(want))]
+    assert got == want
+    rng = np.random.default_rng(3)
+    logits = rng.standard_normal((5, 499, 32)).astype(np.float32)
+    lens = np.array([499, 1, 64, 65, 300], np.int32)
+    ids, n = hip.ctc_greedy_decode(_dev(logits), _dev(lens), 0)
+    for b in range(5):
+        assert ids[b, :n[b]].cpu().tolist() == R.greedy_ctc_ids(logits[b:b + 1, :lens[b]])[0]
+
+
+# ------------------------------------------------------------------ normalise
+def test_wave_normalize_golden(hip, gold):
+    z = gold("features.npz")
+    waves = [z[f"wave{i}"] for i in range(4)]
+    T = max(len(w) for w in waves)
+    x = np.zeros((4, T), np.float32)
+    x[:] = 7.0  # garbage in the padding must be ignored
+    for i, w in enumerate(waves):
+        x[i, :len(w)] = w
+    lens = np.array([len(w) for w in waves], np.int32)
+    out, mask = hip.wave_normalize(_dev(x), _dev(lens), return_mask=True)
+    assert np.abs(out.cpu().numpy() - z["input_values"]).max() < 2e-5
+    assert (mask.cpu().numpy() == z["attention_mask"]).all()
+
+
+def test_wave_normalize_full_size(hip):
+    from oracle import w2v2_ref as R
+    rng = np.random.default_rng(5)
+    B, T = 8, 160000
+    x = (rng.standard_normal((B, T)) * 0.1 + 0.3).astype(np.float32)
+    lens = np.array([T, T - 1, 12345, 8192, 8193, 1000, T, 400], np.int32)
+    out = hip.wave_normalize(_dev(x), _dev(lens)).cpu().numpy()
+    ref = R.zero_mean_unit_var_norm([x[b] for b in range(B)], lens)
+    assert np.abs(out - ref).max() < 5e-5
+    for b in range(B):  # properties: zero mean, unit variance over the valid part; idempotent
+        v = out[b, :lens[b]].astype(np.float64)
+        assert abs(v.mean()) < 1e-4 and abs(v.var() - 1.0) < 1e-3
+    again = hip.wave_normalize(_dev(out), _dev(lens)).cpu().numpy()
+    assert np.abs(again - out).max() < 1e-4
+
+
+# ------------------------------------------------------------------ GEMM
+def _gemm_ref(A, B, a_km, b_km):
+    A = A.float().T if a_km else A.float()
+    B = B.float() if b_km else B.float().T
+    return A @ B
+
+
+@pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (499, 768, 768), (257, 48, 200), (64, 3072, 520), (1000, 32, 768)])
+def test_gemm_layouts(hip, a_km, b_km, M, N, K):
+    """All four operand layouts on ragged shapes, integer-valued operands (exact in bf16 and fp32):
+    bit-exact against an fp32 matmul.  Asymmetric operands catch transposed fragment maps."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    Mp, Np, Kp = (M + 7) // 8 * 8, (N + 7) // 8 * 8, (K + 7) // 8 * 8
+    A = torch.randint(-3, 4, (Kp, Mp) if a_km else (Mp, Kp), generator=g).to(torch.bfloat16)
+    B = torch.randint(-3, 4, (Kp, Np) if b_km else (Np, Kp), generator=g).to(torch.bfloat16)
+    # poison the padding: it must never leak into the result
+    if a_km:
+        A[K:, :] = 100
+        A[:, M:] = 100
+    else:
+        A[M:, :] = 100
+        A[:, K:] = 100
+    if b_km:
+        B[K:, :] = 100
+        B[:, N:] = 100
+    else:
+        B[N:, :] = 100
+        B[:, K:] = 100
+    Av = A[:K, :M] if a_km else A[:M, :K]
+    Bv = B[:K, :N] if b_km else B[:N, :K]
+    ref = _gemm_ref(Av, Bv, a_km, b_km)
+    Cc = torch.full((M, Np), -7.0, dtype=torch.float32).cuda()
+    hip.gemm(A.cuda(), B.cuda(), Cc, M, N, K, a_kmajor=a_km, b_kmajor=b_km, lda=A.shape[1], ldb=B.shape[1], ldc=Np)
+    assert torch.equal(Cc[:, :N].cpu(), ref), (Cc[:, :N].cpu() - ref).abs().max()
+    assert (Cc[:, N:] == -7.0).all()  # nothing written outside N
+
+
+def test_gemm_epilogues_and_batches(hip):
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 300, 200, 136
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+    B = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = A.float() @ B.float().T * 0.5 + bias
+    # bias + GELU with pre-activation side output, bf16 out
+    Cc = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    pre = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    hip.gemm(A, B, Cc, M, N, K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias, epilogue=hip.EPI_GELU, aux_out=pre)
+    assert (pre.float() - ref).abs().max() < 2e-2
+    assert (Cc.float() - torch.nn.functional.gelu(ref)).abs().max() < 2e-2
+    # multiply by gelu'(aux)
+    Cg = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    hip.gemm(A, B, Cg, M, N, K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias, epilogue=hip.EPI_MUL_GELU_GRAD, aux_in=pre)
+    x = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert (Cg.float() - ref * x.grad).abs().max() < 3e-2
+    # split-K (deterministic slab reduce) + accumulate into fp32
+    Cf = torch.ones(M, N, dtype=torch.float32).cuda()
+    hip.gemm(A, B, Cf, M, N, K, lda=K, ldb=K, ldc=N, alpha=0.5, accumulate=True, split_k=3)
+    assert (Cf - (ref - bias + 1.0)).abs().max() < 1e-3
+    # two-level batch with strides (attention-style: heads interleaved in the channel dimension)
+    nb, nh, T, hd = 2, 3, 50, 16
+    qkv = torch.randn(nb * T, 3 * nh * hd, generator=g).to(torch.bfloat16).cuda()
+    S = torch.empty(nb, nh, T, 56, dtype=torch.float32).cuda()
+    hip.gemm(qkv, qkv[:, nh * hd:], S, T, T, hd, lda=3 * nh * hd, ldb=3 * nh * hd, ldc=56, nb1=nb, nb2=nh,
+             sa=(T * 3 * nh * hd, hd), sb=(T * 3 * nh * hd, hd), sc=(nh * T * 56, T * 56), alpha=0.25)
+    q = qkv[:, :nh * hd].float().view(nb, T, nh, hd).transpose(1, 2)
+    k = qkv[:, nh * hd:2 * nh * hd].float().view(nb, T, nh, hd).transpose(1, 2)
+    assert (S[..., :T] - 0.25 * q @ k.transpose(2, 3)).abs().max() < 1e-3
+
+
+def test_gemm_toeplitz_conv(hip):
+    """channels-last Conv1d as a GEMM with overlapping A rows (lda = stride*C < K = kernel*C)."""
+    g = torch.Generator().manual_seed(1)
+    Bn, Tin, Cc, Co, k, s = 2, 101, 16, 24, 3, 2
+    Tout = (Tin - k) // s + 1
+    x = torch.randint(-2, 3, (Bn, Tin, Cc), generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (Co, Cc, k), generator=g).to(torch.bfloat16)
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), stride=s).transpose(1, 2)
+    wk = w.permute(0, 2, 1).contiguous().view(Co, k * Cc)  # [Co, k, Cin]: K index = tap*Cin + c
+    y = torch.empty(Bn, Tout, Co, dtype=torch.float32).cuda()
+    hip.gemm(x.cuda(), wk.cuda(), y, Tout, Co, k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Co, nb1=Bn,
+             sa=(Tin * Cc, 0), sc=(Tout * Co, 0))
+    assert torch.equal(y.cpu(), ref)
+
+
+def test_gemm_rejects_bad_args(hip):
+    A = torch.zeros(8, 8, dtype=torch.bfloat16).cuda()
+    Cc = torch.zeros(8, 8, dtype=torch.float32).cuda()
+    with pytest.raises(ValueError):
+        hip.gemm(A, A, Cc, 8, 8, 8, lda=7, ldb=8, ldc=8)
+    with pytest.raises(ValueError):
+        hip.gemm(A, A, Cc, 0, 8, 8, lda=8, ldb=8, ldc=8)
