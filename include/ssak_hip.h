@@ -85,9 +85,71 @@ typedef struct {
   int out_f32;
   int accumulate; /* C += result (fp32 out only) */
   int split_k;
+  float drop_p;        /* > 0: dropout fused into the epilogue (after GELU / on the GELU-grad product) */
+  uint32_t drop_stream; /* mask bit = hash(drop_seed, drop_stream, element offset in C): replayable in backward */
+  uint64_t drop_seed;
+  long bias_s2; /* bias element stride per second-level batch index (grouped conv: one bias slice per group) */
 } ssak_gemm_desc;
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
+ * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer
+ * (docker/transformers_modified/trainer.py:1827-1855; ssak/train/transformers/wav2vec_train.py:353-384).
+ * ssak_grad_sumsq: out[0] = sum(grads^2).  ssak_adamw_step: g' = grads * grad_scale * min(1, max_norm /
+ * (sqrt(gnorm_sq[0]) * grad_scale + 1e-6)) (no clipping when gnorm_sq is NULL or max_norm <= 0), then the
+ * AdamW update with bias correction for 1-based `step`; shadow_bf16 (or NULL) receives the bf16 copy of the
+ * new parameters.  The clip coefficient is read on the device: no host synchronisation. */
+int ssak_grad_sumsq(const float* grads, long n, float* out, void* stream);
+int ssak_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                    const float* gnorm_sq, float max_norm, float grad_scale, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, void* stream);
+
+/* ---- a3-a10: the Wav2Vec2-CTC acoustic model ------------------------------------------------
+ * Replaces `model(input_values, attention_mask, labels)` / `loss.backward()` of transformers.Wav2Vec2ForCTC as
+ * called at ssak/train/transformers/wav2vec_train.py:387-415 (through HF Trainer.training_step) and
+ * ssak/infer/transformers_infer.py:235.  The handle owns only derived weight layouts; parameters, gradients,
+ * the bf16 shadow and the workspace are caller-owned flat device buffers.
+ *
+ * Parameter layout: ssak_w2v2_param_info enumerates (HF state_dict name, element offset, shape) of every
+ * tensor inside the flat buffers; [0, ssak_w2v2_num_trainable) is what the optimizer / all-reduce touch. */
+typedef struct {
+  int vocab_size, hidden_size, num_layers, num_heads, intermediate_size;
+  int num_conv_layers;
+  int conv_dim[8], conv_kernel[8], conv_stride[8];
+  int conv_bias;            /* 0 (base) */
+  int feat_extract_norm;    /* 0 = "group" (base), 1 = "layer" (XLSR; not built yet) */
+  int do_stable_layer_norm; /* 0 = post-LN (base) */
+  int num_conv_pos_embeddings, num_conv_pos_embedding_groups;
+  float layer_norm_eps;
+  float attention_dropout, hidden_dropout, activation_dropout, feat_proj_dropout, final_dropout;
+  int freeze_feature_encoder; /* wav2vec_train.py:326-327 */
+} ssak_w2v2_config;
+typedef struct ssak_w2v2 ssak_w2v2;
+
+int ssak_w2v2_create(const ssak_w2v2_config* cfg /*host*/, ssak_w2v2** out);
+void ssak_w2v2_destroy(ssak_w2v2* h);
+long ssak_w2v2_num_params(const ssak_w2v2* h);
+long ssak_w2v2_num_trainable(const ssak_w2v2* h);
+int ssak_w2v2_param_count(const ssak_w2v2* h);
+int ssak_w2v2_param_info(const ssak_w2v2* h, int index, char* name /*host*/, int name_cap, long* offset, long* numel,
+                         int* ndim, long* shape4 /*host [4]*/);
+/* params/grads fp32 [num_params] (grads may be NULL for inference), shadow_bf16 uint16 [num_params] */
+int ssak_w2v2_bind(ssak_w2v2* h, float* params, float* grads, void* shadow_bf16);
+/* full != 0: rebuild the whole bf16 shadow + conv layouts from `params` (after loading weights);
+ * full == 0: only the weight-normed positional-conv layouts (after an optimizer step that updated the shadow). */
+int ssak_w2v2_sync_weights(ssak_w2v2* h, int full, void* stream);
+int ssak_w2v2_num_frames(const ssak_w2v2* h, int T); /* floor((L-k)/s)+1 chain, modeling_wav2vec2.py:997-1016 */
+size_t ssak_w2v2_workspace_bytes(const ssak_w2v2* h, int B, int T, int training);
+/* input_values [B,T] fp32 normalised waveforms; lens [B] int32 valid samples or NULL (= no attention mask, the
+ * group-norm/base convention); spec_mask [B,F] uint8 SpecAugment mask or NULL; layer_keep host uint8 [num_layers]
+ * LayerDrop decisions or NULL; seed drives every dropout mask of this step; logits [B,F,V] fp32 out;
+ * frame_lens [B] int32 out (or NULL).  training != 0 keeps the activations for ssak_w2v2_backward. */
+int ssak_w2v2_forward(ssak_w2v2* h, const float* input_values, const int32_t* lens, int B, int T,
+                      const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed, int training,
+                      float* logits, int32_t* frame_lens, void* workspace, size_t workspace_bytes, void* stream);
+/* dlogits [B,F,V] fp32 (e.g. from ssak_ctc_loss_fwd_bwd); overwrites grads[0, num_trainable). */
+int ssak_w2v2_backward(ssak_w2v2* h, const float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

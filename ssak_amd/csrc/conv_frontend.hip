@@ -1,0 +1,236 @@
+// Feature-encoder front end and positional-convolution weight plumbing.  gfx950.
+//
+//  * conv0 (C_in = 1, k = 10, s = 5) + GroupNorm(C groups = per-channel over time) + GELU, written
+//    channels-last in bf16 (transformers modeling_wav2vec2.py:302-323).  The fp32 pre-norm activation
+//    (65 MB / utterance at 10 s) is never materialised: pass 1 recomputes the 10-tap dot product to get the
+//    per-channel statistics (fp64 atomics), pass 2 recomputes it again, normalises, applies GELU and writes
+//    bf16 once.  HBM-bound on the 32.7 MB / utterance bf16 store.
+//  * Conv1d weight re-layout [Co, Ci, k] -> [Co, k, Ci] bf16: with channels-last activations a strided
+//    Conv1d is then a GEMM whose A rows overlap (lda = stride * Ci), no im2col.
+//  * Positional conv (:326-368): weight_norm(dim=2) materialisation w = g v / ||v|| into the forward GEMM
+//    layout [H][K][H/G] and the flipped/transposed layout of the input-gradient GEMM, its backward to
+//    (g, v), and the zero-padded per-group activation packing that turns the grouped conv into batched GEMMs.
+#include "kernels.h"
+
+namespace {
+
+constexpr int KS0 = 10, ST0 = 5, FR0 = 128;  // conv0 taps / stride / frames per workgroup
+constexpr int NS0 = (FR0 - 1) * ST0 + KS0;
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    bf16* __restrict__ out, double* __restrict__ stats, int T, int T0,
+                                                    int C) {
+  __shared__ float xs[NS0];
+  __shared__ float red[256][9];
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * FR0;
+  const int nq = C >> 2;        // channel quads
+  const int fl = 256 / nq;      // frame lanes
+  const int q = threadIdx.x % nq, fli = threadIdx.x / nq;
+  const int nfr = min(FR0, T0 - f0);
+  const float* xb = x + (size_t)b * T;
+  for (int i = threadIdx.x; i < NS0; i += 256) {
+    const int s = f0 * ST0 + i;
+    xs[i] = (s < T) ? xb[s] : 0.f;
+  }
+  float wr[4][KS0];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < KS0; ++k) wr[j][k] = w[(q * 4 + j) * KS0 + k];
+  float mu[4], rs[4], ga[4], be[4];
+  if (APPLY) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double s1 = stats[((size_t)b * C + q * 4 + j) * 2], s2 = stats[((size_t)b * C + q * 4 + j) * 2 + 1];
+      const double m = s1 / T0;
+      const double var = fmax(s2 / T0 - m * m, 0.0);
+      mu[j] = (float)m;
+      rs[j] = (float)(1.0 / sqrt(var + 1e-5));
+      ga[j] = gamma[q * 4 + j];
+      be[j] = beta[q * 4 + j];
+    }
+  }
+  __syncthreads();
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int f = fli; f < nfr; f += fl) {
+    float xv[KS0];
+#pragma unroll
+    for (int k = 0; k < KS0; ++k) xv[k] = xs[f * ST0 + k];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS0; ++k) a = fmaf(wr[j][k], xv[k], a);
+      v[j] = a;
+    }
+    if (APPLY) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)gelu_f((v[j] - mu[j]) * rs[j] * ga[j] + be[j]);
+      *reinterpret_cast<bf16x4*>(out + ((size_t)b * T0 + f0 + f) * C + q * 4) = o;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1[j] += v[j];
+        s2[j] = fmaf(v[j], v[j], s2[j]);
+      }
+    }
+  }
+  if (!APPLY) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[threadIdx.x][j] = s1[j];
+      red[threadIdx.x][4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (fli == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double a = 0.0, c = 0.0;
+        for (int l = 0; l < fl; ++l) {
+          a += red[l * nq + q][j];
+          c += red[l * nq + q][4 + j];
+        }
+        atomicAdd(&stats[((size_t)b * C + q * 4 + j) * 2], a);
+        atomicAdd(&stats[((size_t)b * C + q * 4 + j) * 2 + 1], c);
+      }
+    }
+  }
+}
+
+__global__ void conv_w_rearrange_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Co, int Ci, int k) {
+  const long n = (long)Co * Ci * k;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(e % k);
+    const int ci = (int)((e / k) % Ci);
+    const int co = (int)(e / ((long)k * Ci));
+    out[((long)co * k + kk) * Ci + ci] = (bf16)w[e];
+  }
+}
+
+// sum over rows of v[r][k]^2 (and optionally dw_fwd[o][k][c] * v[o][c][k]); K <= 1024 threads, rows strided by grid
+__global__ void posconv_colnorm_kernel(const float* __restrict__ v, const float* __restrict__ dwf, int rows, int K,
+                                       int cg, float* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float a = v[(long)r * K + k];
+    if (dwf) {
+      const int o = r / cg, c = r % cg;
+      s = fmaf(a, dwf[((long)o * K + k) * cg + c], s);
+    } else {
+      s = fmaf(a, a, s);
+    }
+  }
+  atomicAdd(out + k, s);
+}
+
+__global__ void posconv_materialize_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                           const float* __restrict__ nsq, bf16* __restrict__ wf, bf16* __restrict__ wb,
+                                           int H, int cg, int K) {
+  const long n = (long)H * cg * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    const int c = (int)((e / K) % cg);
+    const int o = (int)(e / ((long)K * cg));
+    const float wv = g[k] * v[e] * rsqrtf(nsq[k]);
+    wf[((long)o * K + k) * cg + c] = (bf16)wv;
+    const int grp = o / cg, nn = o % cg;
+    wb[(((long)grp * cg + c) * K + (K - 1 - k)) * cg + nn] = (bf16)wv;
+  }
+}
+
+__global__ void posconv_wbwd_kernel(const float* __restrict__ dwf, const float* __restrict__ g,
+                                    const float* __restrict__ v, const float* __restrict__ nsq,
+                                    const float* __restrict__ dot, float* __restrict__ dg, float* __restrict__ dv, int H,
+                                    int cg, int K) {
+  const long n = (long)H * cg * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    const int c = (int)((e / K) % cg);
+    const int o = (int)(e / ((long)K * cg));
+    const float inv = rsqrtf(nsq[k]);
+    const float d = dwf[((long)o * K + k) * cg + c];
+    dv[e] += g[k] * inv * (d - v[e] * dot[k] * inv * inv);
+    if (e < K) dg[e] += dot[e] * rsqrtf(nsq[e]);
+  }
+}
+
+__global__ void posconv_pack_kernel(const bf16* __restrict__ h, bf16* __restrict__ pg, int B, int F, int H, int G,
+                                    int lead, int RS, long rows_total) {
+  const int cg = H / G, cpr = cg >> 3;
+  const long n = rows_total * G * cpr;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(e % cpr);
+    const long r = (e / cpr) % rows_total;
+    const int g = (int)(e / ((long)cpr * rows_total));
+    const long rr = r - lead;
+    uint4 val = make_uint4(0u, 0u, 0u, 0u);
+    if (rr >= 0) {
+      const int b = (int)(rr / RS), t = (int)(rr % RS);
+      if (b < B && t < F) val = *reinterpret_cast<const uint4*>(h + ((long)b * F + t) * H + g * cg + cc * 8);
+    }
+    *reinterpret_cast<uint4*>(pg + ((long)g * rows_total + r) * cg + cc * 8) = val;
+  }
+}
+
+}  // namespace
+
+int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,
+                    int B, int T, int T0, int C, int ksize, int stride, hipStream_t st) {
+  SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
+  SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
+  SSAK_REQUIRE(T0 == (T - KS0) / ST0 + 1 && T0 > 0, "conv0: T0 mismatch");
+  SSAK_HIP(hipMemsetAsync(stats, 0, (size_t)B * C * 2 * sizeof(double), st));
+  dim3 grid(ssak_cdiv(T0, FR0), B);
+  conv0_kernel<false><<<grid, 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
+  SSAK_LAUNCH_CHECK();
+  conv0_kernel<true><<<grid, 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_conv_weight_rearrange(const float* w, bf16* out, int Co, int Ci, int k, hipStream_t st) {
+  conv_w_rearrange_kernel<<<min(2048, ssak_cdiv((long)Co * Ci * k, 256)), 256, 0, st>>>(w, out, Co, Ci, k);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, float* norms, int H, int G, int K,
+                      hipStream_t st) {
+  SSAK_REQUIRE(K <= 1024 && H % G == 0 && ((H / G) & 7) == 0, "posconv: K=%d <= 1024 and (H/G)=%d %% 8 == 0 required", K, H / G);
+  const int cg = H / G;
+  SSAK_HIP(hipMemsetAsync(norms, 0, (size_t)K * sizeof(float), st));
+  posconv_colnorm_kernel<<<256, ((K + 63) / 64) * 64, 0, st>>>(v, nullptr, H * cg, K, cg, norms);
+  SSAK_LAUNCH_CHECK();
+  posconv_materialize_kernel<<<min(2048, ssak_cdiv((long)H * cg * K, 256)), 256, 0, st>>>(g, v, norms, w_fwd, w_bwd, H, cg, K);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const float* norms, float* dg, float* dv,
+                         int H, int G, int K, hipStream_t st) {
+  // `dg` doubles as the scratch for dot[k] would alias the output; use the tail of `norms` (2K floats allocated)
+  const int cg = H / G;
+  float* dot = const_cast<float*>(norms) + K;
+  SSAK_HIP(hipMemsetAsync(dot, 0, (size_t)K * sizeof(float), st));
+  posconv_colnorm_kernel<<<256, ((K + 63) / 64) * 64, 0, st>>>(v, dw, H * cg, K, cg, dot);
+  SSAK_LAUNCH_CHECK();
+  posconv_wbwd_kernel<<<min(2048, ssak_cdiv((long)H * cg * K, 256)), 256, 0, st>>>(dw, g, v, norms, dot, dg, dv, H, cg, K);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, hipStream_t st) {
+  const int lead = K / 2, RS = F + K;
+  const long rows_total = lead + (long)B * RS + K;
+  const long n = rows_total * G * (H / G / 8);
+  posconv_pack_kernel<<<min(4096, ssak_cdiv(n, 256)), 256, 0, st>>>(h, pg, B, F, H, G, lead, RS, rows_total);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}

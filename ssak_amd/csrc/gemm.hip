@@ -35,6 +35,10 @@ struct GemmParams {
   float alpha;
   int epilogue, out_f32, accumulate, split_k;
   int tiles_m, tiles_n, nz, kt_per_split;
+  uint32_t drop_thresh, drop_stream;
+  float drop_scale;
+  uint64_t drop_seed;
+  long bias_s2;
 };
 
 // ---- LDS tile geometry -------------------------------------------------------------------------
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     if (p.bias) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < p.N) bv[r] = p.bias[n + r];
+        if (n + r < p.N) bv[r] = p.bias[z2 * p.bias_s2 + n + r];
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -266,6 +270,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < p.N) v[r] *= gelu_grad_f((float)p.aux_in[o + r]);
+      }
+      if (p.drop_thresh) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] = keep_bit(p.drop_seed, p.drop_stream, (uint64_t)(o + r), p.drop_thresh) ? v[r] * p.drop_scale : 0.f;
       }
       if (p.out_f32) {
         float* dst = reinterpret_cast<float*>(p.C) + o;
@@ -305,7 +314,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
     const int m = (int)(r / p.N), n = (int)(r % p.N);
     float s = 0.f;
     for (int k = 0; k < p.split_k; ++k) s += p.slab[((long)k * p.nz + z) * per + r];
-    s = s * p.alpha + (p.bias ? p.bias[n] : 0.f);
+    s = s * p.alpha + (p.bias ? p.bias[(z % p.nb2) * p.bias_s2 + n] : 0.f);
     const long o = (long)(z / p.nb2) * p.sc1 + (long)(z % p.nb2) * p.sc2 + (long)m * p.ldc + n;
     if (p.out_f32) {
       float* dst = reinterpret_cast<float*>(p.C) + o;
@@ -384,6 +393,13 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   p.accumulate = d->accumulate;
   p.split_k = split;
   p.nz = d->nb1 * d->nb2;
+  p.drop_thresh = d->drop_p > 0.f ? (uint32_t)fminf(4294967295.f, d->drop_p * 4294967296.f) : 0u;
+  p.drop_scale = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  p.drop_stream = d->drop_stream;
+  p.drop_seed = d->drop_seed;
+  p.bias_s2 = d->bias_s2;
+  SSAK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p must be in [0,1)");
+  SSAK_REQUIRE(!(d->drop_p > 0.f && d->split_k > 1), "gemm: dropout epilogue is not available with split_k");
   const int nkt = ssak_cdiv(d->K, BK);
   p.kt_per_split = ssak_cdiv(nkt, split);
   if (split > 1)

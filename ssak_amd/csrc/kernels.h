@@ -1,0 +1,45 @@
+// Internal C++ launch functions shared between the kernel files and the engine (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+struct DropSpec {
+  uint64_t seed = 0;
+  uint32_t stream = 0;
+  float p = 0.f;
+};
+
+// norm_act.hip
+int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
+                    float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
+                    hipStream_t st);
+int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
+                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta, int M, int C,
+                    const DropSpec& pre, const DropSpec& post, hipStream_t st);
+int k_softmax_fwd(const float* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
+                  int rows_per_batch, const DropSpec& drop, hipStream_t st);
+int k_softmax_bwd(const float* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
+                  hipStream_t st);
+int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st);
+int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st);
+int k_specaug_fwd(bf16* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
+                  hipStream_t st);
+int k_specaug_bwd(bf16* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
+                  hipStream_t st);
+
+int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStream_t st);
+int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st);
+
+// conv_frontend.hip
+int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,
+                    int B, int T, int T0, int C, int ksize, int stride, hipStream_t st);
+int k_conv_weight_rearrange(const float* w, bf16* out, int Co, int Ci, int k, hipStream_t st);
+int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, float* norms, int H, int G, int K,
+                      hipStream_t st);
+int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const float* norms, float* dg, float* dv,
+                         int H, int G, int K, hipStream_t st);
+int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, hipStream_t st);
+
+// optim.hip
+int k_sumsq(const float* g, long n, float* out /*[1], zeroed by caller*/, hipStream_t st);
+int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, const float* gnorm_sq, float max_norm,
+            float grad_scale, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t st);

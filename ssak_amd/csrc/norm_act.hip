@@ -1,0 +1,547 @@
+// Row-wise and element-wise kernels around the GEMMs of the encoder (all HBM-bound).  gfx950.
+//
+//  * residual + dropout + LayerNorm forward / backward   (transformers modeling_wav2vec2.py:429-434, :591-608,
+//    :631-654, :667-726 -- feature projection LN, encoder LN, per-layer post-/pre-LN)
+//  * attention softmax forward / backward with key-padding mask and dropout (:438-463)
+//  * column sums (bias gradients), dtype casts, SpecAugment scatter (:1272-1316)
+// One wave owns one row; 16-byte vector accesses; statistics in fp32; two-pass variance as torch does.
+// Dropout masks are recomputed from (seed, stream, element index) in the backward kernels.
+#include "common.h"
+
+namespace {
+
+constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows per workgroup
+
+__device__ __forceinline__ void unpack8(const uint4& q, float* f) {
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2 t = {(bf16)f[2 * i], (bf16)f[2 * i + 1]};
+    w[i] = __builtin_bit_cast(uint32_t, t);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+struct LnFwdParams {
+  const bf16* y;      // [M,C] branch output (may be null -> r = res)
+  const bf16* res;    // [M,C] residual (may be null)
+  const float* gamma;
+  const float* beta;
+  bf16* r_out;        // [M,C] r = res + drop(y)   (may be null)
+  bf16* out;          // [M,C] LN(r) (then optional post-dropout); null -> no LN (plain residual add)
+  float* mean;
+  float* rstd;
+  int M, C;
+  float eps;
+  uint64_t seed;
+  uint32_t pre_stream, pre_thresh, post_stream, post_thresh;
+  float pre_scale, post_scale;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int nch = p.C >> 3;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+    if (ch < nch) {
+      const size_t o = (size_t)row * p.C + ch * 8;
+      if (p.y) {
+        unpack8(*reinterpret_cast<const uint4*>(p.y + o), v[i]);
+        if (p.pre_thresh) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[i][k] = keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh) ? v[i][k] * p.pre_scale : 0.f;
+        }
+      }
+      if (p.res) {
+        float r[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.res + o), r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[i][k] += r[k];
+      }
+      if (p.r_out) {
+        // round through bf16 so that forward and backward see the same LN input
+        const uint4 q = pack8(v[i]);
+        *reinterpret_cast<uint4*>(p.r_out + o) = q;
+        unpack8(q, v[i]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[i][k];
+    }
+  }
+  if (!p.out) return;
+  const float mean = wave_sum(s) / (float)p.C;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = v[i][k] - mean;
+        q2 += d * d;
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(q2) / (float)p.C + p.eps);
+  if (lane == 0 && p.mean) {
+    p.mean[row] = mean;
+    p.rstd[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const size_t o = (size_t)row * p.C + ch * 8;
+      float g[8], b[8], w[8];
+      *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(p.gamma + ch * 8);
+      *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(p.gamma + ch * 8 + 4);
+      *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(p.beta + ch * 8);
+      *reinterpret_cast<float4*>(b + 4) = *reinterpret_cast<const float4*>(p.beta + ch * 8 + 4);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        w[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
+        if (p.post_thresh) w[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? w[k] * p.post_scale : 0.f;
+      }
+      *reinterpret_cast<uint4*>(p.out + o) = pack8(w);
+    }
+  }
+}
+
+struct LnBwdParams {
+  const bf16* g1;     // [M,C] grad wrt (post-dropout) LN output
+  const bf16* g2;     // [M,C] second contribution or null
+  const bf16* r;      // [M,C] saved LN input
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const bf16* g_res;  // [M,C] extra gradient added to dr AFTER the LN backward (pre-LN residual stream) or null
+  bf16* dr;           // [M,C] grad wrt r (residual path)
+  bf16* dy;           // [M,C] grad wrt y = dr * premask/(1-p)  (null when no pre-dropout: use dr)
+  float* dgamma;      // [C] accumulated with atomics
+  float* dbeta;
+  int M, C;
+  uint64_t seed;
+  uint32_t pre_stream, pre_thresh, post_stream, post_thresh;
+  float pre_scale, post_scale;
+  int rows_per_wave;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p) {
+  __shared__ float red[2][ROW_THREADS / 64][NCH * 64 * 8 / 64][64];  // [dgamma|dbeta][wave][slot][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = p.C >> 3;
+  const int wid = blockIdx.x * (ROW_THREADS / 64) + wave;
+  float ag[NCH][8], ab[NCH][8], gm[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ag[i][k] = 0.f;
+      ab[i][k] = 0.f;
+      gm[i][k] = (ch < nch) ? p.gamma[ch * 8 + k] : 0.f;
+    }
+  }
+  const int row0 = wid * p.rows_per_wave;
+  for (int row = row0; row < min(p.M, row0 + p.rows_per_wave); ++row) {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float dyv[NCH][8], xh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        dyv[i][k] = 0.f;
+        xh[i][k] = 0.f;
+      }
+      if (ch < nch) {
+        const size_t o = (size_t)row * p.C + ch * 8;
+        float a[8], x[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.g1 + o), a);
+        if (p.g2) {
+          float b2[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.g2 + o), b2);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[k] += b2[k];
+        }
+        unpack8(*reinterpret_cast<const uint4*>(p.r + o), x);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (p.post_thresh) a[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? a[k] * p.post_scale : 0.f;
+          xh[i][k] = (x[k] - mean) * rstd;
+          ag[i][k] += a[k] * xh[i][k];
+          ab[i][k] += a[k];
+          dyv[i][k] = a[k] * gm[i][k];
+          s1 += dyv[i][k];
+          s2 += dyv[i][k] * xh[i][k];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)p.C;
+    s2 = wave_sum(s2) / (float)p.C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        const size_t o = (size_t)row * p.C + ch * 8;
+        float d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = rstd * (dyv[i][k] - s1 - xh[i][k] * s2);
+        if (p.g_res) {
+          float e[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.g_res + o), e);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) d[k] += e[k];
+        }
+        *reinterpret_cast<uint4*>(p.dr + o) = pack8(d);
+        if (p.dy) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            d[k] = (!p.pre_thresh || keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh)) ? d[k] * p.pre_scale : 0.f;
+          *reinterpret_cast<uint4*>(p.dy + o) = pack8(d);
+        }
+      }
+    }
+  }
+  // reduce the per-wave column partials across the 4 waves, then one atomic per column per workgroup
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[0][wave][i * 8 + k][lane] = ag[i][k];
+      red[1][wave][i * 8 + k][lane] = ab[i][k];
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NCH * 8 * 64; e += ROW_THREADS) {
+    const int slot = e >> 6, ln = e & 63;
+    const int i = slot >> 3, k = slot & 7;
+    const int col = (ln + 64 * i) * 8 + k;
+    if (col < p.C) {
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < ROW_THREADS / 64; ++w) {
+        sg += red[0][w][slot][ln];
+        sb += red[1][w][slot][ln];
+      }
+      atomicAdd(p.dgamma + col, sg);
+      atomicAdd(p.dbeta + col, sb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- softmax
+struct SoftmaxParams {
+  const float* S;       // [rows, ld] fp32 scores (already scaled)
+  bf16* P;              // [rows, ld] probabilities (pre-dropout)
+  bf16* Pd;             // [rows, ld] dropped probabilities or null
+  const int32_t* klens; // [B] valid keys per utterance or null
+  int rows, cols, ld, rows_per_batch;
+  uint64_t seed;
+  uint32_t stream, thresh;
+  float scale;
+};
+
+template <int NIT>
+__global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int kl = p.klens ? min(p.klens[row / p.rows_per_batch], p.cols) : p.cols;
+  const float* s = p.S + (size_t)row * p.ld;
+  float v[NIT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (c < kl) ? s[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    v[i] = (lane + 64 * i < kl) ? __expf(v[i] - mx) : 0.f;
+    sum += v[i];
+  }
+  const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = lane + 64 * i;
+    if (c < p.ld) {
+      const size_t o = (size_t)row * p.ld + c;
+      const float pr = v[i] * inv;
+      p.P[o] = (bf16)pr;
+      if (p.Pd) p.Pd[o] = (bf16)((!p.thresh || keep_bit(p.seed, p.stream, o, p.thresh)) ? pr * p.scale : 0.f);
+    }
+  }
+}
+
+struct SoftmaxBwdParams {
+  const float* dPd;  // [rows, ld] fp32 grad wrt dropped probabilities
+  const bf16* P;     // [rows, ld]
+  bf16* dS;          // [rows, ld]
+  int rows, cols, ld;
+  uint64_t seed;
+  uint32_t stream, thresh;
+  float scale;
+};
+
+template <int NIT>
+__global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxBwdParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  float pr[NIT], dp[NIT];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = lane + 64 * i;
+    pr[i] = 0.f;
+    dp[i] = 0.f;
+    if (c < p.cols) {
+      const size_t o = (size_t)row * p.ld + c;
+      pr[i] = (float)p.P[o];
+      const float g = p.dPd[o];
+      dp[i] = (!p.thresh || keep_bit(p.seed, p.stream, o, p.thresh)) ? g * p.scale : 0.f;
+      dot += pr[i] * dp[i];
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = lane + 64 * i;
+    if (c < p.ld) p.dS[(size_t)row * p.ld + c] = (bf16)(pr[i] * (dp[i] - dot));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- column sums
+// out[n] += sum_m X[m, n]  (bias gradients).  Workgroup: 8 threads across 64 columns x 32 row lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, long ld, int M, int N,
+                                                     float* __restrict__ out) {
+  __shared__ float red[32][65];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + cx * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    for (int m = blockIdx.y * 32 + ry; m < M; m += gridDim.y * 32) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(X + (size_t)m * ld + c0), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += f[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[ry][cx * 8 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) atomicAdd(out + c, s);
+  }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 q = *reinterpret_cast<const float4*>(in + i);
+    const bf16x4 t = {(bf16)q.x, (bf16)q.y, (bf16)q.z, (bf16)q.w};
+    *reinterpret_cast<bf16x4*>(out + i) = t;
+  } else {
+    for (long j = i; j < n; ++j) out[j] = (bf16)in[j];
+  }
+}
+
+// SpecAugment + padding: h[row,:] = embed where mask[row]; = 0 where frame >= flen[b]
+__global__ void specaug_fwd_kernel(bf16* __restrict__ h, const uint8_t* __restrict__ mask,
+                                   const int32_t* __restrict__ flens, const float* __restrict__ embed, int M, int F, int C) {
+  const int row = blockIdx.x;
+  const int b = row / F, t = row % F;
+  const bool pad = flens && t >= flens[b];
+  const bool mk = mask && mask[row];
+  if (!pad && !mk) return;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) h[(size_t)row * C + c] = pad ? (bf16)0.f : (bf16)embed[c];
+}
+// backward: rows that were overwritten pass no gradient; masked rows feed d embed
+__global__ void specaug_bwd_kernel(bf16* __restrict__ dh, const uint8_t* __restrict__ mask,
+                                   const int32_t* __restrict__ flens, float* __restrict__ dembed, int M, int F, int C) {
+  const int row = blockIdx.x;
+  const int b = row / F, t = row % F;
+  const bool pad = flens && t >= flens[b];
+  const bool mk = mask && mask[row];
+  if (!pad && !mk) return;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const size_t o = (size_t)row * C + c;
+    if (!pad && dembed) atomicAdd(dembed + c, (float)dh[o]);
+    dh[o] = (bf16)0.f;
+  }
+}
+
+__global__ void gelu_grad_mul_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ pre, bf16* __restrict__ out, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float a[8], x[8];
+    unpack8(reinterpret_cast<const uint4*>(dy)[i], a);
+    unpack8(reinterpret_cast<const uint4*>(pre)[i], x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] *= gelu_grad_f(x[k]);
+    reinterpret_cast<uint4*>(out)[i] = pack8(a);
+  }
+}
+__global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float x[8], y[8];
+    unpack8(reinterpret_cast<const uint4*>(a)[i], x);
+    unpack8(reinterpret_cast<const uint4*>(b)[i], y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] += y[k];
+    reinterpret_cast<uint4*>(out)[i] = pack8(x);
+  }
+}
+
+uint32_t thresh_of(float p) { return p <= 0.f ? 0u : (uint32_t)fminf(4294967295.f, p * 4294967296.f); }
+
+}  // namespace
+
+// ---- internal C++ entry points used by the engine (declared in kernels.h) ------------------------
+#include "kernels.h"
+
+int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
+                    float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
+                    hipStream_t st) {
+  SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
+  LnFwdParams p{y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, pre.seed,
+                pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
+                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f};
+  const int grid = ssak_cdiv(M, ROW_THREADS / 64);
+  const int nch = ssak_cdiv(C / 8, 64);
+  if (nch == 1)
+    ln_fwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nch == 2)
+    ln_fwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+  else
+    ln_fwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
+                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta, int M, int C,
+                    const DropSpec& pre, const DropSpec& post, hipStream_t st) {
+  SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm_bwd: C=%d must be a multiple of 8 and <= 1536", C);
+  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, M, C, pre.seed,
+                pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
+                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f, 1};
+  // ~2048 waves in flight; each wave walks a contiguous run of rows and keeps column partials in registers
+  const int waves = 2048;
+  p.rows_per_wave = ssak_cdiv(M, waves);
+  const int grid = ssak_cdiv(ssak_cdiv(M, p.rows_per_wave), ROW_THREADS / 64);
+  const int nch = ssak_cdiv(C / 8, 64);
+  if (nch == 1)
+    ln_bwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nch == 2)
+    ln_bwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+  else
+    ln_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_softmax_fwd(const float* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
+                  int rows_per_batch, const DropSpec& drop, hipStream_t st) {
+  SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && ld <= 24 * 64, "softmax: cols=%d ld=%d unsupported (ld <= 1536)", cols, ld);
+  SoftmaxParams p{S, P, Pd, klens, rows, cols, ld, rows_per_batch, drop.seed, drop.stream, thresh_of(drop.p),
+                  drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f};
+  const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
+  const int nit = ssak_cdiv(ld, 64);
+  if (nit <= 2)
+    softmax_fwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nit <= 8)
+    softmax_fwd_kernel<8><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nit <= 12)
+    softmax_fwd_kernel<12><<<grid, ROW_THREADS, 0, st>>>(p);
+  else
+    softmax_fwd_kernel<24><<<grid, ROW_THREADS, 0, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_softmax_bwd(const float* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
+                  hipStream_t st) {
+  SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && ld <= 24 * 64, "softmax_bwd: cols=%d ld=%d unsupported", cols, ld);
+  SoftmaxBwdParams p{dPd, P, dS, rows, cols, ld, drop.seed, drop.stream, thresh_of(drop.p),
+                     drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f};
+  const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
+  const int nit = ssak_cdiv(ld, 64);
+  if (nit <= 2)
+    softmax_bwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nit <= 8)
+    softmax_bwd_kernel<8><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nit <= 12)
+    softmax_bwd_kernel<12><<<grid, ROW_THREADS, 0, st>>>(p);
+  else
+    softmax_bwd_kernel<24><<<grid, ROW_THREADS, 0, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st) {
+  SSAK_REQUIRE(M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ld);
+  dim3 grid(ssak_cdiv(N, 64), min(64, ssak_cdiv(M, 32)));
+  colsum_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, out);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st) {
+  if (n <= 0) return SSAK_OK;
+  cast_f32_bf16_kernel<<<ssak_cdiv(ssak_cdiv(n, 4), 256), 256, 0, st>>>(in, out, n);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_specaug_fwd(bf16* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
+                  hipStream_t st) {
+  if (!mask && !flens) return SSAK_OK;
+  specaug_fwd_kernel<<<B * F, 128, 0, st>>>(h, mask, flens, embed, B * F, F, C);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_specaug_bwd(bf16* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
+                  hipStream_t st) {
+  if (!mask && !flens) return SSAK_OK;
+  specaug_bwd_kernel<<<B * F, 128, 0, st>>>(dh, mask, flens, dembed, B * F, F, C);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStream_t st) {
+  SSAK_REQUIRE((n & 7) == 0, "gelu_grad_mul: n must be a multiple of 8");
+  gelu_grad_mul_kernel<<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(dy, pre, out, n / 8);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st) {
+  SSAK_REQUIRE((n & 7) == 0, "add: n must be a multiple of 8");
+  add_bf16_kernel<<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(a, b, out, n / 8);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}

@@ -1,0 +1,744 @@
+// Wav2Vec2-CTC acoustic-model engine: forward, CTC loss + gradient, backward.  Host-side sequencing of
+// the gfx950 kernels; everything runs asynchronously on one HIP stream and is hipGraph-capturable (no
+// allocation, no synchronisation, no host reads inside forward/backward).
+//
+// Stands behind `model(input_values, attention_mask, labels)` + `loss.backward()` as the reference drives them
+// through HF Trainer (ssak/train/transformers/wav2vec_train.py:387-415; module graph: transformers
+// modeling_wav2vec2.py, Wav2Vec2ForCTC.forward :1667-1742) and `model(input_values).logits` for inference
+// (ssak/infer/transformers_infer.py:235).
+//
+// MI355X-first choices (vs the reference's eager PyTorch graph):
+//   * activations are bf16, channels-last everywhere; every Conv1d is a GEMM on overlapping rows (no im2col);
+//   * 288 GB of HBM: every activation the backward needs is kept (no gradient checkpointing /
+//     recompute, which the reference enables to fit 16 GB cards, wav2vec_train.py:329);
+//   * q/k/v projections are one [3H,H] GEMM; bias, GELU, dropout and GELU-gradient live in GEMM epilogues;
+//     residual + dropout + LayerNorm is one kernel; dropout masks are recomputed from a counter hash;
+//   * weight gradients are deterministic split-K GEMMs reading both operands K-major (hardware transpose
+//     read), written straight into one flat fp32 gradient buffer that RCCL all-reduces in one call.
+#include <algorithm>
+#include <string>
+#include <vector>
+#include <string.h>
+
+#include "kernels.h"
+
+namespace {
+
+struct PInfo {
+  std::string name;
+  std::vector<long> shape;
+  long offset = 0, numel = 0;
+  int region = 0;  // 0 trainable, 1 feature encoder
+};
+
+struct LayerP {
+  long wqkv, bqkv, wo, bo, ln1w, ln1b, w1, b1, w2, b2, ln2w, ln2b;
+};
+
+inline long align_up(long x, long a) { return (x + a - 1) / a * a; }
+
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off = (size_t)align_up((long)(off + bytes), 256);
+    return o;
+  }
+};
+
+struct LayerBuf {
+  size_t qkv, P, Pd, ctx, r1, x1, f1pre, f1, r2, st;  // st: mean1|rstd1|mean2|rstd2 (4*M floats)
+};
+
+struct Plan {
+  int B = 0, T = 0, F = 0, M = 0, Fp = 0, training = 0;
+  int Tl[8] = {0};
+  long pg_rows = 0;
+  size_t bufA, bufB, feat, stats0, ln0, st0, h0, pgx, pc_pre, pc, h1, stE, tmpH, S, xf, flens;
+  std::vector<size_t> x;       // L+1 layer inputs/outputs
+  std::vector<LayerBuf> lb;
+  // backward temporaries
+  size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH;
+  size_t slab_bytes = 0;
+  size_t total = 0;
+};
+
+}  // namespace
+
+struct ssak_w2v2 {
+  ssak_w2v2_config cfg;
+  std::vector<PInfo> params;
+  long n_total = 0, n_train = 0;
+  // parameter offsets (elements into the flat buffers)
+  long p_mse, p_fpln_w, p_fpln_b, p_fp_w, p_fp_b, p_pc_b, p_pc_g, p_pc_v, p_eln_w, p_eln_b, p_lm_w, p_lm_b;
+  long p_conv_w[8], p_gn_w, p_gn_b;
+  std::vector<LayerP> lp;
+  // bound buffers (caller-owned)
+  float* P = nullptr;
+  float* G = nullptr;
+  bf16* W = nullptr;
+  // engine-owned derived weights
+  bf16* conv_w[8] = {nullptr};
+  bf16* pc_wf = nullptr;
+  bf16* pc_wb = nullptr;
+  float* pc_norms = nullptr;  // [2K]: ||v||^2 per tap | scratch
+  Plan plan;
+  bool have_fwd = false;
+  uint64_t seed = 0;
+  const uint8_t* spec_mask = nullptr;
+  const int32_t* lens = nullptr;
+  std::vector<int> keep;  // LayerDrop decisions of the last forward
+};
+
+namespace {
+
+// stream ids of the dropout sites (mask bit = hash(seed, stream, element offset))
+enum : uint32_t { DS_FEATPROJ = 1, DS_ENCIN = 2, DS_FINAL = 3, DS_LAYER0 = 16 };
+inline uint32_t ds_attn(int l) { return DS_LAYER0 + 4 * l; }
+inline uint32_t ds_hid1(int l) { return DS_LAYER0 + 4 * l + 1; }
+inline uint32_t ds_act(int l) { return DS_LAYER0 + 4 * l + 2; }
+inline uint32_t ds_hid2(int l) { return DS_LAYER0 + 4 * l + 3; }
+
+int conv_len(int L, int k, int s) { return (L - k) / s + 1; }
+
+void add_param(ssak_w2v2* e, long& cursor, const std::string& name, std::vector<long> shape, int region, long* off_out) {
+  PInfo pi;
+  pi.name = name;
+  pi.shape = shape;
+  pi.numel = 1;
+  for (long d : shape) pi.numel *= d;
+  pi.offset = cursor;
+  pi.region = region;
+  cursor = align_up(cursor + pi.numel, 8);
+  if (off_out) *off_out = pi.offset;
+  e->params.push_back(pi);
+}
+
+void build_param_table(ssak_w2v2* e) {
+  const ssak_w2v2_config& c = e->cfg;
+  const long H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, C = c.conv_dim[c.num_conv_layers - 1];
+  const long K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
+  long cur = 0;
+  e->lp.resize(c.num_layers);
+  // region 0a: trainable matrices (weight-decayed set of HF Trainer, trainer.py:1013-1024)
+  add_param(e, cur, "wav2vec2.masked_spec_embed", {H}, 0, &e->p_mse);
+  add_param(e, cur, "wav2vec2.feature_projection.projection.weight", {H, C}, 0, &e->p_fp_w);
+  add_param(e, cur, "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original0", {1, 1, K}, 0, &e->p_pc_g);
+  add_param(e, cur, "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1", {H, cg, K}, 0, &e->p_pc_v);
+  for (int l = 0; l < c.num_layers; ++l) {
+    const std::string p = "wav2vec2.encoder.layers." + std::to_string(l) + ".";
+    LayerP& L = e->lp[l];
+    long dummy;
+    add_param(e, cur, p + "attention.q_proj.weight", {H, H}, 0, &L.wqkv);  // q,k,v contiguous = one [3H,H] matrix
+    add_param(e, cur, p + "attention.k_proj.weight", {H, H}, 0, &dummy);
+    add_param(e, cur, p + "attention.v_proj.weight", {H, H}, 0, &dummy);
+    add_param(e, cur, p + "attention.out_proj.weight", {H, H}, 0, &L.wo);
+    add_param(e, cur, p + "feed_forward.intermediate_dense.weight", {I, H}, 0, &L.w1);
+    add_param(e, cur, p + "feed_forward.output_dense.weight", {H, I}, 0, &L.w2);
+  }
+  add_param(e, cur, "lm_head.weight", {V, H}, 0, &e->p_lm_w);
+  // region 0b: trainable vectors (biases, LayerNorm affine: no weight decay)
+  add_param(e, cur, "wav2vec2.feature_projection.layer_norm.weight", {C}, 0, &e->p_fpln_w);
+  add_param(e, cur, "wav2vec2.feature_projection.layer_norm.bias", {C}, 0, &e->p_fpln_b);
+  add_param(e, cur, "wav2vec2.feature_projection.projection.bias", {H}, 0, &e->p_fp_b);
+  add_param(e, cur, "wav2vec2.encoder.pos_conv_embed.conv.bias", {H}, 0, &e->p_pc_b);
+  add_param(e, cur, "wav2vec2.encoder.layer_norm.weight", {H}, 0, &e->p_eln_w);
+  add_param(e, cur, "wav2vec2.encoder.layer_norm.bias", {H}, 0, &e->p_eln_b);
+  for (int l = 0; l < c.num_layers; ++l) {
+    const std::string p = "wav2vec2.encoder.layers." + std::to_string(l) + ".";
+    LayerP& L = e->lp[l];
+    long dummy;
+    add_param(e, cur, p + "attention.q_proj.bias", {H}, 0, &L.bqkv);
+    add_param(e, cur, p + "attention.k_proj.bias", {H}, 0, &dummy);
+    add_param(e, cur, p + "attention.v_proj.bias", {H}, 0, &dummy);
+    add_param(e, cur, p + "attention.out_proj.bias", {H}, 0, &L.bo);
+    add_param(e, cur, p + "layer_norm.weight", {H}, 0, &L.ln1w);
+    add_param(e, cur, p + "layer_norm.bias", {H}, 0, &L.ln1b);
+    add_param(e, cur, p + "feed_forward.intermediate_dense.bias", {I}, 0, &L.b1);
+    add_param(e, cur, p + "feed_forward.output_dense.bias", {H}, 0, &L.b2);
+    add_param(e, cur, p + "final_layer_norm.weight", {H}, 0, &L.ln2w);
+    add_param(e, cur, p + "final_layer_norm.bias", {H}, 0, &L.ln2b);
+  }
+  add_param(e, cur, "lm_head.bias", {V}, 0, &e->p_lm_b);
+  e->n_train = cur;
+  // region 1: feature encoder (frozen by default, wav2vec_train.py:326-327)
+  long cin = 1;
+  for (int i = 0; i < c.num_conv_layers; ++i) {
+    const std::string p = "wav2vec2.feature_extractor.conv_layers." + std::to_string(i) + ".";
+    add_param(e, cur, p + "conv.weight", {c.conv_dim[i], cin, c.conv_kernel[i]}, 1, &e->p_conv_w[i]);
+    if (i == 0) {
+      add_param(e, cur, p + "layer_norm.weight", {c.conv_dim[0]}, 1, &e->p_gn_w);
+      add_param(e, cur, p + "layer_norm.bias", {c.conv_dim[0]}, 1, &e->p_gn_b);
+    }
+    cin = c.conv_dim[i];
+  }
+  e->n_total = cur;
+}
+
+int check_config(const ssak_w2v2_config& c) {
+  SSAK_REQUIRE(c.num_conv_layers >= 2 && c.num_conv_layers <= 8, "w2v2: num_conv_layers %d unsupported", c.num_conv_layers);
+  SSAK_REQUIRE(c.feat_extract_norm == 0 && !c.conv_bias && !c.do_stable_layer_norm,
+               "w2v2: only the group-norm / post-LN (wav2vec2-base) topology is built in this round; "
+               "layer-norm feature encoder / stable-layer-norm (XLSR) is not");
+  SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "w2v2: head_dim must be a multiple of 8");
+  SSAK_REQUIRE(c.hidden_size % 8 == 0 && c.intermediate_size % 8 == 0 && c.vocab_size % 8 == 0,
+               "w2v2: hidden/intermediate/vocab sizes must be multiples of 8 (pad the vocabulary)");
+  SSAK_REQUIRE(c.hidden_size % c.num_conv_pos_embedding_groups == 0 &&
+                   (c.hidden_size / c.num_conv_pos_embedding_groups) % 8 == 0, "w2v2: pos-conv group width must be a multiple of 8");
+  for (int i = 0; i < c.num_conv_layers; ++i) {
+    SSAK_REQUIRE(c.conv_dim[i] % 8 == 0, "w2v2: conv_dim must be multiples of 8");
+  }
+  SSAK_REQUIRE(c.num_layers >= 1 && c.num_layers <= 64, "w2v2: num_layers out of range");
+  return SSAK_OK;
+}
+
+int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
+  const ssak_w2v2_config& c = e->cfg;
+  p = Plan();
+  p.B = B;
+  p.T = T;
+  p.training = training;
+  int L = T;
+  for (int i = 0; i < c.num_conv_layers; ++i) {
+    L = conv_len(L, c.conv_kernel[i], c.conv_stride[i]);
+    SSAK_REQUIRE(L > 0, "w2v2: input of %d samples is too short for the feature encoder", T);
+    p.Tl[i] = L;
+  }
+  p.F = L;
+  p.M = B * L;
+  p.Fp = (int)align_up(L, 8);
+  const long H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads;
+  const long C = c.conv_dim[c.num_conv_layers - 1], K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups;
+  const long M = p.M;
+  p.pg_rows = K / 2 + (long)B * (p.F + K) + K;
+  Carver cv;
+  const size_t b2 = sizeof(bf16);
+  p.bufA = cv.take((size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
+  p.bufB = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
+  p.feat = cv.take((size_t)M * C * b2);
+  p.stats0 = cv.take((size_t)B * c.conv_dim[0] * 2 * sizeof(double));
+  p.flens = cv.take((size_t)B * sizeof(int32_t));
+  p.ln0 = cv.take((size_t)M * C * b2);
+  p.st0 = cv.take((size_t)2 * M * sizeof(float));
+  p.h0 = cv.take((size_t)M * H * b2);
+  p.pgx = cv.take((size_t)G * p.pg_rows * (H / G) * b2);
+  p.pc_pre = cv.take((size_t)M * H * b2);
+  p.pc = cv.take((size_t)M * H * b2);
+  p.h1 = cv.take((size_t)M * H * b2);
+  p.stE = cv.take((size_t)2 * M * sizeof(float));
+  p.tmpH = cv.take((size_t)M * H * b2);
+  p.S = cv.take((size_t)B * nh * p.F * p.Fp * sizeof(float));
+  p.xf = cv.take((size_t)M * H * b2);
+  const int nl = c.num_layers;
+  p.x.resize(nl + 1);
+  p.lb.resize(nl);
+  const bool drop_attn = training && c.attention_dropout > 0.f;
+  for (int l = 0; l <= nl; ++l)
+    p.x[l] = (training || l < 2) ? cv.take((size_t)M * H * b2) : p.x[l & 1];
+  for (int l = 0; l < nl; ++l) {
+    LayerBuf& lb = p.lb[l];
+    if (training || l == 0) {
+      lb.qkv = cv.take((size_t)M * 3 * H * b2);
+      lb.P = cv.take((size_t)B * nh * p.F * p.Fp * b2);
+      lb.Pd = drop_attn ? cv.take((size_t)B * nh * p.F * p.Fp * b2) : lb.P;
+      lb.ctx = cv.take((size_t)M * H * b2);
+      lb.r1 = cv.take((size_t)M * H * b2);
+      lb.x1 = cv.take((size_t)M * H * b2);
+      lb.f1pre = cv.take((size_t)M * I * b2);
+      lb.f1 = cv.take((size_t)M * I * b2);
+      lb.r2 = cv.take((size_t)M * H * b2);
+      lb.st = cv.take((size_t)4 * M * sizeof(float));
+    } else {
+      lb = p.lb[0];
+    }
+  }
+  if (training) {
+    p.dlog = cv.take((size_t)M * V * b2);
+    p.dA = cv.take((size_t)M * H * b2);
+    p.dB = cv.take((size_t)M * H * b2);
+    p.dY = cv.take((size_t)M * H * b2);
+    p.dC = cv.take((size_t)M * H * b2);
+    p.scratchH = cv.take((size_t)M * H * b2);
+    p.dI = cv.take((size_t)M * I * b2);
+    p.dqkv = cv.take((size_t)M * 3 * H * b2);
+    p.dSb = cv.take((size_t)B * nh * p.F * p.Fp * b2);
+    p.pgdy = cv.take((size_t)G * p.pg_rows * (H / G) * b2);
+    p.dwf = cv.take((size_t)H * K * (H / G) * sizeof(float));
+    p.dln0 = cv.take((size_t)M * C * b2);
+    // split-K slabs: the largest weight-gradient product is [I,H] (or [3H,H]); at most 32 slices
+    const size_t big = (size_t)std::max(std::max(I * H, 3 * H * H), std::max(H * C, V * H));
+    p.slab_bytes = big * 32 * sizeof(float);
+    p.slab = cv.take(p.slab_bytes);
+  }
+  p.total = cv.off;
+  return SSAK_OK;
+}
+
+struct Gemm {
+  ssak_gemm_desc d;
+  const void* A = nullptr;
+  const void* B = nullptr;
+  void* C = nullptr;
+  const float* bias = nullptr;
+  const void* aux_in = nullptr;
+  void* aux_out = nullptr;
+  Gemm(int M, int N, int K) {
+    memset(&d, 0, sizeof(d));
+    d.M = M;
+    d.N = N;
+    d.K = K;
+    d.nb1 = d.nb2 = 1;
+    d.alpha = 1.f;
+    d.split_k = 1;
+  }
+  Gemm& a(const void* p, long ld, bool km = false) {
+    A = p;
+    d.lda = ld;
+    d.a_kmajor = km;
+    return *this;
+  }
+  Gemm& b(const void* p, long ld, bool km = false) {
+    B = p;
+    d.ldb = ld;
+    d.b_kmajor = km;
+    return *this;
+  }
+  Gemm& c(void* p, long ld, bool f32 = false) {
+    C = p;
+    d.ldc = ld;
+    d.out_f32 = f32;
+    return *this;
+  }
+  Gemm& batch(int nb1, int nb2, long sa1, long sa2, long sb1, long sb2, long sc1, long sc2) {
+    d.nb1 = nb1;
+    d.nb2 = nb2;
+    d.sa1 = sa1;
+    d.sa2 = sa2;
+    d.sb1 = sb1;
+    d.sb2 = sb2;
+    d.sc1 = sc1;
+    d.sc2 = sc2;
+    return *this;
+  }
+  Gemm& with_bias(const float* bp, long s2 = 0) {
+    bias = bp;
+    d.bias_s2 = s2;
+    return *this;
+  }
+  Gemm& epi(int e, const void* ain = nullptr, void* aout = nullptr) {
+    d.epilogue = e;
+    aux_in = ain;
+    aux_out = aout;
+    return *this;
+  }
+  Gemm& alpha(float a_) {
+    d.alpha = a_;
+    return *this;
+  }
+  Gemm& drop(float p, uint32_t stream, uint64_t seed) {
+    d.drop_p = p;
+    d.drop_stream = stream;
+    d.drop_seed = seed;
+    return *this;
+  }
+  int run(hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
+    return ssak_gemm_bf16(&d, A, B, C, bias, aux_in, aux_out, ws, ws_bytes, (void*)st);
+  }
+  // weight-gradient form: long K, few output tiles -> deterministic split-K sized to fill the chip
+  int run_wgrad(hipStream_t st, void* slab, size_t slab_bytes) {
+    const long tiles = (long)ssak_cdiv(d.M, 128) * ssak_cdiv(d.N, d.N > 64 ? 128 : 64) * d.nb1 * d.nb2;
+    const int nkt = ssak_cdiv(d.K, 64);
+    int split = (int)std::min<long>(32, std::max<long>(1, (768 + tiles - 1) / tiles));
+    split = std::max(1, std::min(split, nkt / 4));
+    while (split > 1 && (size_t)split * d.nb1 * d.nb2 * (size_t)d.M * d.N * sizeof(float) > slab_bytes) --split;
+    d.split_k = split;
+    return run(st, slab, slab_bytes);
+  }
+};
+
+#define TRY(x)                    \
+  do {                            \
+    int rc__ = (x);               \
+    if (rc__ != SSAK_OK) return rc__; \
+  } while (0)
+
+struct ConvChain {
+  int n;
+  int k[8], s[8];
+};
+__global__ void frame_lens_kernel(const int32_t* __restrict__ lens, int B, int T, ConvChain cc, int32_t* __restrict__ flens) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int L = min(max(lens[b], 0), T);
+  for (int i = 0; i < cc.n; ++i) L = (L >= cc.k[i]) ? (L - cc.k[i]) / cc.s[i] + 1 : 0;
+  flens[b] = L;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" int ssak_w2v2_create(const ssak_w2v2_config* cfg, ssak_w2v2** out) {
+  SSAK_REQUIRE(cfg && out, "w2v2_create: null pointer");
+  TRY(check_config(*cfg));
+  ssak_w2v2* e = new ssak_w2v2();
+  e->cfg = *cfg;
+  build_param_table(e);
+  const ssak_w2v2_config& c = e->cfg;
+  const long H = c.hidden_size, K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
+  long cin = 1;
+  for (int i = 0; i < c.num_conv_layers; ++i) {
+    if (i > 0) SSAK_HIP(hipMalloc((void**)&e->conv_w[i], (size_t)c.conv_dim[i] * cin * c.conv_kernel[i] * sizeof(bf16)));
+    cin = c.conv_dim[i];
+  }
+  SSAK_HIP(hipMalloc((void**)&e->pc_wf, (size_t)H * K * cg * sizeof(bf16)));
+  SSAK_HIP(hipMalloc((void**)&e->pc_wb, (size_t)H * K * cg * sizeof(bf16)));
+  SSAK_HIP(hipMalloc((void**)&e->pc_norms, (size_t)2 * K * sizeof(float)));
+  *out = e;
+  return SSAK_OK;
+}
+
+extern "C" void ssak_w2v2_destroy(ssak_w2v2* e) {
+  if (!e) return;
+  for (int i = 0; i < 8; ++i)
+    if (e->conv_w[i]) (void)hipFree(e->conv_w[i]);
+  if (e->pc_wf) (void)hipFree(e->pc_wf);
+  if (e->pc_wb) (void)hipFree(e->pc_wb);
+  if (e->pc_norms) (void)hipFree(e->pc_norms);
+  delete e;
+}
+
+extern "C" long ssak_w2v2_num_params(const ssak_w2v2* e) { return e ? e->n_total : 0; }
+extern "C" long ssak_w2v2_num_trainable(const ssak_w2v2* e) {
+  if (!e) return 0;
+  return e->cfg.freeze_feature_encoder ? e->n_train : e->n_total;
+}
+extern "C" int ssak_w2v2_param_count(const ssak_w2v2* e) { return e ? (int)e->params.size() : 0; }
+extern "C" int ssak_w2v2_param_info(const ssak_w2v2* e, int index, char* name, int name_cap, long* offset, long* numel,
+                                    int* ndim, long* shape4) {
+  SSAK_REQUIRE(e && index >= 0 && index < (int)e->params.size(), "w2v2_param_info: bad index %d", index);
+  const PInfo& pi = e->params[index];
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", pi.name.c_str());
+  if (offset) *offset = pi.offset;
+  if (numel) *numel = pi.numel;
+  if (ndim) *ndim = (int)pi.shape.size();
+  if (shape4)
+    for (size_t i = 0; i < 4; ++i) shape4[i] = i < pi.shape.size() ? pi.shape[i] : 1;
+  return SSAK_OK;
+}
+
+extern "C" int ssak_w2v2_bind(ssak_w2v2* e, float* params, float* grads, void* shadow_bf16) {
+  SSAK_REQUIRE(e && params && shadow_bf16, "w2v2_bind: null pointer");
+  SSAK_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)shadow_bf16) & 15) == 0, "w2v2_bind: buffers must be 16-byte aligned");
+  e->P = params;
+  e->G = grads;
+  e->W = (bf16*)shadow_bf16;
+  return SSAK_OK;
+}
+
+extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
+  SSAK_REQUIRE(e && e->P && e->W, "w2v2_sync_weights: bind the parameter buffers first");
+  hipStream_t st = (hipStream_t)stream;
+  const ssak_w2v2_config& c = e->cfg;
+  if (full) {
+    TRY(k_cast_f32_bf16(e->P, e->W, e->n_total, st));
+    long cin = c.conv_dim[0];
+    for (int i = 1; i < c.num_conv_layers; ++i) {
+      TRY(k_conv_weight_rearrange(e->P + e->p_conv_w[i], e->conv_w[i], c.conv_dim[i], (int)cin, c.conv_kernel[i], st));
+      cin = c.conv_dim[i];
+    }
+  }
+  TRY(k_posconv_prepare(e->P + e->p_pc_g, e->P + e->p_pc_v, e->pc_wf, e->pc_wb, e->pc_norms, c.hidden_size,
+                        c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
+  return SSAK_OK;
+}
+
+extern "C" size_t ssak_w2v2_workspace_bytes(const ssak_w2v2* e, int B, int T, int training) {
+  if (!e || B <= 0 || T <= 0) return 0;
+  Plan p;
+  if (make_plan(e, B, T, training, p) != SSAK_OK) return 0;
+  return p.total;
+}
+
+extern "C" int ssak_w2v2_num_frames(const ssak_w2v2* e, int T) {
+  if (!e) return 0;
+  int L = T;
+  for (int i = 0; i < e->cfg.num_conv_layers; ++i) {
+    if (L < e->cfg.conv_kernel[i]) return 0;
+    L = conv_len(L, e->cfg.conv_kernel[i], e->cfg.conv_stride[i]);
+  }
+  return L;
+}
+
+extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const int32_t* lens, int B, int T,
+                                 const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed,
+                                 int training, float* logits, int32_t* frame_lens, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(e && input_values && logits && workspace, "w2v2_forward: null pointer");
+  SSAK_REQUIRE(e->P && e->W, "w2v2_forward: bind + sync_weights first");
+  SSAK_REQUIRE(B > 0 && T > 0, "w2v2_forward: bad shape B=%d T=%d", B, T);
+  SSAK_REQUIRE(((uintptr_t)workspace & 255) == 0, "w2v2_forward: workspace must be 256-byte aligned");
+  Plan& p = e->plan;
+  e->have_fwd = false;
+  TRY(make_plan(e, B, T, training, p));
+  SSAK_REQUIRE(workspace_bytes >= p.total, "w2v2_forward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+  const ssak_w2v2_config& c = e->cfg;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto BF = [&](size_t off) { return (bf16*)(ws + off); };
+  auto FP = [&](size_t off) { return (float*)(ws + off); };
+  const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads, hd = H / nh;
+  const int nc = c.num_conv_layers, C = c.conv_dim[nc - 1], K = c.num_conv_pos_embeddings;
+  const int G = c.num_conv_pos_embedding_groups, cg = H / G;
+  const int F = p.F, M = p.M, Fp = p.Fp;
+  const float* P = e->P;
+  const bf16* W = e->W;
+  e->seed = seed;
+  e->spec_mask = spec_mask;
+  e->lens = lens;
+  const bool tr = training != 0;
+  auto DS = [&](float prob, uint32_t stream_id) {
+    DropSpec d;
+    d.seed = seed;
+    d.stream = stream_id;
+    d.p = tr ? prob : 0.f;
+    return d;
+  };
+  const DropSpec none;
+
+  // frame lengths (attention / CTC masks) from sample lengths: integer floor-div chain (modeling_wav2vec2.py:997-1016)
+  int32_t* flens = nullptr;
+  if (lens) {
+    flens = (int32_t*)(ws + p.flens);
+    ConvChain cc;
+    cc.n = nc;
+    for (int i = 0; i < nc; ++i) {
+      cc.k[i] = c.conv_kernel[i];
+      cc.s[i] = c.conv_stride[i];
+    }
+    frame_lens_kernel<<<ssak_cdiv(B, 64), 64, 0, st>>>(lens, B, T, cc, flens);
+    SSAK_LAUNCH_CHECK();
+    if (frame_lens) SSAK_HIP(hipMemcpyAsync(frame_lens, flens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  }
+
+  // ---- a3: feature encoder (frozen: forward only)
+  TRY(k_conv0_gn_gelu(input_values, P + e->p_conv_w[0], P + e->p_gn_w, P + e->p_gn_b, BF(p.bufA), (double*)(ws + p.stats0),
+                      B, T, p.Tl[0], c.conv_dim[0], c.conv_kernel[0], c.conv_stride[0], st));
+  {
+    bf16* src = BF(p.bufA);
+    for (int i = 1; i < nc; ++i) {
+      bf16* dst = (i == nc - 1) ? BF(p.feat) : ((i & 1) ? BF(p.bufB) : BF(p.bufA));
+      const int Ci = c.conv_dim[i - 1], Co = c.conv_dim[i], k = c.conv_kernel[i], s = c.conv_stride[i];
+      TRY(Gemm(p.Tl[i], Co, k * Ci)
+              .a(src, (long)s * Ci)
+              .b(e->conv_w[i], (long)k * Ci)
+              .c(dst, Co)
+              .batch(B, 1, (long)p.Tl[i - 1] * Ci, 0, 0, 0, (long)p.Tl[i] * Co, 0)
+              .epi(SSAK_EPI_GELU)
+              .run(st));
+      src = dst;
+    }
+  }
+  // ---- a4: feature projection  LN -> Linear (+ feat_proj_dropout)
+  TRY(k_layernorm_fwd(BF(p.feat), nullptr, P + e->p_fpln_w, P + e->p_fpln_b, nullptr, BF(p.ln0), FP(p.st0),
+                      FP(p.st0) + M, M, C, c.layer_norm_eps, none, none, st));
+  TRY(Gemm(M, H, C).a(BF(p.ln0), C).b(W + e->p_fp_w, C).c(BF(p.h0), H).with_bias(P + e->p_fp_b)
+          .drop(tr ? c.feat_proj_dropout : 0.f, DS_FEATPROJ, seed).run(st));
+  // ---- a5: SpecAugment scatter + zeroing of padded frames
+  TRY(k_specaug_fwd(BF(p.h0), spec_mask, flens, P + e->p_mse, B, F, H, st));
+  // ---- a6: positional conv (grouped, weight-normed) + GELU, residual, LayerNorm, dropout
+  TRY(k_posconv_pack(BF(p.h0), BF(p.pgx), B, F, H, G, K, st));
+  TRY(Gemm(F, cg, K * cg)
+          .a(BF(p.pgx), cg)
+          .b(e->pc_wf, (long)K * cg)
+          .c(BF(p.pc), H)
+          .batch(B, G, (long)(F + K) * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
+          .with_bias(P + e->p_pc_b, cg)
+          .epi(SSAK_EPI_GELU, nullptr, BF(p.pc_pre))
+          .run(st));
+  TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->p_eln_w, P + e->p_eln_b, BF(p.h1), BF(p.x[0]), FP(p.stE), FP(p.stE) + M,
+                      M, H, c.layer_norm_eps, none, DS(c.hidden_dropout, DS_ENCIN), st));
+  // ---- a7: encoder layers (post-LN) with LayerDrop
+  e->keep.assign(c.num_layers, 1);
+  const float scale = 1.f / sqrtf((float)hd);
+  for (int l = 0; l < c.num_layers; ++l) {
+    if (tr && layer_keep && !layer_keep[l]) {
+      e->keep[l] = 0;
+      // skipped layer: output = input (modeling_wav2vec2.py:701-712)
+      SSAK_HIP(hipMemcpyAsync(BF(p.x[l + 1]), BF(p.x[l]), (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
+      continue;
+    }
+    const LayerP& L = e->lp[l];
+    const LayerBuf& lb = p.lb[l];
+    const bf16* x = BF(p.x[l]);
+    bf16* qkv = BF(lb.qkv);
+    TRY(Gemm(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
+    TRY(Gemm(F, F, hd).a(qkv, 3 * H).b(qkv + H, 3 * H).c(FP(p.S), Fp, true).alpha(scale)
+            .batch(B, nh, (long)F * 3 * H, hd, (long)F * 3 * H, hd, (long)nh * F * Fp, (long)F * Fp).run(st));
+    TRY(k_softmax_fwd(FP(p.S), BF(lb.P), lb.Pd != lb.P ? BF(lb.Pd) : nullptr, flens, B * nh * F, F, Fp, nh * F,
+                      DS(c.attention_dropout, ds_attn(l)), st));
+    TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
+            .batch(B, nh, (long)nh * F * Fp, (long)F * Fp, (long)F * 3 * H, hd, (long)F * H, hd).run(st));
+    TRY(Gemm(M, H, H).a(BF(lb.ctx), H).b(W + L.wo, H).c(BF(p.tmpH), H).with_bias(P + L.bo).run(st));
+    float* stl = FP(lb.st);
+    TRY(k_layernorm_fwd(BF(p.tmpH), x, P + L.ln1w, P + L.ln1b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
+                        c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    TRY(Gemm(M, I, H).a(BF(lb.x1), H).b(W + L.w1, H).c(BF(lb.f1), I).with_bias(P + L.b1)
+            .epi(SSAK_EPI_GELU, nullptr, BF(lb.f1pre)).drop(tr ? c.activation_dropout : 0.f, ds_act(l), seed).run(st));
+    TRY(Gemm(M, H, I).a(BF(lb.f1), I).b(W + L.w2, I).c(BF(p.tmpH), H).with_bias(P + L.b2).run(st));
+    TRY(k_layernorm_fwd(BF(p.tmpH), BF(lb.x1), P + L.ln2w, P + L.ln2b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M,
+                        M, H, c.layer_norm_eps, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+  }
+  // ---- a8: final dropout + lm_head -> fp32 logits
+  const bf16* xl = BF(p.x[c.num_layers]);
+  if (tr && c.final_dropout > 0.f) {
+    TRY(k_layernorm_fwd(xl, nullptr, nullptr, nullptr, BF(p.xf), nullptr, nullptr, nullptr, M, H, 0.f,
+                        DS(c.final_dropout, DS_FINAL), none, st));
+    xl = BF(p.xf);
+  }
+  TRY(Gemm(M, V, H).a(xl, H).b(W + e->p_lm_w, H).c(logits, V, true).with_bias(P + e->p_lm_b).run(st));
+  e->have_fwd = tr;
+  return SSAK_OK;
+}
+
+extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  SSAK_REQUIRE(e && dlogits && workspace, "w2v2_backward: null pointer");
+  if (!e->have_fwd) {
+    ssak_set_error("w2v2_backward: no training-mode forward to differentiate");
+    return SSAK_ERR_STATE;
+  }
+  SSAK_REQUIRE(e->G, "w2v2_backward: no gradient buffer bound");
+  SSAK_REQUIRE(e->cfg.freeze_feature_encoder, "w2v2_backward: feature-encoder gradients (--no_freeze) are not built in this round");
+  Plan& p = e->plan;
+  SSAK_REQUIRE(workspace_bytes >= p.total, "w2v2_backward: workspace too small");
+  const ssak_w2v2_config& c = e->cfg;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto BF = [&](size_t off) { return (bf16*)(ws + off); };
+  auto FP = [&](size_t off) { return (float*)(ws + off); };
+  const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads, hd = H / nh;
+  const int nc = c.num_conv_layers, C = c.conv_dim[nc - 1], K = c.num_conv_pos_embeddings;
+  const int G = c.num_conv_pos_embedding_groups, cg = H / G;
+  const int B = p.B, F = p.F, M = p.M, Fp = p.Fp;
+  const float* P = e->P;
+  float* Gd = e->G;
+  const bf16* W = e->W;
+  const uint64_t seed = e->seed;
+  const int32_t* flens = e->lens ? (const int32_t*)(ws + p.flens) : nullptr;
+  auto DS = [&](float prob, uint32_t stream_id) {
+    DropSpec d;
+    d.seed = seed;
+    d.stream = stream_id;
+    d.p = prob;
+    return d;
+  };
+  const DropSpec none;
+  void* slab = ws + p.slab;
+  const float scale = 1.f / sqrtf((float)hd);
+
+  SSAK_HIP(hipMemsetAsync(Gd, 0, (size_t)e->n_train * sizeof(float), st));
+  // ---- lm_head
+  bf16* dlog = BF(p.dlog);
+  TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
+  const bf16* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
+  TRY(Gemm(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
+  TRY(k_colsum(dlog, V, M, V, Gd + e->p_lm_b, st));
+  bf16* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
+  bf16* gB = nullptr;
+  TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).drop(c.final_dropout, DS_FINAL, seed).run(st));
+  // ---- encoder layers, last to first
+  for (int l = c.num_layers - 1; l >= 0; --l) {
+    if (!e->keep[l]) continue;  // identity layer: gradient passes through unchanged
+    const LayerP& L = e->lp[l];
+    const LayerBuf& lb = p.lb[l];
+    float* stl = FP(lb.st);
+    bf16* dR = BF(p.dC);   // grad wrt r2, then reused
+    bf16* dY = BF(p.dY);
+    const bool hdrop = c.hidden_dropout > 0.f;
+    // final_layer_norm backward: r2 = x1 + drop(ffn)
+    TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, hdrop ? dY : nullptr,
+                        Gd + L.ln2w, Gd + L.ln2b, M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+    const bf16* dy2 = hdrop ? dY : dR;
+    TRY(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true).run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_colsum(dy2, H, M, H, Gd + L.b2, st));
+    TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(BF(p.dI), I)
+            .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed).run(st));
+    TRY(Gemm(I, H, M).a(BF(p.dI), I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true).run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_colsum(BF(p.dI), I, M, I, Gd + L.b1, st));
+    bf16* dX = BF(p.dB);
+    TRY(Gemm(M, H, I).a(BF(p.dI), I).b(W + L.w1, H, true).c(dX, H).run(st));
+    // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
+    bf16* dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
+    TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, hdrop ? dY : nullptr, Gd + L.ln1w,
+                        Gd + L.ln1b, M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    const bf16* dy1 = hdrop ? dY : dR1;
+    TRY(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true).run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_colsum(dy1, H, M, H, Gd + L.bo, st));
+    bf16* dctx = BF(p.dC);
+    TRY(Gemm(M, H, H).a(dy1, H).b(W + L.wo, H, true).c(dctx, H).run(st));
+    // attention backward per (utterance, head)
+    bf16* qkv = BF(lb.qkv);
+    bf16* dqkv = BF(p.dqkv);
+    const long sq1 = (long)F * 3 * H, sp1 = (long)nh * F * Fp, sp2 = (long)F * Fp, sh1 = (long)F * H;
+    TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
+            .batch(B, nh, sp1, sp2, sh1, hd, sq1, hd).run(st));  // dV = Pd^T dctx
+    TRY(Gemm(F, F, hd).a(dctx, H).b(qkv + 2 * H, 3 * H).c(FP(p.S), Fp, true)
+            .batch(B, nh, sh1, hd, sq1, hd, sp1, sp2).run(st));  // dPd = dctx V^T
+    TRY(k_softmax_bwd(FP(p.S), BF(lb.P), BF(p.dSb), B * nh * F, F, Fp, DS(c.attention_dropout, ds_attn(l)), st));
+    TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp).b(qkv + H, 3 * H, true).c(dqkv, 3 * H).alpha(scale)
+            .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dQ = scale dS K
+    TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
+            .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
+    TRY(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true).run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st));
+    TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
+    // gradient w.r.t. this layer's input = dR1 (residual of r1) + dX
+    gA = dR1;
+    gB = dX;
+  }
+  // ---- encoder input: x0 = drop(LN(h1)), h1 = h0 + gelu(posconv(h0))
+  bf16* dh1 = BF(p.dC);
+  TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->p_eln_w, nullptr, dh1, nullptr, Gd + e->p_eln_w,
+                      Gd + e->p_eln_b, M, H, none, DS(c.hidden_dropout, DS_ENCIN), st));
+  bf16* dpre = BF(p.dY);
+  TRY(k_gelu_grad_mul(dh1, BF(p.pc_pre), dpre, (long)M * H, st));
+  TRY(k_colsum(dpre, H, M, H, Gd + e->p_pc_b, st));
+  TRY(k_posconv_pack(dpre, BF(p.pgdy), B, F, H, G, K, st));
+  {
+    const int lead = K / 2, RS = F + K;
+    // dW[g][n][tap*cg + c] = sum over packed rows of dy[row][n] * x[row + tap][c]   (one long-K GEMM per group)
+    TRY(Gemm(cg, K * cg, B * RS)
+            .a(BF(p.pgdy) + (long)lead * cg, cg, true)
+            .b(BF(p.pgx), cg, true)
+            .c(FP(p.dwf), (long)K * cg, true)
+            .batch(1, G, 0, p.pg_rows * cg, 0, p.pg_rows * cg, 0, (long)cg * K * cg)
+            .run(st));
+    TRY(k_posconv_weight_bwd(FP(p.dwf), P + e->p_pc_g, P + e->p_pc_v, e->pc_norms, Gd + e->p_pc_g, Gd + e->p_pc_v, H, G, K, st));
+    // input gradient: correlation of dy with the flipped, transposed taps
+    const int shift = 2 * (K / 2) - K + 1;  // 1 for even K (SamePad drops the last frame), 0 for odd
+    TRY(Gemm(F, cg, K * cg)
+            .a(BF(p.pgdy) + (long)shift * cg, cg)
+            .b(e->pc_wb, (long)K * cg)
+            .c(BF(p.dB), H)
+            .batch(B, G, (long)RS * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
+            .run(st));
+  }
+  bf16* dh0 = BF(p.dA);
+  TRY(k_add_bf16(dh1, BF(p.dB), dh0, (long)M * H, st));
+  TRY(k_specaug_bwd(dh0, e->spec_mask, flens, Gd + e->p_mse, B, F, H, st));
+  // ---- feature projection
+  const bf16* dh0d = dh0;
+  if (c.feat_proj_dropout > 0.f) {
+    // replay the projection-output dropout mask on the gradient
+    TRY(k_layernorm_fwd(dh0, nullptr, nullptr, nullptr, BF(p.scratchH), nullptr, nullptr, nullptr, M, H, 0.f,
+                        DS(c.feat_proj_dropout, DS_FEATPROJ), none, st));
+    dh0d = BF(p.scratchH);
+  }
+  TRY(Gemm(H, C, M).a(dh0d, H, true).b(BF(p.ln0), C, true).c(Gd + e->p_fp_w, C, true).run_wgrad(st, slab, p.slab_bytes));
+  TRY(k_colsum(dh0d, H, M, H, Gd + e->p_fp_b, st));
+  TRY(Gemm(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
+  TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, BF(p.ln0), nullptr,
+                      Gd + e->p_fpln_w, Gd + e->p_fpln_b, M, C, none, none, st));
+  e->have_fwd = false;
+  return SSAK_OK;
+}

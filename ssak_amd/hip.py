@@ -19,7 +19,19 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long), ("nb1", C.c_int), ("nb2", C.c_int),
                 ("sa1", C.c_long), ("sa2", C.c_long), ("sb1", C.c_long), ("sb2", C.c_long), ("sc1", C.c_long),
                 ("sc2", C.c_long), ("alpha", C.c_float), ("epilogue", C.c_int), ("out_f32", C.c_int),
-                ("accumulate", C.c_int), ("split_k", C.c_int)]
+                ("accumulate", C.c_int), ("split_k", C.c_int), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
+                ("drop_seed", C.c_uint64), ("bias_s2", C.c_long)]
+
+
+class W2V2Config(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("hidden_size", C.c_int), ("num_layers", C.c_int), ("num_heads", C.c_int),
+                ("intermediate_size", C.c_int), ("num_conv_layers", C.c_int), ("conv_dim", C.c_int * 8),
+                ("conv_kernel", C.c_int * 8), ("conv_stride", C.c_int * 8), ("conv_bias", C.c_int),
+                ("feat_extract_norm", C.c_int), ("do_stable_layer_norm", C.c_int),
+                ("num_conv_pos_embeddings", C.c_int), ("num_conv_pos_embedding_groups", C.c_int),
+                ("layer_norm_eps", C.c_float), ("attention_dropout", C.c_float), ("hidden_dropout", C.c_float),
+                ("activation_dropout", C.c_float), ("feat_proj_dropout", C.c_float), ("final_dropout", C.c_float),
+                ("freeze_feature_encoder", C.c_int)]
 
 
 def _load():
@@ -37,6 +49,21 @@ def _load():
         "ssak_ctc_loss_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]),
         "ssak_ctc_greedy_decode": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "ssak_grad_sumsq": (i32, [vp, C.c_long, vp, vp]),
+        "ssak_adamw_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+        "ssak_w2v2_create": (i32, [C.POINTER(W2V2Config), C.POINTER(vp)]),
+        "ssak_w2v2_destroy": (None, [vp]),
+        "ssak_w2v2_num_params": (C.c_long, [vp]),
+        "ssak_w2v2_num_trainable": (C.c_long, [vp]),
+        "ssak_w2v2_param_count": (i32, [vp]),
+        "ssak_w2v2_param_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(C.c_long), C.POINTER(C.c_long),
+                                       C.POINTER(i32), C.POINTER(C.c_long)]),
+        "ssak_w2v2_bind": (i32, [vp, vp, vp, vp]),
+        "ssak_w2v2_sync_weights": (i32, [vp, i32, vp]),
+        "ssak_w2v2_num_frames": (i32, [vp, i32]),
+        "ssak_w2v2_workspace_bytes": (sz, [vp, i32, i32, i32]),
+        "ssak_w2v2_forward": (i32, [vp, vp, vp, i32, i32, vp, vp, C.c_uint64, i32, vp, vp, vp, sz, vp]),
+        "ssak_w2v2_backward": (i32, [vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -56,6 +83,8 @@ def check(rc: int):
     msg = lib.ssak_last_error().decode()
     if rc == SSAK_ERR_INVALID:
         raise ValueError(msg)
+    if rc == SSAK_ERR_STATE:
+        raise RuntimeError(msg)
     raise RuntimeError(f"libssak_hip status {rc}: {msg}")
 
 
@@ -119,10 +148,11 @@ def ctc_greedy_decode(logits: torch.Tensor, in_lens: torch.Tensor | None = None,
 
 def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
-         accumulate=False, split_k=1):
+         accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0):
     """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h)."""
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
-                 sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k)
+                 sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k, float(drop_p),
+                 drop_stream, drop_seed, 0)
     ws = _ws(split_k * nb1 * nb2 * M * N * 4, A.device) if split_k > 1 else None
     check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
                              0 if ws is None else ws.numel(), stream()))

@@ -1,0 +1,244 @@
+"""Host-side mirror of the acoustic-model interface the reference calls.
+
+``Wav2Vec2ForCTC`` keeps the call contract of ``transformers.Wav2Vec2ForCTC`` as used by SSAK --
+``model(input_values, attention_mask=..., labels=...)`` returning ``.loss`` / ``.logits``
+(ssak/train/transformers/wav2vec_train.py:387-415 via HF Trainer; ssak/infer/transformers_infer.py:235) --
+but every tensor operation runs in ``libssak_hip.so`` (HIP kernels for gfx950).  torch supplies device
+buffers, the stream and (in ``ssak_amd.trainer``) the RCCL process group; nothing else.
+
+State lives in four flat fp32 device buffers (params, grads, exp_avg, exp_avg_sq) plus one bf16 shadow,
+laid out by the engine (``ssak_w2v2_param_info``); ``state_dict``/``load_state_dict`` speak the HF names.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import hip
+from .config import Wav2Vec2Config
+
+
+class CTCOutput:
+    __slots__ = ("loss", "logits", "nll", "frame_lens")
+
+    def __init__(self, loss, logits, nll=None, frame_lens=None):
+        self.loss, self.logits, self.nll, self.frame_lens = loss, logits, nll, frame_lens
+
+
+def conv_out_lengths(cfg: Wav2Vec2Config, lengths):
+    """floor((L-k)/s)+1 chained over the conv layers (transformers modeling_wav2vec2.py:997-1016)."""
+    L = np.asarray(lengths, dtype=np.int64)
+    for k, s in zip(cfg.conv_kernel, cfg.conv_stride):
+        L = np.floor_divide(L - k, s) + 1
+    return L
+
+
+def compute_mask_indices(shape, mask_prob, mask_length, lengths=None, min_masks=0, rng=np.random) -> np.ndarray:
+    """SpecAugment span sampling with the draw order of HF ``_compute_mask_indices``
+    (transformers modeling_wav2vec2.py:101-217): one uniform for the probabilistic rounding, then one
+    ``choice`` without replacement per utterance.  Host-side like the reference, off the device's critical path."""
+    B, S = shape
+    if mask_length > S:
+        raise ValueError("`mask_length` has to be smaller than `sequence_length`")
+    eps = rng.rand(1).item()
+
+    def nspan(L):
+        n = max(int(mask_prob * L / mask_length + eps), min_masks)
+        if n * mask_length > S:
+            n = S // mask_length
+        if L - (mask_length - 1) < n:
+            n = max(L - (mask_length - 1), 0)
+        return n
+
+    mask = np.zeros((B, S), dtype=bool)
+    nmax = nspan(S)
+    if nmax == 0:
+        return mask
+    for b in range(B):
+        L = S if lengths is None else int(lengths[b])
+        n = nspan(L)
+        idx = rng.choice(np.arange(L - (mask_length - 1)), n, replace=False)
+        dummy = S - 1 if len(idx) == 0 else idx[0]
+        idx = np.concatenate([idx, np.ones(nmax - n, dtype=np.int32) * dummy])
+        span = np.minimum(idx[:, None] + np.arange(mask_length)[None, :], S - 1).reshape(-1)
+        mask[b, span.astype(np.int64)] = True
+    return mask
+
+
+class Wav2Vec2ForCTC:
+    def __init__(self, config: Wav2Vec2Config, device: str = "cuda:0", freeze_feature_encoder: bool = True,
+                 seed: int = 69):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ssak_amd needs an MI355X: there is no CPU fallback for the acoustic model")
+        self.config = config
+        self.device = torch.device(device)
+        self.training = False
+        self.freeze = freeze_feature_encoder
+        c = hip.W2V2Config()
+        c.vocab_size, c.hidden_size, c.num_layers = config.vocab_size, config.hidden_size, config.num_hidden_layers
+        c.num_heads, c.intermediate_size = config.num_attention_heads, config.intermediate_size
+        c.num_conv_layers = len(config.conv_dim)
+        for i, (d, k, s) in enumerate(zip(config.conv_dim, config.conv_kernel, config.conv_stride)):
+            c.conv_dim[i], c.conv_kernel[i], c.conv_stride[i] = d, k, s
+        c.conv_bias = int(config.conv_bias)
+        c.feat_extract_norm = {"group": 0, "layer": 1}[config.feat_extract_norm]
+        c.do_stable_layer_norm = int(config.do_stable_layer_norm)
+        c.num_conv_pos_embeddings = config.num_conv_pos_embeddings
+        c.num_conv_pos_embedding_groups = config.num_conv_pos_embedding_groups
+        c.layer_norm_eps = config.layer_norm_eps
+        c.attention_dropout, c.hidden_dropout = config.attention_dropout, config.hidden_dropout
+        c.activation_dropout, c.feat_proj_dropout = config.activation_dropout, config.feat_proj_dropout
+        c.final_dropout = config.final_dropout
+        c.freeze_feature_encoder = int(freeze_feature_encoder)
+        self._c = c
+        h = C.c_void_p()
+        hip.check(hip.lib.ssak_w2v2_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self.num_params = hip.lib.ssak_w2v2_num_params(h)
+        self.num_trainable = hip.lib.ssak_w2v2_num_trainable(h)
+        self.layout: Dict[str, tuple] = {}
+        name = C.create_string_buffer(256)
+        off, numel, nd = C.c_long(), C.c_long(), C.c_int()
+        shp = (C.c_long * 4)()
+        for i in range(hip.lib.ssak_w2v2_param_count(h)):
+            hip.check(hip.lib.ssak_w2v2_param_info(h, i, name, 256, C.byref(off), C.byref(numel), C.byref(nd), shp))
+            self.layout[name.value.decode()] = (off.value, numel.value, tuple(shp[j] for j in range(nd.value)))
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(self.num_params, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.num_params, dtype=torch.float32, device=self.device)
+            self.shadow = torch.zeros(self.num_params, dtype=torch.bfloat16, device=self.device)
+        hip.check(hip.lib.ssak_w2v2_bind(h, hip.ptr(self.params), hip.ptr(self.grads), hip.ptr(self.shadow)))
+        self._ws = None
+        self._ws_key = None
+        self._step_seed = np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0]
+        self._host_rng = np.random.RandomState(seed)
+        self._last = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            hip.lib.ssak_w2v2_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------ parameters
+    def param(self, name: str) -> torch.Tensor:
+        off, n, shape = self.layout[name]
+        return self.params[off:off + n].view(shape)
+
+    def grad(self, name: str) -> torch.Tensor:
+        off, n, shape = self.layout[name]
+        return self.grads[off:off + n].view(shape)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {n: self.param(n).detach().cpu().clone() for n in self.layout}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        missing = [n for n in self.layout if n not in sd]
+        extra = [n for n in sd if n not in self.layout]
+        if strict and (missing or extra):
+            raise RuntimeError(f"state_dict mismatch: missing {missing[:4]} unexpected {extra[:4]}")
+        for n, (off, numel, shape) in self.layout.items():
+            if n in sd:
+                t = torch.as_tensor(sd[n]).to(torch.float32)
+                if tuple(t.shape) != shape:
+                    raise RuntimeError(f"size mismatch for {n}: {tuple(t.shape)} vs {shape}")
+                self.params[off:off + numel].copy_(t.reshape(-1).to(self.device), non_blocking=True)
+        self.sync_weights(full=True)
+        return self
+
+    def sync_weights(self, full: bool = True):
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib.ssak_w2v2_sync_weights(self._h, int(full), hip.stream()))
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def freeze_feature_encoder(self):
+        if not self.freeze:
+            raise RuntimeError("construct the model with freeze_feature_encoder=True")
+        return self
+
+    def num_frames(self, T: int) -> int:
+        return hip.lib.ssak_w2v2_num_frames(self._h, int(T))
+
+    # ------------------------------------------------------------------ forward / backward
+    def _workspace(self, B, T, training):
+        key = (B, T, bool(training))
+        need = hip.lib.ssak_w2v2_workspace_bytes(self._h, B, T, int(training))
+        if need == 0:
+            raise ValueError(f"input of {T} samples is too short for the feature encoder")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ws_key = key
+        return self._ws
+
+    def __call__(self, input_values, attention_mask=None, labels=None, mask_time_indices=None, layer_keep=None,
+                 lengths=None):
+        return self.forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths)
+
+    def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                labels: Optional[torch.Tensor] = None, mask_time_indices=None, layer_keep=None, lengths=None):
+        cfg = self.config
+        x = input_values.to(device=self.device, dtype=torch.float32).contiguous()
+        B, T = x.shape
+        if attention_mask is not None and lengths is None:
+            lengths = attention_mask.to(self.device).sum(-1)
+        lens_dev = None
+        if lengths is not None:
+            lens_dev = torch.as_tensor(lengths).to(device=self.device, dtype=torch.int32).contiguous()
+        F = self.num_frames(T)
+        training = self.training
+        if labels is not None:
+            labels = torch.as_tensor(labels)
+            if labels.numel() and int(labels.max()) >= cfg.vocab_size:
+                raise ValueError(f"Label values must be <= vocab_size: {cfg.vocab_size}")
+        ws = self._workspace(B, T, training)
+        # stochastic regularisers drawn on the host ahead of the step, as the reference does
+        mask_dev, keep_arr = None, None
+        if training:
+            if mask_time_indices is None and cfg.mask_time_prob > 0:
+                fl = None if lengths is None else conv_out_lengths(cfg, torch.as_tensor(lengths).cpu().numpy())
+                mask_time_indices = compute_mask_indices((B, F), cfg.mask_time_prob, cfg.mask_time_length, fl,
+                                                         cfg.mask_time_min_masks, rng=self._host_rng)
+            if layer_keep is None and cfg.layerdrop > 0:
+                layer_keep = self._host_rng.rand(cfg.num_hidden_layers) >= cfg.layerdrop
+        if mask_time_indices is not None:
+            mask_dev = torch.as_tensor(np.ascontiguousarray(mask_time_indices)).to(torch.uint8).to(self.device, non_blocking=True)
+        if layer_keep is not None:
+            keep_arr = (C.c_uint8 * cfg.num_hidden_layers)(*[int(bool(k)) for k in layer_keep])
+        self._step_seed = (int(self._step_seed) * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        logits = torch.empty((B, F, cfg.vocab_size), dtype=torch.float32, device=self.device)
+        flens = torch.empty(B, dtype=torch.int32, device=self.device) if lens_dev is not None else None
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib.ssak_w2v2_forward(self._h, hip.ptr(x), hip.ptr(lens_dev), B, T, hip.ptr(mask_dev), keep_arr,
+                                                C.c_uint64(int(self._step_seed)), int(training), hip.ptr(logits),
+                                                hip.ptr(flens), hip.ptr(ws), ws.numel(), hip.stream()))
+            loss = nll = dlogits = None
+            if labels is not None:
+                loss, nll, dlogits = hip.ctc_loss(logits, flens, labels, cfg.pad_token_id, cfg.ctc_loss_reduction,
+                                                  cfg.ctc_zero_infinity, 1.0, want_grad=training)
+        self._last = (dlogits, mask_dev, lens_dev, x) if training else None
+        return CTCOutput(loss, logits, nll, flens)
+
+    def backward(self, grad_scale: float = 1.0):
+        """d loss / d params into ``self.grads`` (the counterpart of ``loss.backward()``)."""
+        if self._last is None or self._last[0] is None:
+            raise RuntimeError("backward() needs a training-mode forward with labels")
+        dlogits = self._last[0]
+        if grad_scale != 1.0:
+            dlogits = dlogits * grad_scale
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib.ssak_w2v2_backward(self._h, hip.ptr(dlogits), hip.ptr(self._ws), self._ws.numel(), hip.stream()))
+        self._last = None
+
+    def named_grads(self):
+        return {n: self.grad(n) for n, (off, _, _) in self.layout.items() if off < self.num_trainable}
