@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: utterances/sec of one full Wav2Vec2-base CTC train step on N MI355X.
+
+Metric and config are BASELINE.json's: 16 kHz x 10 s utterances, Wav2Vec2-base (Wav2Vec2Config() defaults),
+bf16 compute, feature encoder frozen, CTC reduction "mean", the train script's regularisers on
+(ssak/train/transformers/wav2vec_train.py:161-165,313-329), AdamW + clip.  A step = waveform normalise ->
+forward -> CTC loss+grad -> backward -> [RCCL all-reduce] -> grad-norm clip + AdamW, on a synthetic batch that is
+already resident in HBM.  One process per GPU; for N > 1 launch under torch.distributed.run (weak scaling:
+the per-GPU batch is fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GF_PER_UTT_TRAIN = 346.32  # algorithmic GFLOP per 10 s utterance, train step, frozen feature encoder
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec)
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (the reference uses
+    every core it sees, ssak/utils/env.py:86-90; oversubscribing a quota-limited box only slows it down)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, int(os.environ.get("SSAK_CPU_THREADS", "64"))))
+
+
+def cpu_baseline(budget_s: float = 25.0):
+    """The CPU restatement (oracle, eager torch fp32 on all host cores as ssak/utils/env.py:86-90 does) timed on a
+    bounded sample of the same workload: full train steps (forward + backward + AdamW) at B=2."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.synth import synth_batch
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = R.W2V2Config.base()
+    p = {n: t.clone().requires_grad_(not R.is_feature_encoder_param(n)) for n, t in R.init_params(cfg, 69).items()}
+    opt = torch.optim.AdamW([t for t in p.values() if t.requires_grad], lr=1e-4, weight_decay=0.0)
+    B = 2
+    waves, labels = synth_batch(B, 160000, seed=99)
+    x = torch.tensor(R.zero_mean_unit_var_norm(list(waves)))
+    lab = torch.tensor(labels)
+    rs = np.random.RandomState(0)
+    times = []
+    t_all = time.time()
+    while len(times) < 3 and (time.time() - t_all) < budget_s:
+        t0 = time.time()
+        mask = torch.tensor(R.compute_mask_indices((B, 499), cfg.mask_time_prob, cfg.mask_time_length, None, 2, rng=rs))
+        keep = rs.rand(cfg.num_hidden_layers) >= cfg.layerdrop
+        loss, _ = R.forward(p, cfg, x, None, lab, train=True, mask_time_indices=mask, layer_keep=keep)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([t for t in p.values() if t.requires_grad], 1.0)
+        opt.step()
+        times.append(time.time() - t0)
+    best = min(times)
+    return {"value": round(B / best, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full train steps (fwd+bwd+clip+AdamW, no gradient checkpointing) of oracle/w2v2_ref.py, "
+                      f"eager torch fp32, B={B} x 10 s, best step {best:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched under torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from ssak_amd import hip
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.synth import synth_batch
+    from ssak_amd.trainer import AdamW, Trainer
+
+    cfg = Wav2Vec2Config()  # wav2vec2-base + the train script's regularisers
+    model = Wav2Vec2ForCTC(cfg, device=dev, freeze_feature_encoder=True, seed=69).train()
+    # seeded random init of the architecture (no network for checkpoints): same scales as HF's _init_weights
+    g = torch.Generator(device="cpu").manual_seed(69)
+    sd = {}
+    for name, (off, n, shape) in model.layout.items():
+        if name.endswith("layer_norm.weight"):
+            t = torch.ones(shape)
+        elif name.endswith(".bias"):
+            t = torch.zeros(shape)
+        elif name.endswith("masked_spec_embed"):
+            t = torch.rand(shape, generator=g)
+        elif ".conv.weight" in name or name.endswith("original1"):
+            t = torch.randn(shape, generator=g) * (2.0 / (shape[1] * shape[2])) ** 0.5
+        else:
+            t = torch.randn(shape, generator=g) * 0.02
+        sd[name] = t
+    v = sd["wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
+    sd["wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    model.load_state_dict(sd)
+    opt = AdamW(model, lr=1e-4, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=500, total_steps=100000)
+    trainer = Trainer(model, opt)
+    trainer.broadcast_parameters()
+
+    T = int(round(args.seconds * 16000))
+    B = args.batch
+    waves_np, labels_np = synth_batch(B, T, seed=1234 + rank)
+    waves = torch.tensor(waves_np).to(dev)
+    labels = torch.tensor(labels_np).to(dev)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(waves, None, labels)
+    sync()
+    hip.prof_enable(True)
+    hip.prof_collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(waves, None, labels)
+    sync()
+    dt = time.perf_counter() - t0
+    hip.prof_enable(False)
+    prof = hip.prof_collect()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        utts = B * world * args.steps
+        value = utts / dt
+        # dominant kernel = the GEMM instantiation with the largest summed duration over the timed region
+        prof = [p for p in prof if p[1] > 0]
+        prof.sort(key=lambda p: -p[2])
+        roof = None
+        if prof:
+            name, launches, ms, flops = prof[0]
+            ach = flops / (ms * 1e-3) / 1e12
+            gemm_ms = sum(p[2] for p in prof)
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches // args.steps, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                    "all_gemm_tflops": round(sum(p[3] for p in prof) / (gemm_ms * 1e-3) / 1e12, 1),
+                    "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 3),
+                    "whole_step_tflops": round(GF_PER_UTT_TRAIN * 1e9 * B * args.steps / dt / 1e12, 1)}
+        out = {"metric": "utterances/sec (16 kHz, 10 s) Wav2Vec2-base CTC train step", "value": round(value, 2),
+               "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "Wav2Vec2-base CTC fine-tune step, bf16, synthetic 10 s @16 kHz utterances "
+                                      "(BASELINE.json configs[1]; DP over xGMI for n_gpus>1 = configs[2])",
+                          "per_gpu_batch": B, "global_batch": B * world, "samples_per_utt": T, "frames": model.num_frames(T),
+                          "frozen_feature_encoder": True, "regularisers": "script defaults (dropout/layerdrop/specaugment on)",
+                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

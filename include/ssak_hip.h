@@ -93,6 +93,18 @@ typedef struct {
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-launch GEMM timing for the roofline report (measurement aid, not on the reference's path): while
+ * enabled, every GEMM launch is bracketed by HIP events on its own stream; ssak_prof_collect waits for them and
+ * returns, per kernel instantiation (named as rocprofv3 prints it), launches / summed ms / algorithmic FLOPs. */
+typedef struct {
+  char name[64];
+  long launches;
+  double total_ms;
+  double total_flops;
+} ssak_prof_entry;
+int ssak_prof_enable(int on);
+int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* returns the number of entries (8) */
+
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer
  * (docker/transformers_modified/trainer.py:1827-1855; ssak/train/transformers/wav2vec_train.py:353-384).

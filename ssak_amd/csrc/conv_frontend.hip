@@ -14,14 +14,15 @@
 
 namespace {
 
-constexpr int KS0 = 10, ST0 = 5, FR0 = 128;  // conv0 taps / stride / frames per workgroup
-constexpr int NS0 = (FR0 - 1) * ST0 + KS0;
+constexpr int KS0 = 10, ST0 = 5;  // conv0 taps / stride
+constexpr int FR_STATS = 1024, FR_APPLY = 128;  // frames per workgroup (statistics pass: few, contended fp64 atomics)
 
-template <bool APPLY>
+template <bool APPLY, int FR0>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     bf16* __restrict__ out, double* __restrict__ stats, int T, int T0,
                                                     int C) {
+  constexpr int NS0 = (FR0 - 1) * ST0 + KS0;
   __shared__ float xs[NS0];
   __shared__ float red[256][9];
   const int b = blockIdx.y;
@@ -187,10 +188,9 @@ int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const fl
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
   SSAK_REQUIRE(T0 == (T - KS0) / ST0 + 1 && T0 > 0, "conv0: T0 mismatch");
   SSAK_HIP(hipMemsetAsync(stats, 0, (size_t)B * C * 2 * sizeof(double), st));
-  dim3 grid(ssak_cdiv(T0, FR0), B);
-  conv0_kernel<false><<<grid, 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
+  conv0_kernel<false, FR_STATS><<<dim3(ssak_cdiv(T0, FR_STATS), B), 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
   SSAK_LAUNCH_CHECK();
-  conv0_kernel<true><<<grid, 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
+  conv0_kernel<true, FR_APPLY><<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

@@ -13,6 +13,8 @@
 // 16x16x32 bf16 MFMAs.  The MFMA is issued with the operands swapped so each lane ends up with 4
 // consecutive output columns (8-/16-byte stores).  Workgroup ids are remapped so that each XCD's L2 sees a
 // contiguous run of tiles sharing the same A row panel.
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -325,6 +327,31 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
   }
 }
 
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events around every GEMM launch ----
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int variant;
+  double flops;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t prof_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+const char* kVariantNames[8] = {
+    "gemm_kernel<128, 128, 2, 2, false, false>", "gemm_kernel<128, 128, 2, 2, false, true>",
+    "gemm_kernel<128, 128, 2, 2, true, false>",  "gemm_kernel<128, 128, 2, 2, true, true>",
+    "gemm_kernel<128, 64, 2, 2, false, false>",  "gemm_kernel<128, 64, 2, 2, false, true>",
+    "gemm_kernel<128, 64, 2, 2, true, false>",   "gemm_kernel<128, 64, 2, 2, true, true>"};
+
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
 int launch(const GemmParams& p, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(Tile<BM, A_KM>::BYTES + Tile<BN, B_KM>::BYTES);
@@ -337,8 +364,20 @@ int launch(const GemmParams& p, hipStream_t st) {
     }
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
+  ProfRec rec;
+  if (g_prof_on) {
+    rec.e0 = prof_event();
+    rec.e1 = prof_event();
+    rec.variant = (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
+    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
+    (void)hipEventRecord(rec.e0, st);
+  }
   kern<<<dim3((unsigned)nblk), NTHREADS, lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.e1, st);
+    g_prof.push_back(rec);
+  }
   return SSAK_OK;
 }
 
@@ -424,4 +463,31 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     SSAK_LAUNCH_CHECK();
   }
   return SSAK_OK;
+}
+
+extern "C" int ssak_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return SSAK_OK;
+}
+
+extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
+  SSAK_REQUIRE(out && cap >= 8, "prof_collect: need room for 8 entries");
+  for (int i = 0; i < 8; ++i) {
+    snprintf(out[i].name, sizeof(out[i].name), "%s", kVariantNames[i]);
+    out[i].launches = 0;
+    out[i].total_ms = 0.0;
+    out[i].total_flops = 0.0;
+  }
+  for (ProfRec& r : g_prof) {
+    SSAK_HIP(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    SSAK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    out[r.variant].launches += 1;
+    out[r.variant].total_ms += ms;
+    out[r.variant].total_flops += r.flops;
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
+  }
+  g_prof.clear();
+  return 8;
 }

@@ -13,8 +13,10 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
                     float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
                     hipStream_t st);
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
-                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta, int M, int C,
-                    const DropSpec& pre, const DropSpec& post, hipStream_t st);
+                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
+                    float* partial /*[LN_BWD_BLOCKS*2*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
+                    hipStream_t st);
+constexpr int LN_BWD_BLOCKS = 512;
 int k_softmax_fwd(const float* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
                   int rows_per_batch, const DropSpec& drop, hipStream_t st);
 int k_softmax_bwd(const float* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,

@@ -6,7 +6,10 @@
 //  * column sums (bias gradients), dtype casts, SpecAugment scatter (:1272-1316)
 // One wave owns one row; 16-byte vector accesses; statistics in fp32; two-pass variance as torch does.
 // Dropout masks are recomputed from (seed, stream, element index) in the backward kernels.
+#include <algorithm>
+
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -131,8 +134,9 @@ struct LnBwdParams {
   const bf16* g_res;  // [M,C] extra gradient added to dr AFTER the LN backward (pre-LN residual stream) or null
   bf16* dr;           // [M,C] grad wrt r (residual path)
   bf16* dy;           // [M,C] grad wrt y = dr * premask/(1-p)  (null when no pre-dropout: use dr)
-  float* dgamma;      // [C] accumulated with atomics
+  float* dgamma;      // [C] += (finalize kernel)
   float* dbeta;
+  float* partial;     // [gridDim.x][2][C] per-workgroup column partials
   int M, C;
   uint64_t seed;
   uint32_t pre_stream, pre_thresh, post_stream, post_thresh;
@@ -157,8 +161,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
       gm[i][k] = (ch < nch) ? p.gamma[ch * 8 + k] : 0.f;
     }
   }
-  const int row0 = wid * p.rows_per_wave;
-  for (int row = row0; row < min(p.M, row0 + p.rows_per_wave); ++row) {
+  for (int row = wid; row < p.M; row += gridDim.x * (ROW_THREADS / 64)) {
     const float mean = p.mean[row], rstd = p.rstd[row];
     float dyv[NCH][8], xh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
@@ -239,10 +242,22 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
         sg += red[0][w][slot][ln];
         sb += red[1][w][slot][ln];
       }
-      atomicAdd(p.dgamma + col, sg);
-      atomicAdd(p.dbeta + col, sb);
+      p.partial[((size_t)blockIdx.x * 2) * p.C + col] = sg;
+      p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + col] = sb;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // one thread per (which, column); sums the per-workgroup partials in a fixed order (deterministic)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * C) return;
+  const int which = e / C, col = e % C;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * 2 + which) * C + col];
+  float* dst = which ? dbeta : dgamma;
+  dst[col] += s;
 }
 
 // ---------------------------------------------------------------------------------------------- softmax
@@ -420,7 +435,6 @@ uint32_t thresh_of(float p) { return p <= 0.f ? 0u : (uint32_t)fminf(4294967295.
 }  // namespace
 
 // ---- internal C++ entry points used by the engine (declared in kernels.h) ------------------------
-#include "kernels.h"
 
 int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
                     float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
@@ -442,16 +456,15 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
 }
 
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
-                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta, int M, int C,
-                    const DropSpec& pre, const DropSpec& post, hipStream_t st) {
+                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
+                    float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm_bwd: C=%d must be a multiple of 8 and <= 1536", C);
-  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, M, C, pre.seed,
+  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, M, C, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
                 pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f, 1};
-  // ~2048 waves in flight; each wave walks a contiguous run of rows and keeps column partials in registers
-  const int waves = 2048;
-  p.rows_per_wave = ssak_cdiv(M, waves);
-  const int grid = ssak_cdiv(ssak_cdiv(M, p.rows_per_wave), ROW_THREADS / 64);
+  // LN_BWD_BLOCKS workgroups of 4 waves stride over the rows and keep column partials in registers
+  p.rows_per_wave = 0;
+  const int grid = std::min(LN_BWD_BLOCKS, ssak_cdiv(M, ROW_THREADS / 64));
   const int nch = ssak_cdiv(C / 8, 64);
   if (nch == 1)
     ln_bwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
@@ -459,6 +472,8 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
     ln_bwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
   else
     ln_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  ln_bwd_finalize_kernel<<<ssak_cdiv(2 * C, 256), 256, 0, st>>>(partial, grid, C, dgamma, dbeta);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

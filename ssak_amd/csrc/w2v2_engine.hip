@@ -58,7 +58,7 @@ struct Plan {
   std::vector<size_t> x;       // L+1 layer inputs/outputs
   std::vector<LayerBuf> lb;
   // backward temporaries
-  size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH;
+  size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH, lnpart;
   size_t slab_bytes = 0;
   size_t total = 0;
 };
@@ -265,6 +265,7 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.pgdy = cv.take((size_t)G * p.pg_rows * (H / G) * b2);
     p.dwf = cv.take((size_t)H * K * (H / G) * sizeof(float));
     p.dln0 = cv.take((size_t)M * C * b2);
+    p.lnpart = cv.take((size_t)LN_BWD_BLOCKS * 2 * std::max(H, C) * sizeof(float));
     // split-K slabs: the largest weight-gradient product is [I,H] (or [3H,H]); at most 32 slices
     const size_t big = (size_t)std::max(std::max(I * H, 3 * H * H), std::max(H * C, V * H));
     p.slab_bytes = big * 32 * sizeof(float);
@@ -657,7 +658,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     const bool hdrop = c.hidden_dropout > 0.f;
     // final_layer_norm backward: r2 = x1 + drop(ffn)
     TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, hdrop ? dY : nullptr,
-                        Gd + L.ln2w, Gd + L.ln2b, M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+                        Gd + L.ln2w, Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
     const bf16* dy2 = hdrop ? dY : dR;
     TRY(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum(dy2, H, M, H, Gd + L.b2, st));
@@ -670,7 +671,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
     bf16* dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
     TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, hdrop ? dY : nullptr, Gd + L.ln1w,
-                        Gd + L.ln1b, M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+                        Gd + L.ln1b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
     const bf16* dy1 = hdrop ? dY : dR1;
     TRY(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum(dy1, H, M, H, Gd + L.bo, st));
@@ -699,7 +700,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   // ---- encoder input: x0 = drop(LN(h1)), h1 = h0 + gelu(posconv(h0))
   bf16* dh1 = BF(p.dC);
   TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->p_eln_w, nullptr, dh1, nullptr, Gd + e->p_eln_w,
-                      Gd + e->p_eln_b, M, H, none, DS(c.hidden_dropout, DS_ENCIN), st));
+                      Gd + e->p_eln_b, FP(p.lnpart), M, H, none, DS(c.hidden_dropout, DS_ENCIN), st));
   bf16* dpre = BF(p.dY);
   TRY(k_gelu_grad_mul(dh1, BF(p.pc_pre), dpre, (long)M * H, st));
   TRY(k_colsum(dpre, H, M, H, Gd + e->p_pc_b, st));
@@ -738,7 +739,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(k_colsum(dh0d, H, M, H, Gd + e->p_fp_b, st));
   TRY(Gemm(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
   TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, BF(p.ln0), nullptr,
-                      Gd + e->p_fpln_w, Gd + e->p_fpln_b, M, C, none, none, st));
+                      Gd + e->p_fpln_w, Gd + e->p_fpln_b, FP(p.lnpart), M, C, none, none, st));
   e->have_fwd = false;
   return SSAK_OK;
 }

@@ -34,6 +34,10 @@ class W2V2Config(C.Structure):
                 ("freeze_feature_encoder", C.c_int)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_long), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+
+
 def _load():
     if not os.path.exists(_LIB_PATH):
         raise ImportError(f"{_LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
@@ -49,6 +53,8 @@ def _load():
         "ssak_ctc_loss_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]),
         "ssak_ctc_greedy_decode": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "ssak_prof_enable": (i32, [i32]),
+        "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
         "ssak_grad_sumsq": (i32, [vp, C.c_long, vp, vp]),
         "ssak_adamw_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
         "ssak_w2v2_create": (i32, [C.POINTER(W2V2Config), C.POINTER(vp)]),
@@ -157,3 +163,16 @@ def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=
     check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
                              0 if ws is None else ws.numel(), stream()))
     return C_out
+
+
+def prof_enable(on: bool):
+    check(lib.ssak_prof_enable(int(on)))
+
+
+def prof_collect():
+    """[(kernel name, launches, total ms, total algorithmic flops)] since the last collect."""
+    arr = (ProfEntry * 8)()
+    n = lib.ssak_prof_collect(arr, 8)
+    if n < 0:
+        check(n)
+    return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops) for i in range(n)]

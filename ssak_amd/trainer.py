@@ -1,0 +1,93 @@
+"""Train step around the HIP engine: forward -> CTC -> backward -> (RCCL all-reduce) -> clip + AdamW.
+
+Mirrors the inner loop the reference gets from HF ``Trainer`` (docker/transformers_modified/trainer.py:1755-1855,
+2504-2548) with the settings of ssak/train/transformers/wav2vec_train.py:353-384: ``optim="adamw_torch"``,
+lr 1e-4, weight_decay 0.0, warm-up 500 steps then linear decay, max_grad_norm 1.0, gradient accumulation 1.
+
+Data parallelism is one process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI): utterances are
+independent through forward/CTC/backward, so the only exchange is ONE sum all-reduce of the flat fp32 gradient
+buffer per step (the reference's single-process ``nn.DataParallel`` gathers to GPU 0 instead, trainer.py:1345-1346).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+from .model import Wav2Vec2ForCTC
+
+
+def linear_warmup_lr(base_lr: float, step: int, warmup_steps: int, total_steps: int) -> float:
+    """lr for 0-based optimizer step ``step`` (transformers.get_linear_schedule_with_warmup)."""
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    return base_lr * max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
+
+
+class AdamW:
+    """Flat-buffer AdamW with fused global-norm clipping (kernels: ssak_grad_sumsq / ssak_adamw_step)."""
+
+    def __init__(self, model: Wav2Vec2ForCTC, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 max_grad_norm=1.0, warmup_steps=500, total_steps=100000):
+        self.model = model
+        self.n = model.num_trainable
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm, self.warmup_steps, self.total_steps = max_grad_norm, warmup_steps, total_steps
+        self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=model.device)
+        self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=model.device)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=model.device)
+        self.step_count = 0
+
+    def current_lr(self) -> float:
+        return linear_warmup_lr(self.lr, self.step_count, self.warmup_steps, self.total_steps)
+
+    def step(self, grad_scale: float = 1.0):
+        m = self.model
+        lr = self.current_lr()
+        self.step_count += 1
+        with torch.cuda.device(m.device):
+            st = hip.stream()
+            hip.check(hip.lib.ssak_grad_sumsq(hip.ptr(m.grads), self.n, hip.ptr(self.gnorm_sq), st))
+            hip.check(hip.lib.ssak_adamw_step(hip.ptr(m.params), hip.ptr(m.grads), hip.ptr(self.exp_avg),
+                                              hip.ptr(self.exp_avg_sq), hip.ptr(m.shadow), self.n, hip.ptr(self.gnorm_sq),
+                                              self.max_grad_norm, grad_scale, lr, self.betas[0], self.betas[1], self.eps,
+                                              self.weight_decay, self.step_count, st))
+        m.sync_weights(full=False)  # the weight-normed positional-conv layouts follow the updated (g, v)
+
+    def grad_norm(self, grad_scale: float = 1.0) -> float:
+        return float(self.gnorm_sq.sqrt().item()) * grad_scale
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.step_count}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+
+
+class Trainer:
+    """One optimizer step per call; data-parallel when a process group is initialised."""
+
+    def __init__(self, model: Wav2Vec2ForCTC, optimizer: AdamW, normalize_on_device: bool = True):
+        self.model, self.opt = model, optimizer
+        self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world = torch.distributed.get_world_size() if self.dist else 1
+        self.normalize_on_device = normalize_on_device
+
+    def broadcast_parameters(self):
+        if self.dist:
+            torch.distributed.broadcast(self.model.params, src=0)
+            self.model.sync_weights(full=True)
+
+    def train_step(self, waves: torch.Tensor, lengths, labels: torch.Tensor, raw: bool = True):
+        """waves [B,T] fp32 on the device (raw samples when ``raw``: normalised here, a1), lengths [B] or None,
+        labels [B,L] (-100 padding).  Returns the (local) loss tensor; no host synchronisation."""
+        m = self.model
+        x = hip.wave_normalize(waves, lengths) if raw else waves
+        out = m(x, lengths=lengths, labels=labels)
+        m.backward()
+        if self.dist:
+            # ONE sum all-reduce of the flat gradient buffer; mean over ranks folded into the optimizer's scale
+            torch.distributed.all_reduce(m.grads[:m.num_trainable])
+        self.opt.step(grad_scale=1.0 / self.world)
+        return out.loss
