@@ -248,16 +248,28 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  // one thread per (which, column); sums the per-workgroup partials in a fixed order (deterministic)
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * C) return;
-  const int which = e / C, col = e % C;
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // workgroup = 64 columns x 16 row groups; fixed summation order (deterministic), then one += per column
+  __shared__ float red[16][65];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + cx;  // index into [2][C]
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * 2 + which) * C + col];
-  float* dst = which ? dbeta : dgamma;
-  dst[col] += s;
+  if (e < 2 * C) {
+    const int which = e / C, col = e % C;
+#pragma unroll 8
+    for (int b = ry; b < nblk; b += 16) s += partial[((size_t)b * 2 + which) * C + col];
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && e < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cx];
+    const int which = e / C, col = e % C;
+    float* dst = which ? dbeta : dgamma;
+    dst[col] += t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- softmax
@@ -473,7 +485,7 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   else
     ln_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
-  ln_bwd_finalize_kernel<<<ssak_cdiv(2 * C, 256), 256, 0, st>>>(partial, grid, C, dgamma, dbeta);
+  ln_bwd_finalize_kernel<<<ssak_cdiv(2 * C, 64), 1024, 0, st>>>(partial, grid, C, dgamma, dbeta);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

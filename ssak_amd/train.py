@@ -1,0 +1,205 @@
+"""Training entry point: the counterpart of ``ssak/train/transformers/wav2vec_train.py`` with the train step on
+HIP kernels.  Same positional arguments and flags (wav2vec_train.py:144-175); HF ``Trainer`` is replaced by
+``ssak_amd.trainer`` (one process per GPU; launch with ``python -m torch.distributed.run --nproc-per-node N
+-m ssak_amd.train ...`` for data parallelism over RCCL).  Output folder naming follows :210-243; evaluation
+computes eval_loss and WER with greedy decoding every ``--eval_steps`` and writes ``trainer_state.json``.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import hip
+from .checkpoint import load_pretrained, save_pretrained
+from .data import (length_grouped_batches, load_audio, load_kaldi, pad_labels, pad_waves, remove_special_words,
+                   shard_batch)
+from .trainer import AdamW, Trainer
+
+
+def hashmd5(obj) -> str:
+    return hashlib.md5(json.dumps(obj, sort_keys=True).encode()).hexdigest()
+
+
+def args_to_str(args, ignore=("gpus", "output_dir", "debug", "online", "disable_first_eval", "train", "valid",
+                              "data_augment_noise", "data_augment_rir")) -> str:
+    """Hyper-parameters encoded in the output folder name (wav2vec_train.py:210-236, ssak/utils/train_utils.py:4-16)."""
+    short = {"max_duration": "mxd", "min_duration": "mnd", "base_model": "bm", "learning_rate": "lr", "batch_size": "bs",
+             "num_epochs": "ne", "weight_decay": "wd", "attention_dropout": "ad", "hidden_dropout": "hd",
+             "feat_proj_dropout": "fd", "layer_dropout": "ld", "mask_time_prob": "mtp", "seed": "s", "eval_steps": "es",
+             "no_freeze": "nf", "data_augment": "da"}
+    parts = []
+    for k, v in sorted(vars(args).items()):
+        if k in ignore:
+            continue
+        if isinstance(v, bool):
+            if v:
+                parts.append(short.get(k, k))
+            continue
+        if isinstance(v, str):
+            v = os.path.basename(v.rstrip("/"))
+        parts.append(f"{short.get(k, k)}-{v}")
+    return "_".join(parts)
+
+
+def word_error_rate(refs, hyps) -> float:
+    """Word-level Levenshtein distance / reference words (the "wer" metric of wav2vec_train.py:107-125)."""
+    errs = tot = 0
+    for r, h in zip(refs, hyps):
+        r, h = r.split(), h.split()
+        d = list(range(len(h) + 1))
+        for i, rw in enumerate(r, 1):
+            prev, d[0] = d[0], i
+            for j, hw in enumerate(h, 1):
+                cur = min(d[j] + 1, d[j - 1] + 1, prev + (rw != hw))
+                prev, d[j] = d[j], cur
+        errs += d[len(h)]
+        tot += len(r)
+    return errs / max(tot, 1)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Train wav2vec2 (CTC) on Kaldi folders, MI355X HIP path",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("train", help="A kaldi folder, or a file containing a list of kaldi folders, with training data")
+    p.add_argument("valid", help="A kaldi folder, or a file containing a list of kaldi folders, with validation data")
+    p.add_argument("--debug", default=False, action="store_true")
+    p.add_argument("--gpus", default=None)
+    p.add_argument("--online", default=False, action="store_true")
+    p.add_argument("--max_duration", default=15, type=int)
+    p.add_argument("--min_duration", default=1, type=int)
+    p.add_argument("--base_model", required=True, type=str, help="Model folder to adapt (HF layout)")
+    p.add_argument("--no_freeze", default=False, action="store_true")
+    p.add_argument("--data_augment", default=False, action="store_true")
+    p.add_argument("--learning_rate", type=float, default=1e-4)
+    p.add_argument("--batch_size", type=int, default=8)
+    p.add_argument("--num_epochs", type=int, default=20)
+    p.add_argument("--weight_decay", type=float, default=0.0)
+    p.add_argument("--attention_dropout", default=0.1, type=float)
+    p.add_argument("--hidden_dropout", default=0.05, type=float)
+    p.add_argument("--feat_proj_dropout", default=0.0, type=float)
+    p.add_argument("--layer_dropout", default=0.1, type=float)
+    p.add_argument("--mask_time_prob", default=0.05, type=float)
+    p.add_argument("--disable_first_eval", default=False, action="store_true")
+    p.add_argument("--seed", default=69, type=int)
+    p.add_argument("--eval_steps", default=400, type=int)
+    p.add_argument("--output_dir", default=".", type=str)
+    return p
+
+
+def prepare(utts, tok):
+    waves = [load_audio(u.path, u.start, u.end) for u in utts]
+    labels = [tok.encode(remove_special_words(u.text)) for u in utts]
+    return waves, labels
+
+
+def evaluate(model, tok, waves, labels, batch_size):
+    model.eval()
+    tot, n, refs, hyps = 0.0, 0, [], []
+    for i in range(0, len(waves), batch_size):
+        x, lens = pad_waves(waves[i:i + batch_size])
+        lab = pad_labels(labels[i:i + batch_size])
+        xd, ld = torch.from_numpy(x).to(model.device), torch.from_numpy(lens).to(model.device)
+        use_mask = model.config.feat_extract_norm == "layer"
+        with torch.cuda.device(model.device):
+            xn = hip.wave_normalize(xd, ld)
+        out = model(xn, lengths=ld if use_mask else None, labels=torch.from_numpy(lab))
+        tot += float(out.loss.item()) * len(x)
+        n += len(x)
+        fl = torch.tensor([model.num_frames(int(l)) for l in lens], dtype=torch.int32)
+        with torch.cuda.device(model.device):
+            dec, cnt = hip.ctc_greedy_decode(out.logits, fl, tok.pad_token_id)
+        dec, cnt = dec.cpu().numpy(), cnt.cpu().numpy()
+        for b in range(len(x)):
+            hyps.append(remove_special_words(tok.decode(dec[b, :cnt[b]], group_tokens=False), glue_apostrophe=False))
+            refs.append(remove_special_words(tok.decode(lab[b], group_tokens=False), glue_apostrophe=False))
+    model.train()
+    return {"eval_loss": tot / max(n, 1), "eval_wer": word_error_rate(refs, hyps)}
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.data_augment:
+        raise NotImplementedError("--data_augment (CPU DSP: audiomentations / RIR) is outside the HIP path")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    train_u = load_kaldi(args.train, args.min_duration, args.max_duration)
+    valid_u = load_kaldi(args.valid, args.min_duration, args.max_duration)
+    if args.debug:
+        train_u, valid_u = train_u[:64], valid_u[:16]
+    name = "hf_" + hashmd5([u.path for u in train_u])[:8] + "_" + args_to_str(args)
+    out_dir = os.path.join(args.output_dir, name)
+    model, tok = load_pretrained(args.base_model, device=dev, attention_dropout=args.attention_dropout,
+                                 hidden_dropout=args.hidden_dropout, feat_proj_dropout=args.feat_proj_dropout,
+                                 mask_time_prob=args.mask_time_prob, layerdrop=args.layer_dropout,
+                                 ctc_loss_reduction="mean", ctc_zero_infinity=True, pad_token_id=tok_pad(args.base_model))
+    if args.no_freeze:
+        raise NotImplementedError("--no_freeze: feature-encoder gradients are not built yet")
+    model.train()
+    tw, tl = prepare(train_u, tok)
+    vw, vl = prepare(valid_u, tok)
+    steps_per_epoch = max(1, len(tw) // args.batch_size)
+    total = round(args.num_epochs * len(tw) / args.batch_size)
+    opt = AdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay, warmup_steps=500, total_steps=max(total, 1))
+    trainer = Trainer(model, opt)
+    trainer.broadcast_parameters()
+    state = {"log_history": [], "global_step": 0, "max_steps": total}
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        if not args.disable_first_eval:
+            with open(os.path.join(out_dir, "init_eval.json"), "w") as f:
+                json.dump(evaluate(model, tok, vw, vl, args.batch_size), f, indent=1)
+    rng = np.random.RandomState(args.seed)
+    use_mask = model.config.feat_extract_norm == "layer"
+    step, t0, run_loss = 0, time.time(), []
+    while step < total:
+        for idx in length_grouped_batches([len(w) for w in tw], args.batch_size, rng):
+            if step >= total:
+                break
+            mine = shard_batch(idx, rank, world) if world > 1 else idx
+            if not mine:
+                continue
+            x, lens = pad_waves([tw[i] for i in mine])
+            lab = pad_labels([tl[i] for i in mine])
+            loss = trainer.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(lens).to(dev),
+                                      torch.from_numpy(lab).to(dev))
+            run_loss.append(loss)
+            step += 1
+            if step % args.eval_steps == 0 or step == total:
+                entry = {"epoch": step / steps_per_epoch, "step": step, "learning_rate": opt.current_lr(),
+                         "loss": float(torch.stack(run_loss).mean().item())}
+                run_loss = []
+                if rank == 0:
+                    state["log_history"].append(entry)
+                    state["log_history"].append({"epoch": entry["epoch"], "step": step, **evaluate(model, tok, vw, vl, args.batch_size)})
+                    state["global_step"] = step
+                    ck = os.path.join(out_dir, f"checkpoint-{step}")
+                    save_pretrained(model, tok, ck)
+                    torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
+                    with open(os.path.join(ck, "trainer_state.json"), "w") as f:
+                        json.dump(state, f, indent=1)
+    if rank == 0:
+        save_pretrained(model, tok, os.path.join(out_dir, "final"))
+        print(f"trained {step} steps in {time.time() - t0:.1f} s -> {out_dir}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def tok_pad(folder: str) -> int:
+    with open(os.path.join(folder, "vocab.json")) as f:
+        return json.load(f).get("<pad>", 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,8 @@ class Trainer:
         self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.dist else 1
         self.normalize_on_device = normalize_on_device
+        # group-norm ("base") models run without attention mask, layer-norm (XLSR) models with it
+        self.use_mask = model.config.feat_extract_norm == "layer"
 
     def broadcast_parameters(self):
         if self.dist:
@@ -84,7 +86,7 @@ class Trainer:
         labels [B,L] (-100 padding).  Returns the (local) loss tensor; no host synchronisation."""
         m = self.model
         x = hip.wave_normalize(waves, lengths) if raw else waves
-        out = m(x, lengths=lengths, labels=labels)
+        out = m(x, lengths=lengths if self.use_mask else None, labels=labels)
         m.backward()
         if self.dist:
             # ONE sum all-reduce of the flat gradient buffer; mean over ranks folded into the optimizer's scale

@@ -1,0 +1,135 @@
+"""CPU: host-side logic of the product (Kaldi ingest, tokenizer, schedules, batching) against the golden vectors and
+the conventions of the reference (file:line in the docstrings of ssak_amd/data.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from ssak_amd import data as D
+from ssak_amd.model import compute_mask_indices, conv_out_lengths
+from ssak_amd.config import Wav2Vec2Config
+from ssak_amd.trainer import linear_warmup_lr
+from ssak_amd.train import word_error_rate, args_to_str, build_parser
+from ssak_amd.synth import synth_batch, VOCAB
+
+
+@pytest.fixture()
+def kaldi(tmp_path, monkeypatch):
+    rng = np.random.default_rng(0)
+    audio = tmp_path / "audio"
+    audio.mkdir()
+    for name, n in (("a.wav", 16000), ("b c.wav", 24000), ("long.wav", 80000)):
+        D.write_wav(str(audio / name), (rng.standard_normal(n) * 0.1).astype(np.float32))
+    monkeypatch.setenv("DATAPATH", str(tmp_path))
+    k1 = tmp_path / "k1"
+    k1.mkdir()
+    (k1 / "wav.scp").write_text("utt_a sox $DATAPATH/audio/a.wav -t wav -r 16k -b 16 -c 1 - |\n"
+                                "utt_b sox '$DATAPATH/audio/b c.wav' -t wav -r 16k -b 16 -c 1 - |\n")
+    (k1 / "text").write_text("utt_a bonjour <noise> le monde\nutt_b allô\n")
+    (k1 / "utt2dur").write_text("utt_a 1.0\nutt_b 1.5\n")
+    k2 = tmp_path / "k2"
+    k2.mkdir()
+    (k2 / "wav.scp").write_text(f"rec {audio}/long.wav\n")
+    (k2 / "text").write_text("rec-s1 un deux\nrec-s2 trois\nrec-s3\n")
+    (k2 / "segments").write_text("rec-s1 rec 0.50 1.50\nrec-s2 rec 2.00 4.25\nrec-s3 rec 4.5 4.6\n")
+    (tmp_path / "list.txt").write_text("$DATAPATH/k1    1\n$DATAPATH/k2 2\n")
+    return tmp_path
+
+
+def test_wavscp_forms(kaldi):
+    w = D.parse_kaldi_wavscp(str(kaldi / "k1" / "wav.scp"))
+    assert w["utt_a"] == str(kaldi / "audio" / "a.wav") and w["utt_b"] == str(kaldi / "audio" / "b c.wav")
+    (kaldi / "bad.scp").write_text("x ffmpeg -i foo.mp3 - |\n")
+    with pytest.raises(RuntimeError):
+        D.parse_kaldi_wavscp(str(kaldi / "bad.scp"))
+    (kaldi / "flac.scp").write_text("x flac -c -d -s -f /tmp/foo.flac |\n")
+    assert D.parse_kaldi_wavscp(str(kaldi / "flac.scp"))["x"] == "/tmp/foo.flac"
+
+
+def test_kaldi_folder_semantics(kaldi):
+    u = D.load_kaldi(str(kaldi / "k1"))
+    assert [x.id for x in u] == ["utt_a", "utt_b"] and u[1].end == 1.5 and u[0].start == 0.0
+    u = D.load_kaldi(str(kaldi / "k2"), min_duration=0.5, max_duration=15)
+    assert [x.id for x in u] == ["rec-s1", "rec-s2"] and u[1].text == "trois"       # too-short segment dropped
+    assert D.load_kaldi(str(kaldi / "k2"))[2].text == ""                               # empty transcript kept
+    u = D.load_kaldi(str(kaldi / "list.txt"))                                          # list file, weight 2 duplicates
+    assert len(u) == 2 + 2 * 3
+    u = D.load_kaldi(f"{kaldi}/k1,{kaldi}/k2")
+    assert len(u) == 5
+    with pytest.raises(RuntimeError):
+        D.load_kaldi(str(kaldi / "nope"))
+    os.remove(kaldi / "k1" / "utt2dur")
+    with pytest.raises(RuntimeError):
+        D.load_kaldi(str(kaldi / "k1"))
+    u = D.load_kaldi(str(kaldi / "k2"), sort_by_len=-1)
+    assert u[0].id == "rec-s2"
+
+
+def test_audio_segments_and_errors(kaldi):
+    full = D.load_audio(str(kaldi / "audio" / "long.wav"))
+    seg = D.load_audio(str(kaldi / "audio" / "long.wav"), 2.0, 4.25)
+    assert len(full) == 80000 and len(seg) == int(4.25 * 16000) - int(2.0 * 16000)
+    assert np.array_equal(seg, full[32000:68000]) and seg.dtype == np.float32
+    with pytest.raises(RuntimeError):
+        D.load_audio(str(kaldi / "audio" / "missing.wav"))
+    (kaldi / "audio" / "fake.wav").write_bytes(b"ID3 not a wav")
+    with pytest.raises(RuntimeError):
+        D.load_audio(str(kaldi / "audio" / "fake.wav"))
+    batches = list(D.to_audio_batches([str(kaldi / "k2")], batch_size=2, output_ids=True))
+    assert [len(b) for b in batches] == [2, 1] and batches[0][0][1] == "rec-s1"
+
+
+def test_label_cleanup_and_tokenizer(gold):
+    assert D.remove_special_words("bonjour <noise>  le   monde") == "bonjour le monde"
+    assert D.remove_special_words("j ' ai") == "j'ai"
+    assert D.remove_special_words("j'ai", glue_apostrophe=False) == "j' ai"
+    assert D.remove_special_words(None) == ""
+    z = gold("greedy.npz")
+    tok = D.CharTokenizer([str(v) for v in z["vocab"]])
+    assert tok.pad_token_id == 0
+    for ids, want in zip(z["ids"], z["text"]):  # Wav2Vec2CTCTokenizer.batch_decode golden
+        assert tok.decode(ids) == " ".join(str(want).split())
+    assert tok.encode("ab c") == [5, 6, 4, 7] and tok.decode(tok.encode("ab c"), group_tokens=False) == "ab c"
+
+
+def test_collation_conventions(gold):
+    z = gold("features.npz")
+    assert (D.pad_labels([[5, 6, 7, 8], [9], [10, 11]]) == z["labels_padded"]).all()
+    x, lens = D.pad_waves([np.ones(5, np.float32), np.ones(3, np.float32)])
+    assert x.shape == (2, 5) and (x[1, 3:] == 0).all() and list(lens) == [5, 3]
+    assert (conv_out_lengths(Wav2Vec2Config(), z["len_T"]) == z["len_F"]).all()
+
+
+def test_specaugment_indices_match_hf(gold):
+    z = gold("specaug.npz")
+    for i, (B, S) in enumerate(((4, 499), (3, 499), (2, 49))):
+        m = compute_mask_indices((B, S), 0.05, 10, None if i == 0 else list(z[f"lens{i}"]), 2, rng=np.random.RandomState(100 + i))
+        assert (m == z[f"mask{i}"]).all()
+
+
+def test_schedule_wer_naming():
+    # lr logged after steps 1 and 2 in the reference's own golden (tests/expected/train_transformers/trainer_state.json:12-13,27-28)
+    assert abs(linear_warmup_lr(1e-4, 1, 500, 10000) - 2e-7) < 1e-15
+    assert abs(linear_warmup_lr(1e-4, 2, 500, 10000) - 4e-7) < 1e-15
+    assert linear_warmup_lr(1e-4, 500, 500, 1000) == 1e-4 and linear_warmup_lr(1e-4, 750, 500, 1000) == 0.5e-4
+    assert word_error_rate(["a b c", "d"], ["a x c", "d e"]) == 2 / 4
+    a = build_parser().parse_args(["tr", "va", "--base_model", "/x/m"])
+    s = args_to_str(a)
+    assert "lr-0.0001" in s and "bs-8" in s and "bm-m" in s and "tr" not in s.split("_")
+
+
+def test_batching_and_sharding():
+    rng = np.random.RandomState(0)
+    lens = list(rng.randint(16000, 240000, 103))
+    b = D.length_grouped_batches(lens, 8, np.random.RandomState(1))
+    assert sorted(i for x in b for i in x) == list(range(103))
+    assert all(lens[x[0]] >= lens[x[-1]] for x in b)
+    shards = [D.shard_batch(b[0], r, 4) for r in range(4)]
+    assert sum(shards, []) == b[0] and all(len(s) == 2 for s in shards)
+
+
+def test_synthetic_batch_is_ctc_feasible():
+    w, lab = synth_batch(4, 16000, seed=1)
+    assert w.shape == (4, 16000) and w.dtype == np.float32 and np.abs(w).max() <= 1.0
+    n = (lab >= 0).sum(-1)
+    assert n.min() >= 60 and n.max() <= 120 and lab.max() < len(VOCAB) and (2 * n + 1 <= 499).all()
