@@ -89,6 +89,9 @@ typedef struct {
   uint32_t drop_stream; /* mask bit = hash(drop_seed, drop_stream, element offset in C): replayable in backward */
   uint64_t drop_seed;
   long bias_s2; /* bias element stride per second-level batch index (grouped conv: one bias slice per group) */
+  int pads_are_zero; /* caller guarantees that elements between the logical extent and the next multiple of 8
+                        (K for K-contiguous operands, rows for K-major ones) are zero in memory: lets operands whose
+                        extent is not a multiple of 8 (e.g. 499 frames) take the direct-to-LDS path */
 } ssak_gemm_desc;
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);
@@ -97,13 +100,13 @@ int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const voi
  * enabled, every GEMM launch is bracketed by HIP events on its own stream; ssak_prof_collect waits for them and
  * returns, per kernel instantiation (named as rocprofv3 prints it), launches / summed ms / algorithmic FLOPs. */
 typedef struct {
-  char name[64];
+  char name[80];
   long launches;
   double total_ms;
   double total_flops;
 } ssak_prof_entry;
 int ssak_prof_enable(int on);
-int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* returns the number of entries (8) */
+int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 16; returns the number of entries (16) */
 
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer

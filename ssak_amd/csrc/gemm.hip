@@ -41,6 +41,7 @@ struct GemmParams {
   float drop_scale;
   uint64_t drop_seed;
   long bias_s2;
+  uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
 };
 
 // ---- LDS tile geometry -------------------------------------------------------------------------
@@ -70,62 +71,104 @@ struct Regs {
   uint4 v[N];
 };
 
+// Per-thread staging state of one operand tile, set up once per workgroup: where each of this thread's
+// 16-byte chunks comes from in global memory (for k-tile 0), where it goes in LDS, and how many of its 8
+// elements are inside the matrix along the non-K axis.  Inside the K loop a chunk's source only advances by a
+// constant, every load is issued unconditionally (out-of-range chunks read a safe in-range address and are
+// zeroed later), and the zero-fill masking is applied when the registers are written to LDS -- one K step after
+// the loads were issued, and only on edge tiles (workgroup-uniform branch), so the loads stay in flight together.
 template <int R, bool KM>
-__device__ __forceinline__ void load_tile(Regs<Tile<R, KM>::NCHUNK>& regs, const bf16* __restrict__ base, long ld,
-                                          int row0, int rows_total, int k0, int k_end) {
-  // base already includes the batch offset.  rows_total / k_end bound the valid region.
-#pragma unroll
-  for (int i = 0; i < Tile<R, KM>::NCHUNK; ++i) {
-    const int q = threadIdx.x + i * NTHREADS;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (!KM) {
-      const int r = q >> 3, c = q & 7;
-      const int gr = row0 + r, gk = k0 + c * 8;
-      if (gr < rows_total && gk < k_end) {
-        v = *reinterpret_cast<const uint4*>(base + (long)gr * ld + gk);
-        if (gk + 8 > k_end) v = mask_chunk(v, k_end - gk);
-      }
-    } else {
-      constexpr int CPR = R / 8;  // chunks per k-row
-      const int kr = q / CPR, c = q % CPR;
-      const int gk = k0 + kr, gr = row0 + c * 8;
-      if (gk < k_end && gr < rows_total) {
-        v = *reinterpret_cast<const uint4*>(base + (long)gk * ld + gr);
-        if (gr + 8 > rows_total) v = mask_chunk(v, rows_total - gr);
-      }
-    }
-    regs.v[i] = v;
-  }
-}
+struct Stager {
+  static constexpr int N = Tile<R, KM>::NCHUNK;
+  const char* base;     // workgroup-uniform operand base (batch offset folded in): loads use base + 32-bit offset
+  uint32_t off[N];      // byte offset of the chunk in the CURRENT k-tile (advanced by kstep after every load)
+  int lds_off[N];
+  int kofs[N];          // KC: k offset of the chunk inside the k-tile (c*8); KM: k-row inside the k-tile
+  int nrow[N];          // KC: 8 if the row is inside the matrix else 0; KM: valid elements along the row axis (0..8)
+  uint32_t kstep;       // byte stride of one k-tile
+  bool rows_full;       // every chunk of this tile is fully inside along the non-K axis
 
-template <int R, bool KM>
-__device__ __forceinline__ void store_tile(const Regs<Tile<R, KM>::NCHUNK>& regs, char* lds) {
+  __device__ __forceinline__ void init(const bf16* base_, long ld, int row0, int rows_total, int kt0) {
+    base = reinterpret_cast<const char*>(base_);
+    rows_full = true;
+    kstep = (uint32_t)((KM ? (long)BK * ld : (long)BK) * 2);
 #pragma unroll
-  for (int i = 0; i < Tile<R, KM>::NCHUNK; ++i) {
-    const int q = threadIdx.x + i * NTHREADS;
-    int off;
-    if (!KM) {
-      const int r = q >> 3, c = q & 7;
-      off = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
-    } else {
-      constexpr int CPR = R / 8;
-      const int kr = q / CPR, c = q % CPR;
-      off = kr * Tile<R, KM>::STRIDE + c * 16;
+    for (int i = 0; i < N; ++i) {
+      const int q = threadIdx.x + i * NTHREADS;
+      if (!KM) {
+        const int r = q >> 3, c = q & 7;
+        const int gr = row0 + r;
+        nrow[i] = gr < rows_total ? 8 : 0;
+        kofs[i] = c * 8;
+        off[i] = (uint32_t)(((long)(gr < rows_total ? gr : 0) * ld + c * 8) * 2);
+        lds_off[i] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+      } else {
+        constexpr int CPR = R / 8;
+        const int kr = q / CPR, c = q % CPR;
+        const int gr = row0 + c * 8;
+        nrow[i] = min(max(rows_total - gr, 0), 8);
+        kofs[i] = kr;
+        off[i] = (uint32_t)(((long)kr * ld + (nrow[i] > 0 ? gr : 0)) * 2);
+        lds_off[i] = kr * Tile<R, KM>::STRIDE + c * 16;
+      }
+      off[i] += (uint32_t)kt0 * kstep;
+      rows_full = rows_full && (nrow[i] == 8);
     }
-    *reinterpret_cast<uint4*>(lds + off) = regs.v[i];
+    rows_full = __syncthreads_and(rows_full);
   }
-}
+  // valid elements of chunk i in k-tile starting at k0 (0..8)
+  __device__ __forceinline__ int nvalid(int i, int k0, int k_end) const {
+    if (!KM) return nrow[i] ? min(max(k_end - (k0 + kofs[i]), 0), 8) : 0;
+    return (k0 + kofs[i] < k_end) ? nrow[i] : 0;
+  }
+  // issue the loads of k-tile kt (all unconditional; chunks with no valid element read offset 0) and advance
+  __device__ __forceinline__ void load(Regs<N>& regs, int kt, int k_end) {
+    const int k0 = kt * BK;
+    if (rows_full && (k0 + BK <= k_end)) {  // workgroup-uniform fast path
+#pragma unroll
+      for (int i = 0; i < N; ++i) regs.v[i] = *reinterpret_cast<const uint4*>(base + off[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        regs.v[i] = *reinterpret_cast<const uint4*>(base + (nvalid(i, k0, k_end) > 0 ? off[i] : 0u));
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) off[i] += kstep;
+  }
+  __device__ __forceinline__ void store(const Regs<N>& regs, char* lds, int kt, int k_end) const {
+    const int k0 = kt * BK;
+    if (rows_full && (k0 + BK <= k_end)) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) *reinterpret_cast<uint4*>(lds + lds_off[i]) = regs.v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) *reinterpret_cast<uint4*>(lds + lds_off[i]) = mask_chunk(regs.v[i], nvalid(i, k0, k_end));
+    }
+  }
+};
 
-// fragment for rows [r0, r0+16) and k in [32*kk, 32*kk+32): lane l gets k = 8*(l>>4)+j, row r0 + (l&15)
+// Fragment addressing.  Lane l of a wave gets k = 8*(l>>4)+j (j = 0..7) of row r0 + (l&15) of the 16-row group.
+// Everything lane-dependent is folded into ONE per-thread byte offset computed before the K loop (frag_lane_off);
+// the 16-row group index i, the 32-deep k half kk and the stage are compile-time / uniform immediates:
+//   K-contiguous: off = lane_off ^ (kk << 6)  + i * 2048          (the XOR swizzle only sees (row>>1)&7, and
+//                                                                  16*i rows leave it unchanged)
+//   K-major     : off = lane_off + kk * 32 * STRIDE + i * 32      (+ 4 * STRIDE for the upper four k)
 template <int R, bool KM>
-__device__ __forceinline__ bf16x8 read_frag(const char* lds, int r0, int kk, int lane) {
+__device__ __forceinline__ int frag_lane_off(int w0, int lane) {
   if (!KM) {
-    const int r = r0 + (lane & 15);
-    const int c = kk * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+    const int r = w0 + (lane & 15);
+    return r * 128 + (((lane >> 4) ^ ((r >> 1) & 7)) << 4);
   } else {
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int off = (kk * 32 + 8 * g + q) * Tile<R, KM>::STRIDE + (r0 + 4 * p) * 2;
+    return (8 * g + q) * Tile<R, KM>::STRIDE + (w0 + 4 * p) * 2;
+  }
+}
+template <int R, bool KM>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int lane_off, int i, int kk) {
+  if (!KM) {
+    return *reinterpret_cast<const bf16x8*>(lds + ((lane_off ^ (kk << 6)) + i * 2048));
+  } else {
+    const int off = lane_off + kk * 32 * Tile<R, KM>::STRIDE + i * 32;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off + 4 * Tile<R, KM>::STRIDE));
@@ -143,75 +186,9 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
-  static_assert(WM * WN == 4, "4 waves");
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int MI = TM / 16, NI = TN / 16;
-  using TA = Tile<BM, A_KM>;
-  using TB = Tile<BN, B_KM>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = TA::BYTES + TB::BYTES;  // stage s: A at s*STAGE, B at s*STAGE + TA::BYTES
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
-
-  const int per_z = p.tiles_m * p.tiles_n;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int zs = id / per_z, rem = id % per_z;
-  const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
-  const int split = zs % p.split_k, z = zs / p.split_k;
-  const int z1 = z / p.nb2, z2 = z % p.nb2;
-  const bf16* Ab = p.A + z1 * p.sa1 + z2 * p.sa2;
-  const bf16* Bb = p.B + z1 * p.sb1 + z2 * p.sb2;
-  const int bm0 = tm * BM, bn0 = tn * BN;
-
-  const int nkt = (p.K + BK - 1) / BK;
-  const int kt0 = split * p.kt_per_split;
-  const int kt1 = min(nkt, kt0 + p.kt_per_split);
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  Regs<TA::NCHUNK> ra;
-  Regs<TB::NCHUNK> rb;
-  if (kt0 < kt1) {
-    load_tile<BM, A_KM>(ra, Ab, p.lda, bm0, p.M, kt0 * BK, p.K);
-    load_tile<BN, B_KM>(rb, Bb, p.ldb, bn0, p.N, kt0 * BK, p.K);
-    store_tile<BM, A_KM>(ra, smem);
-    store_tile<BN, B_KM>(rb, smem + TA::BYTES);
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
-    if (more) {
-      load_tile<BM, A_KM>(ra, Ab, p.lda, bm0, p.M, (kt + 1) * BK, p.K);
-      load_tile<BN, B_KM>(rb, Bb, p.ldb, bn0, p.N, (kt + 1) * BK, p.K);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[MI], fb[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = read_frag<BM, A_KM>(smem + cur * STAGE, wm0 + 16 * i, kk, lane);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) fb[j] = read_frag<BN, B_KM>(smem + cur * STAGE + TA::BYTES, wn0 + 16 * j, kk, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      store_tile<BM, A_KM>(ra, smem + (cur ^ 1) * STAGE);
-      store_tile<BN, B_KM>(rb, smem + (cur ^ 1) * STAGE + TA::BYTES);
-    }
-    __syncthreads();
-  }
-
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int bm0, int bn0, int wm0,
+                                              int wn0, int lane, int z, int z1, int z2, int split) {
   // ---- epilogue: lane holds m = .. + (lane & 15), n = .. + 4 * (lane >> 4) + r, r = 0..3
   const int lm = lane & 15, ln = (lane >> 4) * 4;
   if (p.split_k > 1) {
@@ -306,6 +283,258 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  using TA = Tile<BM, A_KM>;
+  using TB = Tile<BN, B_KM>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = TA::BYTES + TB::BYTES;  // stage s: A at s*STAGE, B at s*STAGE + TA::BYTES
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
+
+  const int per_z = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int zs = id / per_z, rem = id % per_z;
+  const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
+  const int split = zs % p.split_k, z = zs / p.split_k;
+  const int z1 = z / p.nb2, z2 = z % p.nb2;
+  const bf16* Ab = p.A + z1 * p.sa1 + z2 * p.sa2;
+  const bf16* Bb = p.B + z1 * p.sb1 + z2 * p.sb2;
+  const int bm0 = tm * BM, bn0 = tn * BN;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = split * p.kt_per_split;
+  const int kt1 = min(nkt, kt0 + p.kt_per_split);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int a_lane_off = frag_lane_off<BM, A_KM>(wm0, lane);
+  const int b_lane_off = frag_lane_off<BN, B_KM>(wn0, lane);
+  Regs<TA::NCHUNK> ra;
+  Regs<TB::NCHUNK> rb;
+  Stager<BM, A_KM> sa;
+  Stager<BN, B_KM> sb;
+  sa.init(Ab, p.lda, bm0, p.M, kt0);
+  sb.init(Bb, p.ldb, bn0, p.N, kt0);
+  if (kt0 < kt1) {
+    sa.load(ra, kt0, p.K);
+    sb.load(rb, kt0, p.K);
+    sa.store(ra, smem, kt0, p.K);
+    sb.store(rb, smem + TA::BYTES, kt0, p.K);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) {
+      sa.load(ra, kt + 1, p.K);
+      sb.load(rb, kt + 1, p.K);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag<BM, A_KM>(smem + cur * STAGE, a_lane_off, i, kk);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = read_frag<BN, B_KM>(smem + cur * STAGE + TA::BYTES, b_lane_off, j, kk);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      sa.store(ra, smem + (cur ^ 1) * STAGE, kt + 1, p.K);
+      sb.store(rb, smem + (cur ^ 1) * STAGE + TA::BYTES, kt + 1, p.K);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue<MI, NI>(p, acc, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
+}
+
+// =================================================================================================
+// LDS-DMA variant: operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no
+// ds_write: on gfx950 a ds_write_b128 costs ~13 cycles of the SIMD->LDS path per wave-instruction, which made the
+// register-staged kernel LDS-store-bound).  An LDS-DMA wave-instruction writes 1 KiB linearly (M0 base + lane*16),
+// so the bank-conflict swizzles are applied on the SOURCE side: lane L fetches the global chunk whose swizzled
+// home is slot L.  Out-of-range chunks are given an offset beyond the buffer descriptor's extent: the DMA then
+// writes zeros (measured: tools/probes/glds_oob.hip), which is the zero fill the edges need.  Partial 16-byte
+// chunks cannot be masked here, so this kernel is selected only when no chunk is partial or the caller
+// guarantees that padding elements are zero in memory (desc.pads_are_zero).
+//   K-contiguous tile: [R rows][128 B], chunk c of row r at slot c ^ ((r >> 1) & 7)               (as above)
+//   K-major tile     : [64 k-rows][2R B], chunk ch of k-row kr at slot ch ^ f(kr); f spreads the 8 k-rows one
+//                      transpose-read touches over the whole 256-B bank row (conflict-free ds_read_b64_tr_b16)
+// Two stages, ONE barrier per K step: wait own DMA (vmcnt 0) -> barrier -> issue next tile's DMA -> MFMA.
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int R>
+__device__ __forceinline__ int km_swz(int kr) {
+  // XOR applied to the 16-B chunk index of k-row kr
+  if (R == 128) return (((kr >> 3) & 1) << 3) | ((kr & 3) << 1);
+  return ((((kr >> 3) & 1) << 1) | ((kr >> 1) & 1)) << 1;  // R == 64: two k-rows share a 256-B bank row
+}
+
+template <int R, bool KM>
+struct DmaStager {
+  static constexpr int NINST = R / 32;  // 1-KiB wave-instructions per wave per tile (tile = R*128 bytes, 4 waves)
+  static constexpr uint32_t OOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t off[NINST];   // byte offset of this lane's chunk in the current k-tile (OOB if its row is outside)
+  int kofs[NINST];       // KC: first k of the chunk inside the k-tile; KM: k-row inside the k-tile
+  uint32_t kstep;
+  int wave;
+
+  __device__ __forceinline__ void init(const bf16* base, long ld, int row0, int rows_total, int K, int kt0,
+                                       uint32_t extent_bytes) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)extent_bytes, 0x00020000);
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    kstep = (uint32_t)((KM ? (long)BK * ld : (long)BK) * 2);
+#pragma unroll
+    for (int j = 0; j < NINST; ++j) {
+      const int S = (wave * NINST + j) * 64 + lane;
+      if (!KM) {
+        const int r = S >> 3, pc = S & 7;
+        const int c = pc ^ ((r >> 1) & 7);
+        const int gr = row0 + r;
+        kofs[j] = c * 8;
+        off[j] = gr < rows_total ? (uint32_t)(((long)gr * ld + c * 8) * 2) : OOB;
+      } else {
+        constexpr int CPR = R / 8;
+        const int kr = S / CPR, pc = S % CPR;
+        const int ch = pc ^ km_swz<R>(kr);
+        const int gr = row0 + ch * 8;
+        kofs[j] = kr;
+        off[j] = gr < rows_total ? (uint32_t)(((long)kr * ld + gr) * 2) : OOB;
+      }
+      if (off[j] != OOB) off[j] += (uint32_t)kt0 * kstep;
+    }
+  }
+  __device__ __forceinline__ void issue(char* lds_tile, int kt, int K) {
+    const int k0 = kt * BK;
+    const bool full = k0 + BK <= K;  // uniform
+#pragma unroll
+    for (int j = 0; j < NINST; ++j) {
+      uint32_t o = off[j];
+      if (!full) o = (k0 + kofs[j] < K) ? o : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * NINST + j) * 1024), 16, o, 0, 0, 0);
+      if (off[j] != OOB) off[j] += kstep;
+    }
+  }
+};
+
+// per-lane fragment offsets for the DMA tile images
+template <int R, bool KM, int NF>
+struct DmaFrag {
+  int off[KM ? NF : 1];
+  __device__ __forceinline__ void init(int w0, int lane) {
+    if (!KM) {
+      const int r = w0 + (lane & 15);
+      off[0] = r * 128 + (((lane >> 4) ^ ((r >> 1) & 7)) << 4);
+    } else {
+      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+      const int kr = 8 * g + q;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int ch = (w0 >> 3) + 2 * i + (p >> 1);
+        off[i] = kr * (2 * R) + ((ch ^ km_swz<R>(kr)) << 4) + (p & 1) * 8;
+      }
+    }
+  }
+  __device__ __forceinline__ bf16x8 read(const char* lds, int i, int kk) const {
+    if (!KM) {
+      return *reinterpret_cast<const bf16x8*>(lds + ((off[0] ^ (kk << 6)) + i * 2048));
+    } else {
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const char* a = lds + off[KM ? i : 0] + kk * 32 * (2 * R);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * (2 * R)));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      return __builtin_bit_cast(bf16x8, v);
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
+  const int per_z = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int zs = id / per_z, rem = id % per_z;
+  const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
+  const int split = zs % p.split_k, z = zs / p.split_k;
+  const int z1 = z / p.nb2, z2 = z % p.nb2;
+  const bf16* Ab = p.A + z1 * p.sa1 + z2 * p.sa2;
+  const bf16* Bb = p.B + z1 * p.sb1 + z2 * p.sb2;
+  const int bm0 = tm * BM, bn0 = tn * BN;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = split * p.kt_per_split;
+  const int kt1 = min(nkt, kt0 + p.kt_per_split);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  DmaStager<BM, A_KM> sa;
+  DmaStager<BN, B_KM> sb;
+  sa.init(Ab, p.lda, bm0, p.M, p.K, kt0, p.ext_a);
+  sb.init(Bb, p.ldb, bn0, p.N, p.K, kt0, p.ext_b);
+  DmaFrag<BM, A_KM, MI> fra;
+  DmaFrag<BN, B_KM, NI> frb;
+  fra.init(wm0, lane);
+  frb.init(wn0, lane);
+
+  if (kt0 < kt1) {
+    sa.issue(smem, kt0, p.K);
+    sb.issue(smem + ABYTES, kt0, p.K);
+  }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    // own DMA of tile kt has landed (vmcnt 0), then everyone's has; also every wave is done reading stage cur^1
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) only
+    __syncthreads();
+    if (kt + 1 < kt1) {
+      sa.issue(smem + (cur ^ 1) * STAGE, kt + 1, p.K);
+      sb.issue(smem + (cur ^ 1) * STAGE + ABYTES, kt + 1, p.K);
+    }
+    const char* la = smem + cur * STAGE;
+    const char* lb = la + ABYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = fra.read(la, i, kk);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = frb.read(lb, j, kk);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  gemm_epilogue<MI, NI>(p, acc, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
+}
+
 // deterministic split-K combine: C = alpha * sum_s slab[s] (+ bias) (+ C)
 __global__ void splitk_reduce_kernel(const GemmParams p) {
   const long per = (long)p.M * p.N;
@@ -346,21 +575,19 @@ hipEvent_t prof_event() {
   (void)hipEventCreate(&e);
   return e;
 }
-const char* kVariantNames[8] = {
-    "gemm_kernel<128, 128, 2, 2, false, false>", "gemm_kernel<128, 128, 2, 2, false, true>",
-    "gemm_kernel<128, 128, 2, 2, true, false>",  "gemm_kernel<128, 128, 2, 2, true, true>",
-    "gemm_kernel<128, 64, 2, 2, false, false>",  "gemm_kernel<128, 64, 2, 2, false, true>",
-    "gemm_kernel<128, 64, 2, 2, true, false>",   "gemm_kernel<128, 64, 2, 2, true, true>"};
+const char* kLayoutNames[8] = {"128, 128, 2, 2, false, false", "128, 128, 2, 2, false, true", "128, 128, 2, 2, true, false",
+                               "128, 128, 2, 2, true, true",   "128, 64, 2, 2, false, false",  "128, 64, 2, 2, false, true",
+                               "128, 64, 2, 2, true, false",   "128, 64, 2, 2, true, true"};
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
-int launch(const GemmParams& p, hipStream_t st) {
-  constexpr size_t lds = 2 * (size_t)(Tile<BM, A_KM>::BYTES + Tile<BN, B_KM>::BYTES);
-  auto kern = gemm_kernel<BM, BN, WM, WN, A_KM, B_KM>;
+int launch(const GemmParams& p, bool dma, hipStream_t st) {
+  const size_t lds = dma ? 2 * (size_t)(BM + BN) * 128 : 2 * (size_t)(Tile<BM, A_KM>::BYTES + Tile<BN, B_KM>::BYTES);
+  auto kern = dma ? gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM> : gemm_kernel<BM, BN, WM, WN, A_KM, B_KM>;
   if (lds > 64 * 1024) {
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
+    static bool attr_done[2] = {false, false};  // per instantiation and kernel flavour
+    if (!attr_done[dma]) {
       SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_done = true;
+      attr_done[dma] = true;
     }
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
@@ -368,7 +595,7 @@ int launch(const GemmParams& p, hipStream_t st) {
   if (g_prof_on) {
     rec.e0 = prof_event();
     rec.e1 = prof_event();
-    rec.variant = (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
+    rec.variant = (dma ? 0 : 8) + (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
     (void)hipEventRecord(rec.e0, st);
   }
@@ -382,11 +609,11 @@ int launch(const GemmParams& p, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int dispatch_layout(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
-  if (!a_km && !b_km) return launch<BM, BN, WM, WN, false, false>(p, st);
-  if (!a_km && b_km) return launch<BM, BN, WM, WN, false, true>(p, st);
-  if (a_km && b_km) return launch<BM, BN, WM, WN, true, true>(p, st);
-  return launch<BM, BN, WM, WN, true, false>(p, st);
+int dispatch_layout(const GemmParams& p, int a_km, int b_km, bool dma, hipStream_t st) {
+  if (!a_km && !b_km) return launch<BM, BN, WM, WN, false, false>(p, dma, st);
+  if (!a_km && b_km) return launch<BM, BN, WM, WN, false, true>(p, dma, st);
+  if (a_km && b_km) return launch<BM, BN, WM, WN, true, true>(p, dma, st);
+  return launch<BM, BN, WM, WN, true, false>(p, dma, st);
 }
 
 }  // namespace
@@ -444,16 +671,29 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   if (split > 1)
     SSAK_REQUIRE(workspace && workspace_bytes >= (size_t)split * p.nz * (size_t)d->M * d->N * sizeof(float),
                  "gemm: split_k workspace too small");
+  {
+    // kernels address an operand slice with 32-bit byte offsets from its (batch-adjusted) base
+    const double ext_a = d->a_kmajor ? ((double)(d->K - 1) * d->lda + d->M) : ((double)(d->M - 1) * d->lda + d->K);
+    const double ext_b = d->b_kmajor ? ((double)(d->K - 1) * d->ldb + d->N) : ((double)(d->N - 1) * d->ldb + d->K);
+    SSAK_REQUIRE(ext_a * 2 < 2.0e9 && ext_b * 2 < 2.0e9, "gemm: one batch slice of an operand must span < 2 GB");
+    // round up to whole 16-byte chunks: a partial last chunk is still fetched (ld* and the allocation cover it)
+    p.ext_a = (uint32_t)(((long)ext_a + 7) / 8 * 16);
+    p.ext_b = (uint32_t)(((long)ext_b + 7) / 8 * 16);
+  }
+  // the LDS-DMA kernel cannot mask partial 16-byte chunks: needs whole chunks or zero padding in memory
+  const bool partial_a = d->a_kmajor ? (d->M & 7) : (d->K & 7);
+  const bool partial_b = d->b_kmajor ? (d->N & 7) : (d->K & 7);
+  const bool dma = d->pads_are_zero || !(partial_a || partial_b);
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (d->N > 64) {
     p.tiles_m = ssak_cdiv(d->M, 128);
     p.tiles_n = ssak_cdiv(d->N, 128);
-    rc = dispatch_layout<128, 128, 2, 2>(p, d->a_kmajor, d->b_kmajor, st);
+    rc = dispatch_layout<128, 128, 2, 2>(p, d->a_kmajor, d->b_kmajor, dma, st);
   } else {
     p.tiles_m = ssak_cdiv(d->M, 128);
     p.tiles_n = ssak_cdiv(d->N, 64);
-    rc = dispatch_layout<128, 64, 2, 2>(p, d->a_kmajor, d->b_kmajor, st);
+    rc = dispatch_layout<128, 64, 2, 2>(p, d->a_kmajor, d->b_kmajor, dma, st);
   }
   if (rc != SSAK_OK) return rc;
   if (split > 1) {
@@ -471,9 +711,9 @@ extern "C" int ssak_prof_enable(int on) {
 }
 
 extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
-  SSAK_REQUIRE(out && cap >= 8, "prof_collect: need room for 8 entries");
-  for (int i = 0; i < 8; ++i) {
-    snprintf(out[i].name, sizeof(out[i].name), "%s", kVariantNames[i]);
+  SSAK_REQUIRE(out && cap >= 16, "prof_collect: need room for 16 entries");
+  for (int i = 0; i < 16; ++i) {
+    snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
     out[i].launches = 0;
     out[i].total_ms = 0.0;
     out[i].total_flops = 0.0;
@@ -489,5 +729,5 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
     g_event_pool.push_back(r.e1);
   }
   g_prof.clear();
-  return 8;
+  return 16;
 }

@@ -291,6 +291,7 @@ struct Gemm {
     d.nb1 = d.nb2 = 1;
     d.alpha = 1.f;
     d.split_k = 1;
+    d.pads_are_zero = 1;  // every engine buffer with a padded leading dimension (P, dS: ld = round_up(F, 8)) is written with zero pads
   }
   Gemm& a(const void* p, long ld, bool km = false) {
     A = p;

@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):
                 ("sa1", C.c_long), ("sa2", C.c_long), ("sb1", C.c_long), ("sb2", C.c_long), ("sc1", C.c_long),
                 ("sc2", C.c_long), ("alpha", C.c_float), ("epilogue", C.c_int), ("out_f32", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
-                ("drop_seed", C.c_uint64), ("bias_s2", C.c_long)]
+                ("drop_seed", C.c_uint64), ("bias_s2", C.c_long), ("pads_are_zero", C.c_int)]
 
 
 class W2V2Config(C.Structure):
@@ -35,7 +35,7 @@ class W2V2Config(C.Structure):
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 64), ("launches", C.c_long), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+    _fields_ = [("name", C.c_char * 80), ("launches", C.c_long), ("total_ms", C.c_double), ("total_flops", C.c_double)]
 
 
 def _load():
@@ -154,11 +154,11 @@ def ctc_greedy_decode(logits: torch.Tensor, in_lens: torch.Tensor | None = None,
 
 def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
-         accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0):
+         accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0, pads_are_zero=False):
     """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h)."""
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
                  sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k, float(drop_p),
-                 drop_stream, drop_seed, 0)
+                 drop_stream, drop_seed, 0, int(pads_are_zero))
     ws = _ws(split_k * nb1 * nb2 * M * N * 4, A.device) if split_k > 1 else None
     check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
                              0 if ws is None else ws.numel(), stream()))
@@ -171,8 +171,8 @@ def prof_enable(on: bool):
 
 def prof_collect():
     """[(kernel name, launches, total ms, total algorithmic flops)] since the last collect."""
-    arr = (ProfEntry * 8)()
-    n = lib.ssak_prof_collect(arr, 8)
+    arr = (ProfEntry * 16)()
+    n = lib.ssak_prof_collect(arr, 16)
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops) for i in range(n)]
