@@ -17,9 +17,9 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
                     float* partial /*[LN_BWD_BLOCKS*2*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
                     hipStream_t st);
 constexpr int LN_BWD_BLOCKS = 512;
-int k_softmax_fwd(const float* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
+int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
                   int rows_per_batch, const DropSpec& drop, hipStream_t st);
-int k_softmax_bwd(const float* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
+int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
                   hipStream_t st);
 int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st);
 int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st);

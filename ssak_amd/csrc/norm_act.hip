@@ -273,9 +273,11 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------- softmax
+// Scores arrive in bf16 (what the bf16 QK^T GEMM produces); statistics are fp32.  One wave per row; a lane owns
+// 16-byte chunks (8 consecutive keys) so every access is a full-width vector load/store.
 struct SoftmaxParams {
-  const float* S;       // [rows, ld] fp32 scores (already scaled)
-  bf16* P;              // [rows, ld] probabilities (pre-dropout)
+  const bf16* S;        // [rows, ld] scores (already scaled)
+  bf16* P;              // [rows, ld] probabilities (pre-dropout); pad columns [cols, ld) are written as 0
   bf16* Pd;             // [rows, ld] dropped probabilities or null
   const int32_t* klens; // [B] valid keys per utterance or null
   int rows, cols, ld, rows_per_batch;
@@ -284,76 +286,108 @@ struct SoftmaxParams {
   float scale;
 };
 
-template <int NIT>
+template <int NCH>
 __global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxParams p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= p.rows) return;
   const int kl = p.klens ? min(p.klens[row / p.rows_per_batch], p.cols) : p.cols;
-  const float* s = p.S + (size_t)row * p.ld;
-  float v[NIT];
+  const int nch = p.ld >> 3;
+  float v[NCH][8];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = lane + 64 * i;
-    v[i] = (c < kl) ? s[c] : -INFINITY;
-    mx = fmaxf(mx, v[i]);
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[i][k] = -INFINITY;
+    if (ch < nch) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.S + (size_t)row * p.ld + ch * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[i][k] = (ch * 8 + k < kl) ? f[k] : -INFINITY;
+        mx = fmaxf(mx, v[i][k]);
+      }
+    }
   }
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    v[i] = (lane + 64 * i < kl) ? __expf(v[i] - mx) : 0.f;
-    sum += v[i];
-  }
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[i][k] = (v[i][k] == -INFINITY) ? 0.f : __expf(v[i][k] - mx);
+      sum += v[i][k];
+    }
   const float inv = 1.f / wave_sum(sum);
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = lane + 64 * i;
-    if (c < p.ld) {
-      const size_t o = (size_t)row * p.ld + c;
-      const float pr = v[i] * inv;
-      p.P[o] = (bf16)pr;
-      if (p.Pd) p.Pd[o] = (bf16)((!p.thresh || keep_bit(p.seed, p.stream, o, p.thresh)) ? pr * p.scale : 0.f);
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const size_t o = (size_t)row * p.ld + ch * 8;
+      float pr[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pr[k] = v[i][k] * inv;
+      *reinterpret_cast<uint4*>(p.P + o) = pack8(pr);
+      if (p.Pd) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pr[k] = (!p.thresh || keep_bit(p.seed, p.stream, o + k, p.thresh)) ? pr[k] * p.scale : 0.f;
+        *reinterpret_cast<uint4*>(p.Pd + o) = pack8(pr);
+      }
     }
   }
 }
 
 struct SoftmaxBwdParams {
-  const float* dPd;  // [rows, ld] fp32 grad wrt dropped probabilities
+  const bf16* dPd;   // [rows, ld] grad wrt dropped probabilities
   const bf16* P;     // [rows, ld]
-  bf16* dS;          // [rows, ld]
+  bf16* dS;          // [rows, ld]; pad columns written as 0
   int rows, cols, ld;
   uint64_t seed;
   uint32_t stream, thresh;
   float scale;
 };
 
-template <int NIT>
+template <int NCH>
 __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxBwdParams p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= p.rows) return;
-  float pr[NIT], dp[NIT];
+  const int nch = p.ld >> 3;
+  float pr[NCH][8], dp[NCH][8];
   float dot = 0.f;
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = lane + 64 * i;
-    pr[i] = 0.f;
-    dp[i] = 0.f;
-    if (c < p.cols) {
-      const size_t o = (size_t)row * p.ld + c;
-      pr[i] = (float)p.P[o];
-      const float g = p.dPd[o];
-      dp[i] = (!p.thresh || keep_bit(p.seed, p.stream, o, p.thresh)) ? g * p.scale : 0.f;
-      dot += pr[i] * dp[i];
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      pr[i][k] = 0.f;
+      dp[i][k] = 0.f;
+    }
+    if (ch < nch) {
+      const size_t o = (size_t)row * p.ld + ch * 8;
+      float g[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.P + o), pr[i]);
+      unpack8(*reinterpret_cast<const uint4*>(p.dPd + o), g);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool in = ch * 8 + k < p.cols;
+        pr[i][k] = in ? pr[i][k] : 0.f;
+        dp[i][k] = (in && (!p.thresh || keep_bit(p.seed, p.stream, o + k, p.thresh))) ? g[k] * p.scale : 0.f;
+        dot += pr[i][k] * dp[i][k];
+      }
     }
   }
   dot = wave_sum(dot);
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = lane + 64 * i;
-    if (c < p.ld) p.dS[(size_t)row * p.ld + c] = (bf16)(pr[i] * (dp[i] - dot));
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = pr[i][k] * (dp[i][k] - dot);
+      *reinterpret_cast<uint4*>(p.dS + (size_t)row * p.ld + ch * 8) = pack8(d);
+    }
   }
 }
 
@@ -490,40 +524,36 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   return SSAK_OK;
 }
 
-int k_softmax_fwd(const float* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
+int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
                   int rows_per_batch, const DropSpec& drop, hipStream_t st) {
-  SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && ld <= 24 * 64, "softmax: cols=%d ld=%d unsupported (ld <= 1536)", cols, ld);
+  SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld & 7) == 0 && ld <= 1536, "softmax: cols=%d ld=%d unsupported (ld %% 8 == 0, <= 1536)", cols, ld);
   SoftmaxParams p{S, P, Pd, klens, rows, cols, ld, rows_per_batch, drop.seed, drop.stream, thresh_of(drop.p),
                   drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
-  const int nit = ssak_cdiv(ld, 64);
-  if (nit <= 2)
+  const int nch = ssak_cdiv(ld / 8, 64);
+  if (nch == 1)
+    softmax_fwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nch == 2)
     softmax_fwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
-  else if (nit <= 8)
-    softmax_fwd_kernel<8><<<grid, ROW_THREADS, 0, st>>>(p);
-  else if (nit <= 12)
-    softmax_fwd_kernel<12><<<grid, ROW_THREADS, 0, st>>>(p);
   else
-    softmax_fwd_kernel<24><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_fwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_softmax_bwd(const float* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
+int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
                   hipStream_t st) {
-  SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && ld <= 24 * 64, "softmax_bwd: cols=%d ld=%d unsupported", cols, ld);
+  SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld & 7) == 0 && ld <= 1536, "softmax_bwd: cols=%d ld=%d unsupported", cols, ld);
   SoftmaxBwdParams p{dPd, P, dS, rows, cols, ld, drop.seed, drop.stream, thresh_of(drop.p),
                      drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
-  const int nit = ssak_cdiv(ld, 64);
-  if (nit <= 2)
+  const int nch = ssak_cdiv(ld / 8, 64);
+  if (nch == 1)
+    softmax_bwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nch == 2)
     softmax_bwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
-  else if (nit <= 8)
-    softmax_bwd_kernel<8><<<grid, ROW_THREADS, 0, st>>>(p);
-  else if (nit <= 12)
-    softmax_bwd_kernel<12><<<grid, ROW_THREADS, 0, st>>>(p);
   else
-    softmax_bwd_kernel<24><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

@@ -227,7 +227,7 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
   p.h1 = cv.take((size_t)M * H * b2);
   p.stE = cv.take((size_t)2 * M * sizeof(float));
   p.tmpH = cv.take((size_t)M * H * b2);
-  p.S = cv.take((size_t)B * nh * p.F * p.Fp * sizeof(float));
+  p.S = cv.take((size_t)B * nh * p.F * p.Fp * b2);
   p.xf = cv.take((size_t)M * H * b2);
   const int nl = c.num_layers;
   p.x.resize(nl + 1);
@@ -574,9 +574,9 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
     const bf16* x = BF(p.x[l]);
     bf16* qkv = BF(lb.qkv);
     TRY(Gemm(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
-    TRY(Gemm(F, F, hd).a(qkv, 3 * H).b(qkv + H, 3 * H).c(FP(p.S), Fp, true).alpha(scale)
+    TRY(Gemm(F, F, hd).a(qkv, 3 * H).b(qkv + H, 3 * H).c(BF(p.S), Fp).alpha(scale)
             .batch(B, nh, (long)F * 3 * H, hd, (long)F * 3 * H, hd, (long)nh * F * Fp, (long)F * Fp).run(st));
-    TRY(k_softmax_fwd(FP(p.S), BF(lb.P), lb.Pd != lb.P ? BF(lb.Pd) : nullptr, flens, B * nh * F, F, Fp, nh * F,
+    TRY(k_softmax_fwd(BF(p.S), BF(lb.P), lb.Pd != lb.P ? BF(lb.Pd) : nullptr, flens, B * nh * F, F, Fp, nh * F,
                       DS(c.attention_dropout, ds_attn(l)), st));
     TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
             .batch(B, nh, (long)nh * F * Fp, (long)F * Fp, (long)F * 3 * H, hd, (long)F * H, hd).run(st));
@@ -684,9 +684,9 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     const long sq1 = (long)F * 3 * H, sp1 = (long)nh * F * Fp, sp2 = (long)F * Fp, sh1 = (long)F * H;
     TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
             .batch(B, nh, sp1, sp2, sh1, hd, sq1, hd).run(st));  // dV = Pd^T dctx
-    TRY(Gemm(F, F, hd).a(dctx, H).b(qkv + 2 * H, 3 * H).c(FP(p.S), Fp, true)
+    TRY(Gemm(F, F, hd).a(dctx, H).b(qkv + 2 * H, 3 * H).c(BF(p.S), Fp)
             .batch(B, nh, sh1, hd, sq1, hd, sp1, sp2).run(st));  // dPd = dctx V^T
-    TRY(k_softmax_bwd(FP(p.S), BF(lb.P), BF(p.dSb), B * nh * F, F, Fp, DS(c.attention_dropout, ds_attn(l)), st));
+    TRY(k_softmax_bwd(BF(p.S), BF(lb.P), BF(p.dSb), B * nh * F, F, Fp, DS(c.attention_dropout, ds_attn(l)), st));
     TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp).b(qkv + H, 3 * H, true).c(dqkv, 3 * H).alpha(scale)
             .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dQ = scale dS K
     TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
