@@ -20,8 +20,8 @@ constexpr int FR_STATS = 1024, FR_APPLY = 128;  // frames per workgroup (statist
 template <bool APPLY, int FR0>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    bf16* __restrict__ out, double* __restrict__ stats, int T, int T0,
-                                                    int C) {
+                                                    bf16* __restrict__ out, double* __restrict__ stats,
+                                                    const double* __restrict__ sums, int T, int T0, int C) {
   constexpr int NS0 = (FR0 - 1) * ST0 + KS0;
   __shared__ float xs[NS0];
   __shared__ float red[256][9];
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
   if (APPLY) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const double s1 = stats[((size_t)b * C + q * 4 + j) * 2], s2 = stats[((size_t)b * C + q * 4 + j) * 2 + 1];
+      const double s1 = sums[((size_t)b * C + q * 4 + j) * 2], s2 = sums[((size_t)b * C + q * 4 + j) * 2 + 1];
       const double m = s1 / T0;
       const double var = fmax(s2 / T0 - m * m, 0.0);
       mu[j] = (float)m;
@@ -96,11 +96,61 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
           a += red[l * nq + q][j];
           c += red[l * nq + q][4 + j];
         }
-        atomicAdd(&stats[((size_t)b * C + q * 4 + j) * 2], a);
-        atomicAdd(&stats[((size_t)b * C + q * 4 + j) * 2 + 1], c);
+        // per-workgroup partial; conv0_stats_finalize_kernel sums them in a fixed order
+        double* dst = stats + (((size_t)b * gridDim.x + blockIdx.x) * C + q * 4 + j) * 2;
+        dst[0] = a;
+        dst[1] = c;
       }
     }
   }
+}
+
+// conv0 (+ bias) only, bf16 channels-last: the layer-norm feature encoder (XLSR) normalises over channels per frame
+// afterwards (LayerNorm + GELU row kernel), so no time statistics are needed here.
+__global__ __launch_bounds__(256) void conv0_bias_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, bf16* __restrict__ out, int T,
+                                                         int T0, int C) {
+  constexpr int FR0 = FR_APPLY, NS0 = (FR0 - 1) * ST0 + KS0;
+  __shared__ float xs[NS0];
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * FR0;
+  const int nq = C >> 2, fl = 256 / nq;
+  const int q = threadIdx.x % nq, fli = threadIdx.x / nq;
+  const int nfr = min(FR0, T0 - f0);
+  const float* xb = x + (size_t)b * T;
+  for (int i = threadIdx.x; i < NS0; i += 256) {
+    const int s = f0 * ST0 + i;
+    xs[i] = (s < T) ? xb[s] : 0.f;
+  }
+  float wr[4][KS0], bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bb[j] = bias ? bias[q * 4 + j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KS0; ++k) wr[j][k] = w[(q * 4 + j) * KS0 + k];
+  }
+  __syncthreads();
+  for (int f = fli; f < nfr; f += fl) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = bb[j];
+#pragma unroll
+      for (int k = 0; k < KS0; ++k) a = fmaf(wr[j][k], xs[f * ST0 + k], a);
+      o[j] = (bf16)a;
+    }
+    *reinterpret_cast<bf16x4*>(out + ((size_t)b * T0 + f0 + f) * C + q * 4) = o;
+  }
+}
+
+__global__ void conv0_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C, double* __restrict__ sums) {
+  // grid (ceil(2C/256), B): sums[b][c][2] = sum over the nblk workgroup partials, fixed order
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * C) return;
+  const int b = blockIdx.y;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += partial[((size_t)b * nblk + k) * 2 * C + e];
+  sums[(size_t)b * 2 * C + e] = s;
 }
 
 __global__ void conv_w_rearrange_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Co, int Ci, int k) {
@@ -115,7 +165,7 @@ __global__ void conv_w_rearrange_kernel(const float* __restrict__ w, bf16* __res
 
 // sum over rows of v[r][k]^2 (and optionally dw_fwd[o][k][c] * v[o][c][k]); K <= 1024 threads, rows strided by grid
 __global__ void posconv_colnorm_kernel(const float* __restrict__ v, const float* __restrict__ dwf, int rows, int K,
-                                       int cg, float* __restrict__ out) {
+                                       int cg, float* __restrict__ partial) {
   const int k = threadIdx.x;
   if (k >= K) return;
   float s = 0.f;
@@ -128,7 +178,14 @@ __global__ void posconv_colnorm_kernel(const float* __restrict__ v, const float*
       s = fmaf(a, a, s);
     }
   }
-  atomicAdd(out + k, s);
+  partial[(size_t)blockIdx.x * K + k] = s;
+}
+__global__ void posconv_colnorm_finalize_kernel(const float* __restrict__ partial, int nblk, int K, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * K + k];
+  out[k] = s;
 }
 
 __global__ void posconv_materialize_kernel(const float* __restrict__ g, const float* __restrict__ v,
@@ -182,15 +239,31 @@ __global__ void posconv_pack_kernel(const bf16* __restrict__ h, bf16* __restrict
 
 }  // namespace
 
+size_t k_conv0_stats_doubles(int B, int T0, int C) { return (size_t)B * 2 * C * (1 + ssak_cdiv(T0, FR_STATS)); }
+
 int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,
                     int B, int T, int T0, int C, int ksize, int stride, hipStream_t st) {
   SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
   SSAK_REQUIRE(T0 == (T - KS0) / ST0 + 1 && T0 > 0, "conv0: T0 mismatch");
-  SSAK_HIP(hipMemsetAsync(stats, 0, (size_t)B * C * 2 * sizeof(double), st));
-  conv0_kernel<false, FR_STATS><<<dim3(ssak_cdiv(T0, FR_STATS), B), 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
+  // stats layout: [B][2C] ordered sums | [B][nblk][2C] per-workgroup partials   (k_conv0_stats_doubles(B, T0, C) doubles)
+  const int nblk = ssak_cdiv(T0, FR_STATS);
+  double* sums = stats;
+  double* partial = stats + (size_t)B * 2 * C;
+  conv0_kernel<false, FR_STATS><<<dim3(nblk, B), 256, 0, st>>>(x, w, gamma, beta, out, partial, nullptr, T, T0, C);
   SSAK_LAUNCH_CHECK();
-  conv0_kernel<true, FR_APPLY><<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, gamma, beta, out, stats, T, T0, C);
+  conv0_stats_finalize_kernel<<<dim3(ssak_cdiv(2 * C, 256), B), 256, 0, st>>>(partial, nblk, C, sums);
+  SSAK_LAUNCH_CHECK();
+  conv0_kernel<true, FR_APPLY><<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, gamma, beta, out, nullptr, sums, T, T0, C);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_conv0_bias(const float* x, const float* w, const float* bias, bf16* out, int B, int T, int T0, int C, int ksize,
+                 int stride, hipStream_t st) {
+  SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
+  SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
+  conv0_bias_kernel<<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, bias, out, T, T0, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -205,8 +278,11 @@ int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, 
                       hipStream_t st) {
   SSAK_REQUIRE(K <= 1024 && H % G == 0 && ((H / G) & 7) == 0, "posconv: K=%d <= 1024 and (H/G)=%d %% 8 == 0 required", K, H / G);
   const int cg = H / G;
-  SSAK_HIP(hipMemsetAsync(norms, 0, (size_t)K * sizeof(float), st));
-  posconv_colnorm_kernel<<<256, ((K + 63) / 64) * 64, 0, st>>>(v, nullptr, H * cg, K, cg, norms);
+  // norms layout: [K] ||v||^2 | [K] dot scratch | [256][K] per-workgroup partials
+  float* partial = norms + 2 * K;
+  posconv_colnorm_kernel<<<256, ((K + 63) / 64) * 64, 0, st>>>(v, nullptr, H * cg, K, cg, partial);
+  SSAK_LAUNCH_CHECK();
+  posconv_colnorm_finalize_kernel<<<ssak_cdiv(K, 256), 256, 0, st>>>(partial, 256, K, norms);
   SSAK_LAUNCH_CHECK();
   posconv_materialize_kernel<<<min(2048, ssak_cdiv((long)H * cg * K, 256)), 256, 0, st>>>(g, v, norms, w_fwd, w_bwd, H, cg, K);
   SSAK_LAUNCH_CHECK();
@@ -218,8 +294,10 @@ int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const 
   // `dg` doubles as the scratch for dot[k] would alias the output; use the tail of `norms` (2K floats allocated)
   const int cg = H / G;
   float* dot = const_cast<float*>(norms) + K;
-  SSAK_HIP(hipMemsetAsync(dot, 0, (size_t)K * sizeof(float), st));
-  posconv_colnorm_kernel<<<256, ((K + 63) / 64) * 64, 0, st>>>(v, dw, H * cg, K, cg, dot);
+  float* partial = const_cast<float*>(norms) + 2 * K;
+  posconv_colnorm_kernel<<<256, ((K + 63) / 64) * 64, 0, st>>>(v, dw, H * cg, K, cg, partial);
+  SSAK_LAUNCH_CHECK();
+  posconv_colnorm_finalize_kernel<<<ssak_cdiv(K, 256), 256, 0, st>>>(partial, 256, K, dot);
   SSAK_LAUNCH_CHECK();
   posconv_wbwd_kernel<<<min(2048, ssak_cdiv((long)H * cg * K, 256)), 256, 0, st>>>(dw, g, v, norms, dot, dg, dv, H, cg, K);
   SSAK_LAUNCH_CHECK();

@@ -11,11 +11,11 @@ struct DropSpec {
 // norm_act.hip
 int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
                     float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
-                    hipStream_t st);
+                    hipStream_t st, const DropSpec& mid = DropSpec(), bool post_gelu = false);
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
                     const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
                     float* partial /*[LN_BWD_BLOCKS*2*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
-                    hipStream_t st);
+                    hipStream_t st, const DropSpec& mid = DropSpec());
 constexpr int LN_BWD_BLOCKS = 512;
 int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
                   int rows_per_batch, const DropSpec& drop, hipStream_t st);
@@ -32,8 +32,11 @@ int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStrea
 int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st);
 
 // conv_frontend.hip
+size_t k_conv0_stats_doubles(int B, int T0, int C);
 int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,
                     int B, int T, int T0, int C, int ksize, int stride, hipStream_t st);
+int k_conv0_bias(const float* x, const float* w, const float* bias, bf16* out, int B, int T, int T0, int C, int ksize,
+                 int stride, hipStream_t st);
 int k_conv_weight_rearrange(const float* w, bf16* out, int Co, int Ci, int k, hipStream_t st);
 int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, float* norms, int H, int G, int K,
                       hipStream_t st);

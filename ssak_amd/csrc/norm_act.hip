@@ -47,6 +47,9 @@ struct LnFwdParams {
   uint64_t seed;
   uint32_t pre_stream, pre_thresh, post_stream, post_thresh;
   float pre_scale, post_scale;
+  uint32_t mid_stream, mid_thresh;  // dropout applied to the SUM res + drop(y) (stable-LN encoder input)
+  float mid_scale;
+  int post_gelu;                    // out = gelu(LN(r))  (layer-norm feature-encoder conv layers)
 };
 
 template <int NCH>
@@ -76,6 +79,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
         unpack8(*reinterpret_cast<const uint4*>(p.res + o), r);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[i][k] += r[k];
+      }
+      if (p.mid_thresh) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[i][k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? v[i][k] * p.mid_scale : 0.f;
       }
       if (p.r_out) {
         // round through bf16 so that forward and backward see the same LN input
@@ -117,6 +124,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         w[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
+        if (p.post_gelu) w[k] = gelu_f(w[k]);
         if (p.post_thresh) w[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? w[k] * p.post_scale : 0.f;
       }
       *reinterpret_cast<uint4*>(p.out + o) = pack8(w);
@@ -142,6 +150,8 @@ struct LnBwdParams {
   uint32_t pre_stream, pre_thresh, post_stream, post_thresh;
   float pre_scale, post_scale;
   int rows_per_wave;
+  uint32_t mid_stream, mid_thresh;
+  float mid_scale;
 };
 
 template <int NCH>
@@ -211,6 +221,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
           unpack8(*reinterpret_cast<const uint4*>(p.g_res + o), e);
 #pragma unroll
           for (int k = 0; k < 8; ++k) d[k] += e[k];
+        }
+        if (p.mid_thresh) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) d[k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? d[k] * p.mid_scale : 0.f;
         }
         *reinterpret_cast<uint4*>(p.dr + o) = pack8(d);
         if (p.dy) {
@@ -484,11 +498,12 @@ uint32_t thresh_of(float p) { return p <= 0.f ? 0u : (uint32_t)fminf(4294967295.
 
 int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
                     float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
-                    hipStream_t st) {
+                    hipStream_t st, const DropSpec& mid, bool post_gelu) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
   LnFwdParams p{y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
-                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f};
+                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f,
+                mid.stream, thresh_of(mid.p), mid.p > 0.f ? 1.f / (1.f - mid.p) : 1.f, post_gelu ? 1 : 0};
   const int grid = ssak_cdiv(M, ROW_THREADS / 64);
   const int nch = ssak_cdiv(C / 8, 64);
   if (nch == 1)
@@ -503,11 +518,13 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
 
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
                     const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
-                    float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st) {
+                    float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st,
+                    const DropSpec& mid) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm_bwd: C=%d must be a multiple of 8 and <= 1536", C);
   LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, M, C, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
-                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f, 1};
+                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f, 1,
+                mid.stream, thresh_of(mid.p), mid.p > 0.f ? 1.f / (1.f - mid.p) : 1.f};
   // LN_BWD_BLOCKS workgroups of 4 waves stride over the rows and keep column partials in registers
   p.rows_per_wave = 0;
   const int grid = std::min(LN_BWD_BLOCKS, ssak_cdiv(M, ROW_THREADS / 64));

@@ -71,7 +71,8 @@ struct ssak_w2v2 {
   long n_total = 0, n_train = 0;
   // parameter offsets (elements into the flat buffers)
   long p_mse, p_fpln_w, p_fpln_b, p_fp_w, p_fp_b, p_pc_b, p_pc_g, p_pc_v, p_eln_w, p_eln_b, p_lm_w, p_lm_b;
-  long p_conv_w[8], p_gn_w, p_gn_b;
+  long p_conv_w[8], p_conv_b[8], p_cln_w[8], p_cln_b[8];  // conv weight / bias / per-layer norm (group: layer 0 only)
+  std::vector<size_t> hres;  // stable-LN: residual-stream buffer that feeds the LayerNorm producing x[l]
   std::vector<LayerP> lp;
   // bound buffers (caller-owned)
   float* P = nullptr;
@@ -166,9 +167,10 @@ void build_param_table(ssak_w2v2* e) {
   for (int i = 0; i < c.num_conv_layers; ++i) {
     const std::string p = "wav2vec2.feature_extractor.conv_layers." + std::to_string(i) + ".";
     add_param(e, cur, p + "conv.weight", {c.conv_dim[i], cin, c.conv_kernel[i]}, 1, &e->p_conv_w[i]);
-    if (i == 0) {
-      add_param(e, cur, p + "layer_norm.weight", {c.conv_dim[0]}, 1, &e->p_gn_w);
-      add_param(e, cur, p + "layer_norm.bias", {c.conv_dim[0]}, 1, &e->p_gn_b);
+    if (c.conv_bias) add_param(e, cur, p + "conv.bias", {c.conv_dim[i]}, 1, &e->p_conv_b[i]);
+    if (i == 0 || c.feat_extract_norm == 1) {
+      add_param(e, cur, p + "layer_norm.weight", {c.conv_dim[i]}, 1, &e->p_cln_w[i]);
+      add_param(e, cur, p + "layer_norm.bias", {c.conv_dim[i]}, 1, &e->p_cln_b[i]);
     }
     cin = c.conv_dim[i];
   }
@@ -177,9 +179,7 @@ void build_param_table(ssak_w2v2* e) {
 
 int check_config(const ssak_w2v2_config& c) {
   SSAK_REQUIRE(c.num_conv_layers >= 2 && c.num_conv_layers <= 8, "w2v2: num_conv_layers %d unsupported", c.num_conv_layers);
-  SSAK_REQUIRE(c.feat_extract_norm == 0 && !c.conv_bias && !c.do_stable_layer_norm,
-               "w2v2: only the group-norm / post-LN (wav2vec2-base) topology is built in this round; "
-               "layer-norm feature encoder / stable-layer-norm (XLSR) is not");
+  SSAK_REQUIRE(c.feat_extract_norm == 0 || c.feat_extract_norm == 1, "w2v2: feat_extract_norm must be 0 (group) or 1 (layer)");
   SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "w2v2: head_dim must be a multiple of 8");
   SSAK_REQUIRE(c.hidden_size % 8 == 0 && c.intermediate_size % 8 == 0 && c.vocab_size % 8 == 0,
                "w2v2: hidden/intermediate/vocab sizes must be multiples of 8 (pad the vocabulary)");
@@ -216,7 +216,7 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
   p.bufA = cv.take((size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
   p.bufB = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
   p.feat = cv.take((size_t)M * C * b2);
-  p.stats0 = cv.take((size_t)B * c.conv_dim[0] * 2 * sizeof(double));
+  p.stats0 = cv.take(k_conv0_stats_doubles(B, p.Tl[0], c.conv_dim[0]) * sizeof(double));
   p.flens = cv.take((size_t)B * sizeof(int32_t));
   p.ln0 = cv.take((size_t)M * C * b2);
   p.st0 = cv.take((size_t)2 * M * sizeof(float));
@@ -394,7 +394,7 @@ extern "C" int ssak_w2v2_create(const ssak_w2v2_config* cfg, ssak_w2v2** out) {
   }
   SSAK_HIP(hipMalloc((void**)&e->pc_wf, (size_t)H * K * cg * sizeof(bf16)));
   SSAK_HIP(hipMalloc((void**)&e->pc_wb, (size_t)H * K * cg * sizeof(bf16)));
-  SSAK_HIP(hipMalloc((void**)&e->pc_norms, (size_t)2 * K * sizeof(float)));
+  SSAK_HIP(hipMalloc((void**)&e->pc_norms, (size_t)(2 + 256) * K * sizeof(float)));
   *out = e;
   return SSAK_OK;
 }
@@ -523,20 +523,31 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   }
 
   // ---- a3: feature encoder (frozen: forward only)
-  TRY(k_conv0_gn_gelu(input_values, P + e->p_conv_w[0], P + e->p_gn_w, P + e->p_gn_b, BF(p.bufA), (double*)(ws + p.stats0),
-                      B, T, p.Tl[0], c.conv_dim[0], c.conv_kernel[0], c.conv_stride[0], st));
+  const bool ln_fe = c.feat_extract_norm == 1;
+  if (!ln_fe) {
+    TRY(k_conv0_gn_gelu(input_values, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0], BF(p.bufA),
+                        (double*)(ws + p.stats0), B, T, p.Tl[0], c.conv_dim[0], c.conv_kernel[0], c.conv_stride[0], st));
+  } else {
+    // layer-norm variant (XLSR, modeling_wav2vec2.py:275-299): conv + bias -> LayerNorm over channels -> GELU
+    TRY(k_conv0_bias(input_values, P + e->p_conv_w[0], c.conv_bias ? P + e->p_conv_b[0] : nullptr, BF(p.bufA), B, T,
+                     p.Tl[0], c.conv_dim[0], c.conv_kernel[0], c.conv_stride[0], st));
+    TRY(k_layernorm_fwd(BF(p.bufA), nullptr, P + e->p_cln_w[0], P + e->p_cln_b[0], nullptr, BF(p.bufA), nullptr, nullptr,
+                        B * p.Tl[0], c.conv_dim[0], 1e-5f, none, none, st, none, true));
+  }
   {
     bf16* src = BF(p.bufA);
     for (int i = 1; i < nc; ++i) {
       bf16* dst = (i == nc - 1) ? BF(p.feat) : ((i & 1) ? BF(p.bufB) : BF(p.bufA));
       const int Ci = c.conv_dim[i - 1], Co = c.conv_dim[i], k = c.conv_kernel[i], s = c.conv_stride[i];
-      TRY(Gemm(p.Tl[i], Co, k * Ci)
-              .a(src, (long)s * Ci)
-              .b(e->conv_w[i], (long)k * Ci)
-              .c(dst, Co)
-              .batch(B, 1, (long)p.Tl[i - 1] * Ci, 0, 0, 0, (long)p.Tl[i] * Co, 0)
-              .epi(SSAK_EPI_GELU)
-              .run(st));
+      Gemm g(p.Tl[i], Co, k * Ci);
+      g.a(src, (long)s * Ci).b(e->conv_w[i], (long)k * Ci).c(dst, Co)
+          .batch(B, 1, (long)p.Tl[i - 1] * Ci, 0, 0, 0, (long)p.Tl[i] * Co, 0);
+      if (c.conv_bias) g.with_bias(P + e->p_conv_b[i]);
+      if (!ln_fe) g.epi(SSAK_EPI_GELU);
+      TRY(g.run(st));
+      if (ln_fe)
+        TRY(k_layernorm_fwd(dst, nullptr, P + e->p_cln_w[i], P + e->p_cln_b[i], nullptr, dst, nullptr, nullptr, B * p.Tl[i], Co,
+                            1e-5f, none, none, st, none, true));
       src = dst;
     }
   }
@@ -557,20 +568,40 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
           .with_bias(P + e->p_pc_b, cg)
           .epi(SSAK_EPI_GELU, nullptr, BF(p.pc_pre))
           .run(st));
-  TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->p_eln_w, P + e->p_eln_b, BF(p.h1), BF(p.x[0]), FP(p.stE), FP(p.stE) + M,
-                      M, H, c.layer_norm_eps, none, DS(c.hidden_dropout, DS_ENCIN), st));
-  // ---- a7: encoder layers (post-LN) with LayerDrop
+  const bool stable = c.do_stable_layer_norm != 0;
+  if (!stable) {
+    // post-LN (base): x0 = dropout(LN(h0 + pos))                                       (modeling_wav2vec2.py:694-697)
+    TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->p_eln_w, P + e->p_eln_b, BF(p.h1), BF(p.x[0]), FP(p.stE), FP(p.stE) + M,
+                        M, H, c.layer_norm_eps, none, DS(c.hidden_dropout, DS_ENCIN), st));
+  } else {
+    // stable-LN (XLSR): residual stream r = dropout(h0 + pos); x0 = LN1 of layer 0 applied to r   (:763-771, :631-640)
+    TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
+                        FP(p.stE) + M, M, H, c.layer_norm_eps, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
+  }
+  // ---- a7: encoder layers with LayerDrop: post-LN (base, :591-608) or pre-LN "stable layer norm" (XLSR, :631-654)
   e->keep.assign(c.num_layers, 1);
+  e->hres.assign(c.num_layers + 1, p.h1);
   const float scale = 1.f / sqrtf((float)hd);
   for (int l = 0; l < c.num_layers; ++l) {
-    if (tr && layer_keep && !layer_keep[l]) {
-      e->keep[l] = 0;
-      // skipped layer: output = input (modeling_wav2vec2.py:701-712)
-      SSAK_HIP(hipMemcpyAsync(BF(p.x[l + 1]), BF(p.x[l]), (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
-      continue;
-    }
     const LayerP& L = e->lp[l];
     const LayerBuf& lb = p.lb[l];
+    float* stl = FP(lb.st);
+    // LayerNorm that produces the next layer's input in stable mode (next layer's LN1, or the encoder's final LN)
+    const float* nxt_w = P + ((l + 1 < c.num_layers) ? e->lp[l + 1].ln1w : e->p_eln_w);
+    const float* nxt_b = P + ((l + 1 < c.num_layers) ? e->lp[l + 1].ln1b : e->p_eln_b);
+    if (tr && layer_keep && !layer_keep[l]) {
+      e->keep[l] = 0;
+      if (!stable) {
+        // skipped layer: output = input (modeling_wav2vec2.py:701-712)
+        SSAK_HIP(hipMemcpyAsync(BF(p.x[l + 1]), BF(p.x[l]), (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
+      } else {
+        // the residual stream passes through; the next LayerNorm still has to be applied to it
+        TRY(k_layernorm_fwd(BF(e->hres[l]), nullptr, nxt_w, nxt_b, nullptr, BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M, M, H,
+                            c.layer_norm_eps, none, none, st));
+        e->hres[l + 1] = e->hres[l];
+      }
+      continue;
+    }
     const bf16* x = BF(p.x[l]);
     bf16* qkv = BF(lb.qkv);
     TRY(Gemm(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
@@ -581,14 +612,26 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
     TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
             .batch(B, nh, (long)nh * F * Fp, (long)F * Fp, (long)F * 3 * H, hd, (long)F * H, hd).run(st));
     TRY(Gemm(M, H, H).a(BF(lb.ctx), H).b(W + L.wo, H).c(BF(p.tmpH), H).with_bias(P + L.bo).run(st));
-    float* stl = FP(lb.st);
-    TRY(k_layernorm_fwd(BF(p.tmpH), x, P + L.ln1w, P + L.ln1b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
-                        c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    if (!stable) {
+      TRY(k_layernorm_fwd(BF(p.tmpH), x, P + L.ln1w, P + L.ln1b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
+                          c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    } else {
+      // r1 = r + drop(attn);  x1 = final_layer_norm(r1)
+      TRY(k_layernorm_fwd(BF(p.tmpH), BF(e->hres[l]), P + L.ln2w, P + L.ln2b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
+                          c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    }
     TRY(Gemm(M, I, H).a(BF(lb.x1), H).b(W + L.w1, H).c(BF(lb.f1), I).with_bias(P + L.b1)
             .epi(SSAK_EPI_GELU, nullptr, BF(lb.f1pre)).drop(tr ? c.activation_dropout : 0.f, ds_act(l), seed).run(st));
     TRY(Gemm(M, H, I).a(BF(lb.f1), I).b(W + L.w2, I).c(BF(p.tmpH), H).with_bias(P + L.b2).run(st));
-    TRY(k_layernorm_fwd(BF(p.tmpH), BF(lb.x1), P + L.ln2w, P + L.ln2b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M,
-                        M, H, c.layer_norm_eps, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+    if (!stable) {
+      TRY(k_layernorm_fwd(BF(p.tmpH), BF(lb.x1), P + L.ln2w, P + L.ln2b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M,
+                          M, H, c.layer_norm_eps, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+    } else {
+      // r2 = r1 + drop(ffn);  x[l+1] = (next layer's LN1 | encoder LN)(r2)
+      TRY(k_layernorm_fwd(BF(p.tmpH), BF(lb.r1), nxt_w, nxt_b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M, M, H,
+                          c.layer_norm_eps, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+      e->hres[l + 1] = lb.r2;
+    }
   }
   // ---- a8: final dropout + lm_head -> fp32 logits
   const bf16* xl = BF(p.x[c.num_layers]);
@@ -648,18 +691,46 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   bf16* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
   bf16* gB = nullptr;
   TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).drop(c.final_dropout, DS_FINAL, seed).run(st));
-  // ---- encoder layers, last to first
+  // ---- encoder layers, last to first.  gA (+gB) = gradient w.r.t. x[l+1], the layer output (post-LN) or the
+  // normalised input of the next layer (stable-LN); Gres = gradient of the residual stream (stable-LN only).
+  const bool stable = c.do_stable_layer_norm != 0;
+  const bool hdrop = c.hidden_dropout > 0.f;
+  const bf16* Gres = nullptr;
+  auto free_buf = [&](const bf16* u1, const bf16* u2, const bf16* u3) {
+    bf16* cand[3] = {BF(p.dC), BF(p.dA), BF(p.scratchH)};
+    for (bf16* cnd : cand)
+      if (cnd != u1 && cnd != u2 && cnd != u3) return cnd;
+    return (bf16*)nullptr;
+  };
   for (int l = c.num_layers - 1; l >= 0; --l) {
-    if (!e->keep[l]) continue;  // identity layer: gradient passes through unchanged
     const LayerP& L = e->lp[l];
     const LayerBuf& lb = p.lb[l];
     float* stl = FP(lb.st);
-    bf16* dR = BF(p.dC);   // grad wrt r2, then reused
+    const long nxt_w = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1w : e->p_eln_w;
+    const long nxt_b = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1b : e->p_eln_b;
+    if (!e->keep[l]) {
+      if (!stable) continue;  // identity layer: gradient passes through unchanged
+      // x[l+1] = LN_next(r): its gradient joins the residual-stream gradient; nothing consumed x[l]
+      bf16* dr = free_buf(gA, gB, Gres);
+      TRY(k_layernorm_bwd(gA, gB, BF(e->hres[l]), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dr, nullptr, Gd + nxt_w, Gd + nxt_b,
+                          FP(p.lnpart), M, H, none, none, st));
+      Gres = dr;
+      gA = BF(p.dB);
+      gB = nullptr;
+      SSAK_HIP(hipMemsetAsync(gA, 0, (size_t)M * H * sizeof(bf16), st));
+      continue;
+    }
+    bf16* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
     bf16* dY = BF(p.dY);
-    const bool hdrop = c.hidden_dropout > 0.f;
-    // final_layer_norm backward: r2 = x1 + drop(ffn)
-    TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, hdrop ? dY : nullptr,
-                        Gd + L.ln2w, Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+    if (!stable) {
+      // final_layer_norm backward: r2 = x1 + drop(ffn)
+      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, hdrop ? dY : nullptr,
+                          Gd + L.ln2w, Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+    } else {
+      // (next LN) backward: x[l+1] = LN_next(r2), r2 = r1 + drop(ffn); the residual-stream gradient is added after it
+      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dR, hdrop ? dY : nullptr, Gd + nxt_w,
+                          Gd + nxt_b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+    }
     const bf16* dy2 = hdrop ? dY : dR;
     TRY(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum(dy2, H, M, H, Gd + L.b2, st));
@@ -669,14 +740,22 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     TRY(k_colsum(BF(p.dI), I, M, I, Gd + L.b1, st));
     bf16* dX = BF(p.dB);
     TRY(Gemm(M, H, I).a(BF(p.dI), I).b(W + L.w1, H, true).c(dX, H).run(st));
-    // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
-    bf16* dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
-    TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, hdrop ? dY : nullptr, Gd + L.ln1w,
-                        Gd + L.ln1b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    bf16* dR1;
+    if (!stable) {
+      // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
+      dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
+      TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, hdrop ? dY : nullptr, Gd + L.ln1w,
+                          Gd + L.ln1b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    } else {
+      // final_layer_norm backward: x1 = LN(r1), r1 = r + drop(attn_out); residual gradient dR is added after it
+      dR1 = free_buf(dR, dX, nullptr);
+      TRY(k_layernorm_bwd(dX, nullptr, BF(lb.r1), stl, stl + M, P + L.ln2w, dR, dR1, hdrop ? dY : nullptr, Gd + L.ln2w,
+                          Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+    }
     const bf16* dy1 = hdrop ? dY : dR1;
     TRY(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum(dy1, H, M, H, Gd + L.bo, st));
-    bf16* dctx = BF(p.dC);
+    bf16* dctx = free_buf(dR1, dX, nullptr);
     TRY(Gemm(M, H, H).a(dy1, H).b(W + L.wo, H, true).c(dctx, H).run(st));
     // attention backward per (utterance, head)
     bf16* qkv = BF(lb.qkv);
@@ -694,14 +773,27 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     TRY(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st));
     TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
-    // gradient w.r.t. this layer's input = dR1 (residual of r1) + dX
-    gA = dR1;
-    gB = dX;
+    if (!stable) {
+      // gradient w.r.t. this layer's input = dR1 (residual of r1) + dX
+      gA = dR1;
+      gB = dX;
+    } else {
+      gA = dX;  // gradient w.r.t. x[l] = LN1_l(residual stream); the stream's own gradient is dR1
+      gB = nullptr;
+      Gres = dR1;
+    }
   }
-  // ---- encoder input: x0 = drop(LN(h1)), h1 = h0 + gelu(posconv(h0))
-  bf16* dh1 = BF(p.dC);
-  TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->p_eln_w, nullptr, dh1, nullptr, Gd + e->p_eln_w,
-                      Gd + e->p_eln_b, FP(p.lnpart), M, H, none, DS(c.hidden_dropout, DS_ENCIN), st));
+  // ---- encoder input
+  bf16* dh1 = free_buf(gA, gB, Gres);
+  if (!stable) {
+    // x0 = drop(LN(h1)), h1 = h0 + gelu(posconv(h0))
+    TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->p_eln_w, nullptr, dh1, nullptr, Gd + e->p_eln_w,
+                        Gd + e->p_eln_b, FP(p.lnpart), M, H, none, DS(c.hidden_dropout, DS_ENCIN), st));
+  } else {
+    // x0 = LN1_0(r), r = drop(h0 + gelu(posconv(h0))): LN backward + residual-stream gradient, then the dropout mask
+    TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->lp[0].ln1w, Gres, dh1, nullptr, Gd + e->lp[0].ln1w,
+                        Gd + e->lp[0].ln1b, FP(p.lnpart), M, H, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
+  }
   bf16* dpre = BF(p.dY);
   TRY(k_gelu_grad_mul(dh1, BF(p.pc_pre), dpre, (long)M * H, st));
   TRY(k_colsum(dpre, H, M, H, Gd + e->p_pc_b, st));
@@ -725,7 +817,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
             .batch(B, G, (long)RS * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
             .run(st));
   }
-  bf16* dh0 = BF(p.dA);
+  bf16* dh0 = (dh1 == BF(p.dA)) ? BF(p.dC) : BF(p.dA);
   TRY(k_add_bf16(dh1, BF(p.dB), dh0, (long)M * H, st));
   TRY(k_specaug_bwd(dh0, e->spec_mask, flens, Gd + e->p_mse, B, F, H, st));
   // ---- feature projection

@@ -91,6 +91,60 @@ def test_tiny_ragged_lengths_vs_oracle(mods):
     _check_grads(model, {n: g.numpy() for n, g in grads.items()}, 6e-2)
 
 
+def test_tiny_xlsr_topology_vs_hf(mods, gold):
+    """Layer-norm feature encoder with conv bias + stable-layer-norm (pre-LN) layers + attention mask on ragged
+    lengths (the XLSR-53 shape of BASELINE config 5), against the transformers golden."""
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    z = gold("w2v2_tiny_xlsr.npz")
+    oc = R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True).deterministic()
+    model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).train()
+    model.load_state_dict(R.init_params(oc, 70))
+    lens = list(z["lens"])
+    out = model(torch.tensor(z["x"]), lengths=torch.tensor(lens), labels=torch.tensor(z["labels"]))
+    fl = R.conv_out_lengths(oc, lens)
+    for b in range(len(lens)):
+        assert rel_l2(out.logits[b, :fl[b]].cpu().numpy(), z["logits"][b, :fl[b]]) < 2e-2
+    assert abs(out.loss.item() - float(z["loss"])) < 2e-2 * float(z["loss"])
+    model.backward()
+    worst = _check_grads(model, {k[5:]: z[k] for k in z.files if k.startswith("grad/")}, 6e-2)
+    print("tiny xlsr worst grad", worst)
+
+
+def test_xlsr_layerdrop_and_dropout_vs_oracle(mods):
+    """stable-LN with a dropped layer (explicit layer_keep) and SpecAugment mask, dropouts off: against the oracle."""
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    import dataclasses
+    oc = R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True, num_hidden_layers=3).deterministic()
+    p = R.init_params(oc, 9)
+    rng = np.random.default_rng(2)
+    x = R.zero_mean_unit_var_norm([rng.standard_normal(8000).astype(np.float32) for _ in range(2)])
+    labels = R.pad_labels([[3, 4, 5, 6], [7, 8]])
+    mask = R.compute_mask_indices((2, 24), 0.2, 3, None, 2, rng=np.random.RandomState(3))
+    keep = [True, False, True]
+    loss, logits, grads = R.loss_and_grads(p, oc, torch.tensor(x), None, torch.tensor(labels),
+                                           mask_time_indices=torch.tensor(mask), layer_keep=keep)
+    model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).train()
+    model.load_state_dict(p)
+    out = model(torch.tensor(x), labels=torch.tensor(labels), mask_time_indices=mask, layer_keep=keep)
+    assert rel_l2(out.logits.cpu().numpy(), logits.numpy()) < 2e-2
+    model.backward()
+    g = {n: v.numpy() for n, v in grads.items()}
+    _check_grads(model, g, 6e-2)
+    assert float(model.grad("wav2vec2.encoder.layers.1.attention.out_proj.weight").abs().max()) == 0.0
+    assert float(model.grad("wav2vec2.encoder.layers.2.layer_norm.weight").abs().max()) > 0.0
+    # dropouts on: finite and replayable
+    oc2 = dataclasses.replace(oc, attention_dropout=0.1, hidden_dropout=0.1, activation_dropout=0.1, final_dropout=0.1)
+    losses = []
+    for rep in range(2):
+        m2 = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc2), seed=5).train()
+        m2.load_state_dict(p)
+        o2 = m2(torch.tensor(x), labels=torch.tensor(labels), layer_keep=keep)
+        m2.backward()
+        losses.append((o2.loss.item(), m2.grads.clone()))
+    assert np.isfinite(losses[0][0]) and losses[0][0] == losses[1][0]
+    assert (losses[0][1] - losses[1][1]).abs().max().item() < 1e-6
+
+
 def test_base_vs_hf_golden(mods, gold):
     """wav2vec2-base, B=2, 10 s utterances (499 frames): logits / loss / per-parameter gradient norms against
     transformers.Wav2Vec2ForCTC (golden), inputs regenerated from the committed seed."""
