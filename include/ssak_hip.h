@@ -163,6 +163,13 @@ size_t ssak_w2v2_workspace_bytes(const ssak_w2v2* h, int B, int T, int training)
 int ssak_w2v2_forward(ssak_w2v2* h, const float* input_values, const int32_t* lens, int B, int T,
                       const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed, int training,
                       float* logits, int32_t* frame_lens, void* workspace, size_t workspace_bytes, void* stream);
+/* Optional: called (on the host, from inside ssak_w2v2_backward) each time all kernels writing a contiguous range
+ * grads[offset, offset+count) have been enqueued on the stream -- once per encoder layer (top to bottom), then for
+ * the rest.  The ranges are disjoint and cover [0, num_trainable).  A data-parallel caller launches one bucketed
+ * all-reduce per announcement on a side stream so that the exchange overlaps the remaining backward
+ * (the reference's nn.DataParallel reduces after backward, docker/transformers_modified/trainer.py:1345-1346). */
+typedef void (*ssak_grad_ready_fn)(long offset, long count, void* user);
+int ssak_w2v2_set_grad_ready_callback(ssak_w2v2* h, ssak_grad_ready_fn fn, void* user);
 /* dlogits [B,F,V] fp32 (e.g. from ssak_ctc_loss_fwd_bwd); overwrites grads[0, num_trainable). */
 int ssak_w2v2_backward(ssak_w2v2* h, const float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -89,6 +89,8 @@ struct ssak_w2v2 {
   const uint8_t* spec_mask = nullptr;
   const int32_t* lens = nullptr;
   std::vector<int> keep;  // LayerDrop decisions of the last forward
+  ssak_grad_ready_fn on_ready = nullptr;  // announces finished gradient ranges during backward (bucketed all-reduce)
+  void* on_ready_user = nullptr;
 };
 
 namespace {
@@ -437,6 +439,13 @@ extern "C" int ssak_w2v2_bind(ssak_w2v2* e, float* params, float* grads, void* s
   return SSAK_OK;
 }
 
+extern "C" int ssak_w2v2_set_grad_ready_callback(ssak_w2v2* e, ssak_grad_ready_fn fn, void* user) {
+  SSAK_REQUIRE(e, "w2v2_set_grad_ready_callback: null handle");
+  e->on_ready = fn;
+  e->on_ready_user = user;
+  return SSAK_OK;
+}
+
 extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
   SSAK_REQUIRE(e && e->P && e->W, "w2v2_sync_weights: bind the parameter buffers first");
   hipStream_t st = (hipStream_t)stream;
@@ -688,6 +697,11 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   const bf16* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
   TRY(Gemm(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
   TRY(k_colsum(dlog, V, M, V, Gd + e->p_lm_b, st));
+  auto announce = [&](long off, long cnt) {
+    if (e->on_ready && cnt > 0) e->on_ready(off, cnt, e->on_ready_user);
+  };
+  const long layer_span = (e->lp[0].w2 + (long)H * I) - e->lp[0].wqkv;  // wqkv|wo|w1|w2 of one layer are contiguous
+  announce(e->p_lm_w, (long)V * H);
   bf16* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
   bf16* gB = nullptr;
   TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).drop(c.final_dropout, DS_FINAL, seed).run(st));
@@ -709,6 +723,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     const long nxt_w = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1w : e->p_eln_w;
     const long nxt_b = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1b : e->p_eln_b;
     if (!e->keep[l]) {
+      announce(L.wqkv, layer_span);  // zeros (memset above), still part of the all-reduce
       if (!stable) continue;  // identity layer: gradient passes through unchanged
       // x[l+1] = LN_next(r): its gradient joins the residual-stream gradient; nothing consumed x[l]
       bf16* dr = free_buf(gA, gB, Gres);
@@ -773,6 +788,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     TRY(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st));
     TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
+    announce(L.wqkv, layer_span);
     if (!stable) {
       // gradient w.r.t. this layer's input = dR1 (residual of r1) + dX
       gA = dR1;
@@ -833,6 +849,9 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(Gemm(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
   TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, BF(p.ln0), nullptr,
                       Gd + e->p_fpln_w, Gd + e->p_fpln_b, FP(p.lnpart), M, C, none, none, st));
+  // everything else: the leading small matrices and the whole vector region (biases, LayerNorm affine)
+  announce(0, e->lp[0].wqkv);
+  announce(e->p_lm_w + (long)V * H, e->n_train - (e->p_lm_w + (long)V * H));
   e->have_fwd = false;
   return SSAK_OK;
 }

@@ -38,6 +38,9 @@ class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 80), ("launches", C.c_long), ("total_ms", C.c_double), ("total_flops", C.c_double)]
 
 
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_long, C.c_long, C.c_void_p)
+
+
 def _load():
     if not os.path.exists(_LIB_PATH):
         raise ImportError(f"{_LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
@@ -70,6 +73,7 @@ def _load():
         "ssak_w2v2_workspace_bytes": (sz, [vp, i32, i32, i32]),
         "ssak_w2v2_forward": (i32, [vp, vp, vp, i32, i32, vp, vp, C.c_uint64, i32, vp, vp, vp, sz, vp]),
         "ssak_w2v2_backward": (i32, [vp, vp, vp, sz, vp]),
+        "ssak_w2v2_set_grad_ready_callback": (i32, [vp, GRAD_READY_FN, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -240,5 +240,14 @@ class Wav2Vec2ForCTC:
             hip.check(hip.lib.ssak_w2v2_backward(self._h, hip.ptr(dlogits), hip.ptr(self._ws), self._ws.numel(), hip.stream()))
         self._last = None
 
+    def set_grad_ready_callback(self, fn):
+        """``fn(offset, count)`` is called during :meth:`backward` whenever grads[offset:offset+count] is final
+        (kernels enqueued); ``None`` removes it.  Used by the data-parallel trainer for bucketed all-reduce."""
+        if fn is None:
+            self._cb = hip.GRAD_READY_FN()  # NULL function pointer
+        else:
+            self._cb = hip.GRAD_READY_FN(lambda off, cnt, _user: fn(off, cnt))
+        hip.check(hip.lib.ssak_w2v2_set_grad_ready_callback(self._h, self._cb, None))
+
     def named_grads(self):
         return {n: self.grad(n) for n, (off, _, _) in self.layout.items() if off < self.num_trainable}

@@ -196,3 +196,48 @@ def test_dropout_replay_and_layerdrop(mods):
         assert float(model.grad("wav2vec2.encoder.layers.0.feed_forward.output_dense.weight").abs().max()) > 0.0
     assert outs[0][0] == outs[1][0]
     assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-6
+
+
+def test_trainer_bucketed_allreduce_single_rank(mods):
+    """The data-parallel code path on one GPU (world_size 1 over RCCL): gradient ranges announced by the engine are
+    disjoint, cover [0, num_trainable) and the bucketed step equals the plain step."""
+    import os
+    import torch.distributed as dist
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    from ssak_amd.trainer import AdamW, Trainer
+    oc = R.W2V2Config.tiny().deterministic()
+    p = R.init_params(oc, 3)
+    rng = np.random.default_rng(1)
+    x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(8000).astype(np.float32) for _ in range(2)])).cuda()
+    labels = torch.tensor(R.pad_labels([[3, 4, 5], [6, 7]])).cuda()
+
+    def run(distributed):
+        model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc), seed=11).train()
+        model.load_state_dict(p)
+        seen = []
+        if distributed:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        try:
+            tr = Trainer(model, AdamW(model, warmup_steps=0, lr=1e-3))
+            if distributed:
+                orig = tr._on_grads_ready
+                model.set_grad_ready_callback(lambda o, c: (seen.append((o, c)), orig(o, c)))
+            for _ in range(2):
+                loss = tr.train_step(x, None, labels, raw=False)
+            torch.cuda.synchronize()
+        finally:
+            if distributed:
+                dist.destroy_process_group()
+        return model.params.clone(), float(loss.item()), seen
+
+    p0, l0, _ = run(False)
+    p1, l1, seen = run(True)
+    # not bitwise: the CTC posterior sums use LDS float atomics (order-dependent last bits)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) and (p0 - p1).abs().max().item() < 1e-5
+    per_step = seen[:len(seen) // 2]
+    spans = sorted(per_step)
+    assert spans[0][0] == 0 and all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    n_train = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).num_trainable
+    assert spans[-1][0] + spans[-1][1] == n_train
+    assert sum(c for _, c in spans) >= n_train - 8 * len(spans)  # only alignment padding is left out
