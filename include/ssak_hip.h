@@ -106,7 +106,7 @@ typedef struct {
   double total_flops;
 } ssak_prof_entry;
 int ssak_prof_enable(int on);
-int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 16; returns the number of entries (16) */
+int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 20; returns the number of entries (20) */
 
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer

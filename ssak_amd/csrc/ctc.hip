@@ -66,9 +66,13 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(const float* __restric
     for (int c = lane; c < V; c += 64) lp[(size_t)t * V + c] = lg[(size_t)t * V + c] - lz;
   }
   if (tid == CTC_THREADS - 1) {
-    int L = 0;
+    int L = 0, bad_label = 0;
     for (int i = 0; i < Lmax; ++i) {
-      const int v = labels[(size_t)b * Lmax + i];
+      int v = labels[(size_t)b * Lmax + i];
+      if (v >= V) {  // "Label values must be <= vocab_size": flagged here, surfaced as a NaN loss (no host sync)
+        bad_label = 1;
+        v = blank;
+      }
       if (v >= 0) {
         ext[2 * L] = blank;
         ext[2 * L + 1] = v;
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(const float* __restric
     }
     ext[2 * L] = blank;
     imisc[0] = L;
+    imisc[2] = bad_label;
   }
   __syncthreads();
   const int L = imisc[0];
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(const float* __restric
     const bool bad = !(nll < INFINITY);  // inf or nan
     float w = (reduction == SSAK_REDUCTION_MEAN) ? 1.f / ((float)max(L, 1) * (float)B) : 1.f;
     if (bad && zero_inf) nll = 0.f;
+    if (imisc[2]) nll = NAN;
     misc[0] = ll;
     misc[1] = w;
     imisc[1] = bad ? 1 : 0;

@@ -13,6 +13,8 @@
 // 16x16x32 bf16 MFMAs.  The MFMA is issued with the operands swapped so each lane ends up with 4
 // consecutive output columns (8-/16-byte stores).  Workgroup ids are remapped so that each XCD's L2 sees a
 // contiguous run of tiles sharing the same A row panel.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -535,6 +537,195 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) 
   gemm_epilogue<MI, NI>(p, acc, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
 }
 
+// =================================================================================================
+// 256x128 tile, 8 waves (4 x 2, 64x64 per wave), THREE LDS stages with two tiles of LDS-DMA in flight.
+// The two-stage kernel above spends ~half of its wave cycles parked at the per-K-step barrier (rocprofv3 PMC:
+// SQ_WAIT_ANY 48 % of SQ_WAVE_CYCLES, MFMA busy 29 %): one 32 KB tile in flight per workgroup cannot cover the
+// L2/HBM latency of ~1-2 us with 0.25-0.5 us of MFMA work.  Here a K step is 1024 MFMA cycles per SIMD and the
+// DMA of tiles kt+1 and kt+2 is in flight while tile kt is multiplied: counted `s_waitcnt vmcnt(N)` (N = this
+// wave's DMA instructions per tile) + a raw s_barrier per K step, never vmcnt(0) inside the loop.
+template <int R, bool KM, int NW>
+struct DmaStagerW {
+  static constexpr int NINST = R / (8 * NW);  // 1-KiB wave-instructions per wave per tile (tile = R*128 bytes)
+  static constexpr uint32_t OOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t off[NINST];
+  int kofs[NINST];
+  uint32_t kstep;
+  int wave;
+
+  __device__ __forceinline__ void init(const bf16* base, long ld, int row0, int rows_total, int kt0, uint32_t extent_bytes) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)extent_bytes, 0x00020000);
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    kstep = (uint32_t)((KM ? (long)BK * ld : (long)BK) * 2);
+#pragma unroll
+    for (int j = 0; j < NINST; ++j) {
+      const int S = (wave * NINST + j) * 64 + lane;
+      if (!KM) {
+        const int r = S >> 3, pc = S & 7;
+        const int c = pc ^ ((r >> 1) & 7);
+        const int gr = row0 + r;
+        kofs[j] = c * 8;
+        off[j] = gr < rows_total ? (uint32_t)(((long)gr * ld + c * 8) * 2) : OOB;
+      } else {
+        constexpr int CPR = R / 8;
+        const int kr = S / CPR, pc = S % CPR;
+        const int ch = pc ^ km_swz<(R >= 128 ? 128 : 64)>(kr);
+        const int gr = row0 + ch * 8;
+        kofs[j] = kr;
+        off[j] = gr < rows_total ? (uint32_t)(((long)kr * ld + gr) * 2) : OOB;
+      }
+      if (off[j] != OOB) off[j] += (uint32_t)kt0 * kstep;
+    }
+  }
+  __device__ __forceinline__ void issue(char* lds_tile, int kt, int K) {
+    const int k0 = kt * BK;
+    const bool full = k0 + BK <= K;
+#pragma unroll
+    for (int j = 0; j < NINST; ++j) {
+      uint32_t o = off[j];
+      if (!full) o = (k0 + kofs[j] < K) ? o : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * NINST + j) * 1024), 16, o, 0, 0, 0);
+      if (off[j] != OOB) off[j] += kstep;
+    }
+  }
+  // issue NINST out-of-range loads (zeros): keeps the per-tile vmcnt bookkeeping uniform past the last tile
+  __device__ __forceinline__ void issue_dummy(char* lds_tile) {
+#pragma unroll
+    for (int j = 0; j < NINST; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * NINST + j) * 1024), 16, OOB, 0, 0, 0);
+  }
+};
+
+template <int R, bool KM, int NF>
+struct DmaFragW {
+  int off[KM ? NF : 1];
+  __device__ __forceinline__ void init(int w0, int lane) {
+    if (!KM) {
+      const int r = w0 + (lane & 15);
+      off[0] = r * 128 + (((lane >> 4) ^ ((r >> 1) & 7)) << 4);
+    } else {
+      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+      const int kr = 8 * g + q;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int ch = (w0 >> 3) + 2 * i + (p >> 1);
+        off[i] = kr * (2 * R) + ((ch ^ km_swz<(R >= 128 ? 128 : 64)>(kr)) << 4) + (p & 1) * 8;
+      }
+    }
+  }
+  __device__ __forceinline__ bf16x8 read(const char* lds, int i, int kk) const {
+    if (!KM) {
+      return *reinterpret_cast<const bf16x8*>(lds + ((off[0] ^ (kk << 6)) + i * 2048));
+    } else {
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const char* a = lds + off[KM ? i : 0] + kk * 32 * (2 * R);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * (2 * R)));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      return __builtin_bit_cast(bf16x8, v);
+    }
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  // s_waitcnt vmcnt(N) only (lgkmcnt / expcnt untouched); gfx9 encoding: vm[3:0] | exp 7<<4 | lgkm 15<<8 | vm[5:4]<<14
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_dma3_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+  using SA = DmaStagerW<BM, A_KM, NW>;
+  using SB = DmaStagerW<BN, B_KM, NW>;
+  constexpr int NPT = SA::NINST + SB::NINST;  // this wave's DMA instructions per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
+  const int per_z = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int zs = id / per_z, rem = id % per_z;
+  const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
+  const int split = zs % p.split_k, z = zs / p.split_k;
+  const int z1 = z / p.nb2, z2 = z % p.nb2;
+  const bf16* Ab = p.A + z1 * p.sa1 + z2 * p.sa2;
+  const bf16* Bb = p.B + z1 * p.sb1 + z2 * p.sb2;
+  const int bm0 = tm * BM, bn0 = tn * BN;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = split * p.kt_per_split;
+  const int kt1 = min(nkt, kt0 + p.kt_per_split);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  SA sa;
+  SB sb;
+  sa.init(Ab, p.lda, bm0, p.M, kt0, p.ext_a);
+  sb.init(Bb, p.ldb, bn0, p.N, kt0, p.ext_b);
+  DmaFragW<BM, A_KM, MI> fra;
+  DmaFragW<BN, B_KM, NI> frb;
+  fra.init(wm0, lane);
+  frb.init(wn0, lane);
+
+  // prologue: two tiles in flight (past the end: zero-filling dummies keep the vmcnt arithmetic uniform)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (kt0 + s < kt1) {
+      sa.issue(smem + s * STAGE, kt0 + s, p.K);
+      sb.issue(smem + s * STAGE + ABYTES, kt0 + s, p.K);
+    } else {
+      sa.issue_dummy(smem + s * STAGE);
+      sb.issue_dummy(smem + s * STAGE + ABYTES);
+    }
+  }
+  int stage = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    // tile kt has landed once all but this wave's NPT youngest DMA instructions (tile kt+1) are done ...
+    wait_vmcnt<NPT>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // ... in every wave; and every wave is done reading the stage refilled below
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int s2 = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3: the stage read in the previous iteration
+      if (kt + 2 < kt1) {
+        sa.issue(smem + s2 * STAGE, kt + 2, p.K);
+        sb.issue(smem + s2 * STAGE + ABYTES, kt + 2, p.K);
+      } else {
+        sa.issue_dummy(smem + s2 * STAGE);
+        sb.issue_dummy(smem + s2 * STAGE + ABYTES);
+      }
+    }
+    const char* la = smem + stage * STAGE;
+    const char* lb = la + ABYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = fra.read(la, i, kk);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = frb.read(lb, j, kk);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  wait_vmcnt<0>();  // drain the trailing dummy DMA before LDS is released
+  gemm_epilogue<MI, NI>(p, acc, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
+}
+
 // deterministic split-K combine: C = alpha * sum_s slab[s] (+ bias) (+ C)
 __global__ void splitk_reduce_kernel(const GemmParams p) {
   const long per = (long)p.M * p.N;
@@ -563,6 +754,7 @@ struct ProfRec {
   double flops;
 };
 bool g_prof_on = false;
+bool g_no_big_tile = false;  // development switch (SSAK_GEMM_NO_BIG=1): keep the 128x128 kernels
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_event_pool;
 hipEvent_t prof_event() {
@@ -606,6 +798,40 @@ int launch(const GemmParams& p, bool dma, hipStream_t st) {
     g_prof.push_back(rec);
   }
   return SSAK_OK;
+}
+
+template <bool A_KM, bool B_KM>
+int launch_big(const GemmParams& p, hipStream_t st) {
+  constexpr size_t lds = 3 * (size_t)(256 + 128) * 128;  // 144 KiB
+  auto kern = gemm_dma3_kernel<256, 128, 4, 2, A_KM, B_KM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
+  ProfRec rec;
+  if (g_prof_on) {
+    rec.e0 = prof_event();
+    rec.e1 = prof_event();
+    rec.variant = 16 + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
+    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
+    (void)hipEventRecord(rec.e0, st);
+  }
+  kern<<<dim3((unsigned)nblk), 512, lds, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.e1, st);
+    g_prof.push_back(rec);
+  }
+  return SSAK_OK;
+}
+
+int dispatch_big(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
+  if (!a_km && !b_km) return launch_big<false, false>(p, st);
+  if (!a_km && b_km) return launch_big<false, true>(p, st);
+  if (a_km && b_km) return launch_big<true, true>(p, st);
+  return launch_big<true, false>(p, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -686,7 +912,16 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   const bool dma = d->pads_are_zero || !(partial_a || partial_b);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (d->N > 64) {
+  static const bool env_no_big = [] {
+    const char* nb = getenv("SSAK_GEMM_NO_BIG");
+    return nb && nb[0] == '1';
+  }();
+  const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
+  if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
+    p.tiles_m = ssak_cdiv(d->M, 256);
+    p.tiles_n = ssak_cdiv(d->N, 128);
+    rc = dispatch_big(p, d->a_kmajor, d->b_kmajor, st);
+  } else if (d->N > 64) {
     p.tiles_m = ssak_cdiv(d->M, 128);
     p.tiles_n = ssak_cdiv(d->N, 128);
     rc = dispatch_layout<128, 128, 2, 2>(p, d->a_kmajor, d->b_kmajor, dma, st);
@@ -707,13 +942,17 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
 
 extern "C" int ssak_prof_enable(int on) {
   g_prof_on = on != 0;
+
   return SSAK_OK;
 }
 
 extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
-  SSAK_REQUIRE(out && cap >= 16, "prof_collect: need room for 16 entries");
-  for (int i = 0; i < 16; ++i) {
-    snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
+  SSAK_REQUIRE(out && cap >= 20, "prof_collect: need room for 20 entries");
+  for (int i = 0; i < 20; ++i) {
+    if (i < 16)
+      snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
+    else
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
     out[i].launches = 0;
     out[i].total_ms = 0.0;
     out[i].total_flops = 0.0;
@@ -729,5 +968,5 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
     g_event_pool.push_back(r.e1);
   }
   g_prof.clear();
-  return 16;
+  return 20;
 }

@@ -129,9 +129,10 @@ def ctc_loss(logits: torch.Tensor, in_lens: torch.Tensor | None, labels: torch.T
     """logits [B,F,V] fp32, labels [B,L] (negative = pad) -> (loss[1], nll[B], dlogits[B,F,V] | None)."""
     assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 3 and logits.is_contiguous()
     B, F, V = logits.shape
-    labels = labels.to(device=logits.device, dtype=torch.int32).contiguous()
-    if labels.numel() and int(labels.max()) >= V:
+    if not labels.is_cuda and labels.numel() and int(labels.max()) >= V:
         raise ValueError(f"Label values must be <= vocab_size: {V}")  # modeling_wav2vec2.py:1686-1687
+    # device-resident labels are validated by the kernel instead (bad label -> NaN nll): no host sync per step
+    labels = labels.to(device=logits.device, dtype=torch.int32).contiguous()
     Lmax = labels.shape[1]
     if in_lens is not None:
         in_lens = in_lens.to(device=logits.device, dtype=torch.int32).contiguous()
@@ -175,8 +176,8 @@ def prof_enable(on: bool):
 
 def prof_collect():
     """[(kernel name, launches, total ms, total algorithmic flops)] since the last collect."""
-    arr = (ProfEntry * 16)()
-    n = lib.ssak_prof_collect(arr, 16)
+    arr = (ProfEntry * 20)()
+    n = lib.ssak_prof_collect(arr, 20)
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops) for i in range(n)]

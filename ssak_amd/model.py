@@ -117,6 +117,7 @@ class Wav2Vec2ForCTC:
         self._step_seed = np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0]
         self._host_rng = np.random.RandomState(seed)
         self._last = None
+        self._pinned_mask = {}
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -199,7 +200,10 @@ class Wav2Vec2ForCTC:
         training = self.training
         if labels is not None:
             labels = torch.as_tensor(labels)
-            if labels.numel() and int(labels.max()) >= cfg.vocab_size:
+            # the reference checks labels.max() on every call, which forces a device sync when the labels live on
+            # the GPU (modeling_wav2vec2.py:1686-1687); here host-resident labels are checked on the host and
+            # device-resident ones are validated inside the CTC kernel (bad label -> NaN loss), so the step never syncs
+            if not labels.is_cuda and labels.numel() and int(labels.max()) >= cfg.vocab_size:
                 raise ValueError(f"Label values must be <= vocab_size: {cfg.vocab_size}")
         ws = self._workspace(B, T, training)
         # stochastic regularisers drawn on the host ahead of the step, as the reference does
@@ -212,7 +216,23 @@ class Wav2Vec2ForCTC:
             if layer_keep is None and cfg.layerdrop > 0:
                 layer_keep = self._host_rng.rand(cfg.num_hidden_layers) >= cfg.layerdrop
         if mask_time_indices is not None:
-            mask_dev = torch.as_tensor(np.ascontiguousarray(mask_time_indices)).to(torch.uint8).to(self.device, non_blocking=True)
+            if torch.is_tensor(mask_time_indices) and mask_time_indices.is_cuda:
+                mask_dev = mask_time_indices.to(torch.uint8).contiguous()
+            else:
+                # pinned staging + async copy: a pageable H2D copy would block the host until the stream drains
+                mh = torch.as_tensor(np.ascontiguousarray(mask_time_indices)).to(torch.uint8)
+                pin = self._pinned_mask.get(tuple(mh.shape))
+                if pin is None:
+                    pin = (torch.empty(mh.shape, dtype=torch.uint8).pin_memory(),
+                           torch.empty(mh.shape, dtype=torch.uint8, device=self.device), torch.cuda.Event())
+                    self._pinned_mask[tuple(mh.shape)] = pin
+                else:
+                    pin[2].synchronize()  # the previous copy out of the pinned buffer has completed
+                pin[0].copy_(mh)
+                with torch.cuda.device(self.device):
+                    pin[1].copy_(pin[0], non_blocking=True)
+                    pin[2].record()
+                mask_dev = pin[1]
         if layer_keep is not None:
             keep_arr = (C.c_uint8 * cfg.num_hidden_layers)(*[int(bool(k)) for k in layer_keep])
         self._step_seed = (int(self._step_seed) * 6364136223846793005 + 1442695040888963407) % (1 << 64)

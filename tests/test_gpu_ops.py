@@ -49,8 +49,10 @@ def test_ctc_edge_cases(hip):
     labels = np.array([[1, 1, 1, 1], [2, -100, -100, -100]])
     loss, nll, grad = hip.ctc_loss(_dev(logits), None, _dev(labels), 0, "sum", False)
     assert torch.isinf(loss).item() and torch.isinf(nll[0]).item() and torch.isfinite(nll[1]).item()
-    with pytest.raises(ValueError):
-        hip.ctc_loss(_dev(logits), None, _dev(np.array([[5], [1]])), 0)
+    with pytest.raises(ValueError):  # host-resident labels: checked on the host like the reference
+        hip.ctc_loss(_dev(logits), None, torch.tensor([[5], [1]]), 0)
+    bad_loss, bad_nll, _ = hip.ctc_loss(_dev(logits), None, _dev(np.array([[5], [1]])), 0)  # device-resident: NaN, no sync
+    assert torch.isnan(bad_loss).item() and torch.isnan(bad_nll[0]).item() and torch.isfinite(bad_nll[1]).item()
     # large vocabulary (Whisper-sized head) and long label sequences (S > 256 states)
     B, F, V = 3, 300, 51
     logits = rng.standard_normal((B, F, V)).astype(np.float32)
