@@ -39,6 +39,20 @@ size_t ssak_wave_normalize_workspace_bytes(int B, int T);
 int ssak_wave_normalize(const float* in, const int32_t* lens, int B, int T, float* out, int32_t* mask,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- a13: Whisper log-mel features ---------------------------------------------------------
+ * Replaces WhisperFeatureExtractor (transformers feature_extraction_whisper.py:95-168), reached from
+ * ssak/utils/dataset.py:632-637 with a Whisper processor (ssak/train/transformers/whisper_train.py:356-367).
+ * wav [B, T] fp32 (lens [B] valid samples or NULL), padded / trimmed to n_samples (480000 = 30 s) -> mel
+ * [B, 80, n_samples/160] fp32 (or NULL).  mel_cl_bf16 (or NULL): the same values as bf16 channels-last
+ * [B, cl_rows, 80] written from row cl_lead (what the Whisper encoder's first conv reads; pad rows untouched).
+ * tables: ssak_logmel_table_floats() floats filled once by ssak_logmel_init_tables (Hann-weighted DFT matrix + Slaney
+ * mel filters, computed in double on the host). */
+size_t ssak_logmel_table_floats(void);
+int ssak_logmel_init_tables(float* tables /*device*/);
+size_t ssak_logmel_workspace_bytes(int B, int n_samples);
+int ssak_logmel_whisper(const float* wav, const int32_t* lens, int B, int T, int n_samples, const float* tables, float* mel,
+                        void* mel_cl_bf16, int cl_rows, int cl_lead, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a9: CTC loss + gradient ----------------------------------------------------------------
  * Replaces log_softmax(fp32) -> F.ctc_loss(blank=pad_token_id, reduction, zero_infinity) and its
  * autograd backward, reached from Wav2Vec2ForCTC.forward (transformers modeling_wav2vec2.py:1705-1728)

@@ -52,6 +52,10 @@ def _load():
         "ssak_last_error": (C.c_char_p, []),
         "ssak_wave_normalize_workspace_bytes": (sz, [i32, i32]),
         "ssak_wave_normalize": (i32, [vp, vp, i32, i32, vp, vp, vp, sz, vp]),
+        "ssak_logmel_table_floats": (sz, []),
+        "ssak_logmel_init_tables": (i32, [vp]),
+        "ssak_logmel_workspace_bytes": (sz, [i32, i32]),
+        "ssak_logmel_whisper": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, vp, sz, vp]),
         "ssak_ctc_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "ssak_ctc_loss_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]),
         "ssak_ctc_greedy_decode": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
@@ -122,6 +126,33 @@ def wave_normalize(x: torch.Tensor, lens: torch.Tensor | None = None, return_mas
     ws = _ws(lib.ssak_wave_normalize_workspace_bytes(B, T), x.device)
     check(lib.ssak_wave_normalize(ptr(x), ptr(lens), B, T, ptr(out), ptr(mask), ptr(ws), ws.numel(), stream()))
     return (out, mask) if return_mask else out
+
+
+_LOGMEL_TABLES = {}
+
+
+def logmel_tables(device):
+    key = str(device)
+    if key not in _LOGMEL_TABLES:
+        t = torch.empty(lib.ssak_logmel_table_floats(), dtype=torch.float32, device=device)
+        check(lib.ssak_logmel_init_tables(ptr(t)))
+        _LOGMEL_TABLES[key] = t
+    return _LOGMEL_TABLES[key]
+
+
+def logmel_whisper(wav: torch.Tensor, lens: torch.Tensor | None = None, n_samples: int = 480000,
+                   channels_last: torch.Tensor | None = None, cl_lead: int = 0, want_mel: bool = True):
+    """[B,T] fp32 waveforms -> Whisper input features [B, 80, n_samples/160] fp32 (30 s windows by default)."""
+    assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
+    B, T = wav.shape
+    if lens is not None:
+        lens = lens.to(device=wav.device, dtype=torch.int32).contiguous()
+    mel = torch.empty((B, 80, n_samples // 160), dtype=torch.float32, device=wav.device) if want_mel else None
+    ws = _ws(lib.ssak_logmel_workspace_bytes(B, n_samples), wav.device)
+    cl_rows = 0 if channels_last is None else channels_last.shape[1]
+    check(lib.ssak_logmel_whisper(ptr(wav), ptr(lens), B, T, n_samples, ptr(logmel_tables(wav.device)), ptr(mel),
+                                  ptr(channels_last), cl_rows, cl_lead, ptr(ws), ws.numel(), stream()))
+    return mel
 
 
 def ctc_loss(logits: torch.Tensor, in_lens: torch.Tensor | None, labels: torch.Tensor, blank: int = 0,

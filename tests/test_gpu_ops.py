@@ -227,3 +227,41 @@ def test_gemm_rejects_bad_args(hip):
         hip.gemm(A, A, Cc, 8, 8, 8, lda=7, ldb=8, ldc=8)
     with pytest.raises(ValueError):
         hip.gemm(A, A, Cc, 0, 8, 8, lda=8, ldb=8, ldc=8)
+
+
+# ------------------------------------------------------------------ Whisper log-mel (a13)
+def test_logmel_golden_and_oracle(hip, gold):
+    """Against WhisperFeatureExtractor goldens (seeded signal + the reference's bonjour.wav fixture) and the float64
+    oracle.  Tolerance 2e-4 absolute on the (log10 + 4) / 4 scale: the kernel is fp32, the reference fp64->fp32."""
+    import os
+    import wave
+    from oracle import logmel_ref
+    z = gold("logmel.npz")
+    w = z["wave"]
+    mel = hip.logmel_whisper(_dev(w[None, :])).cpu().numpy()[0]
+    assert mel.shape == (80, 3000)
+    assert np.abs(mel[:, ::7] - z["mel_stride7"]).max() < 2e-4
+    assert np.abs(mel[:, :40] - z["mel_head"]).max() < 2e-4
+    assert np.abs(mel - logmel_ref.log_mel(w)).max() < 2e-4
+    with wave.open(os.path.join(os.path.dirname(__file__), "golden", "bonjour.wav")) as f:
+        pcm = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+    mb = hip.logmel_whisper(_dev(pcm[None, :])).cpu().numpy()[0]
+    assert np.abs(mb[:, :130] - z["bonjour_mel_head"]).max() < 2e-4
+
+
+def test_logmel_batch_ragged_and_properties(hip):
+    from oracle import logmel_ref
+    rng = np.random.default_rng(4)
+    B, T = 3, 500000  # longer than 30 s: trimmed; ragged lengths: zero padded
+    x = (rng.standard_normal((B, T)) * 0.05).astype(np.float32)
+    lens = np.array([500000, 160000, 777], np.int32)
+    cl = torch.full((B, 3008, 80), 9.0, dtype=torch.bfloat16).cuda()
+    mel = hip.logmel_whisper(_dev(x), _dev(lens), channels_last=cl, cl_lead=1).cpu().numpy()
+    for b in range(B):
+        ref = logmel_ref.log_mel(x[b, :lens[b]])
+        assert np.abs(mel[b] - ref).max() < 2e-4, b
+        # property: range is exactly 2 wide at most (max(x, max - 8) then / 4) and the max is attained
+        assert mel[b].max() - mel[b].min() <= 2.0 + 1e-5
+    c = cl.float().cpu().numpy()
+    assert np.abs(c[:, 1:3001, :] - mel.transpose(0, 2, 1)).max() < 1e-2  # bf16 copy, channels-last, shifted by cl_lead
+    assert (c[:, 0, :] == 9.0).all() and (c[:, 3001:, :] == 9.0).all()       # pad rows untouched
