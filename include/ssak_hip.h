@@ -153,6 +153,11 @@ typedef struct {
   float layer_norm_eps;
   float attention_dropout, hidden_dropout, activation_dropout, feat_proj_dropout, final_dropout;
   int freeze_feature_encoder; /* wav2vec_train.py:326-327 */
+  /* arch 1 = Whisper encoder + CTC head (BASELINE config 4; a composition of the build): conv1/conv2
+   * front end on log-mel features, fixed sinusoidal positions, pre-LN layers (k_proj without bias), final LayerNorm,
+   * Linear(d_model, vocab).  input_values is then the feature tensor [B, num_mel_bins, T] (T = 2 * frames, even). */
+  int arch;
+  int num_mel_bins, max_source_positions;
 } ssak_w2v2_config;
 typedef struct ssak_w2v2 ssak_w2v2;
 

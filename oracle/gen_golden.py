@@ -293,6 +293,51 @@ def gen_w2v2():
     print("w2v2 ok")
 
 
+def gen_whisper():
+    """Whisper encoder + CTC head composition (BASELINE config 4; no reference call site): tiny dims, 100 mel frames."""
+    import transformers
+    from . import whisper_ref as WR
+    cfg = WR.WhisperCTCConfig.tiny()
+    p = WR.init_params(cfg, 69)
+    hc = transformers.WhisperConfig(num_mel_bins=cfg.num_mel_bins, d_model=cfg.d_model, encoder_layers=cfg.encoder_layers,
+                                    encoder_attention_heads=cfg.encoder_attention_heads, encoder_ffn_dim=cfg.encoder_ffn_dim,
+                                    max_source_positions=cfg.max_source_positions, dropout=0.0, attention_dropout=0.0,
+                                    activation_dropout=0.0, encoder_layerdrop=0.0, decoder_layers=1, decoder_attention_heads=4,
+                                    decoder_ffn_dim=128)
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    enc = WhisperEncoder(hc)
+    sd = {k[len("encoder."):]: v for k, v in p.items() if k.startswith("encoder.")}
+    enc.load_state_dict(sd, strict=True)
+    head = torch.nn.Linear(cfg.d_model, cfg.vocab_size)
+    head.weight.data.copy_(p["ctc_head.weight"])
+    head.bias.data.copy_(p["ctc_head.bias"])
+    rng = np.random.default_rng(21)
+    wav = np.stack([synth_wave(rng, 16000) for _ in range(2)])
+    mel = np.stack([logmel_ref.log_mel(w, n_samples=16000) for w in wav])  # [2, 80, 100]
+    labels = R.pad_labels([list(rng.integers(1, 32, n)) for n in (9, 5)])
+    enc.train(False)
+    hs = enc(torch.tensor(mel)).last_hidden_state
+    logits = head(hs)
+    lm = torch.tensor(labels) >= 0
+    lp = torch.nn.functional.log_softmax(logits, dim=-1, dtype=torch.float32).transpose(0, 1)
+    loss = torch.nn.functional.ctc_loss(lp, torch.tensor(labels).masked_select(lm), torch.full((2,), hs.shape[1]), lm.sum(-1),
+                                        blank=0, reduction="mean", zero_infinity=True)
+    loss.backward()
+    o_loss, o_logits, o_grads = WR.loss_and_grads(p, cfg, torch.tensor(mel), torch.tensor(labels))
+    assert abs(o_loss.item() - loss.item()) < 1e-4 * abs(loss.item())
+    assert np.abs(o_logits.numpy() - logits.detach().numpy()).max() < 2e-4
+    d = dict(wav=wav, mel=mel.astype(np.float32), labels=labels, loss=np.float32(loss.item()), logits=logits.detach().numpy())
+    hg = {"encoder." + n: q.grad for n, q in enc.named_parameters() if q.grad is not None}
+    hg["ctc_head.weight"], hg["ctc_head.bias"] = head.weight.grad, head.bias.grad
+    floor = 1e-3 * max(float(g.abs().max()) for g in hg.values())
+    for n, g in hg.items():
+        e = float((o_grads[n] - g).abs().max()) / max(float(g.abs().max()), floor)
+        assert e < 5e-3, (n, e)
+        d["grad/" + n] = g.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "whisper_tiny.npz"), **d)
+    print("whisper ok; loss", loss.item())
+
+
 def base_inputs():
     """Re-create gen_w2v2()'s base-config inputs (used by tests on the GPU box).  Must replay the
     same RNG stream as gen_w2v2 up to the base section."""
@@ -314,7 +359,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["ctc", "features", "logmel", "adamw", "w2v2"]
+    which = sys.argv[1:] or ["ctc", "features", "logmel", "adamw", "w2v2", "whisper"]
     for w in which:
         globals()["gen_" + w]()
 

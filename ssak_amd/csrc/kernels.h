@@ -44,6 +44,13 @@ int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const 
                          int H, int G, int K, hipStream_t st);
 int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, hipStream_t st);
 
+// whisper_frontend.hip
+int k_mel_to_cl(const float* mel, bf16* cl, int B, int C, int T, int RS, int lead, hipStream_t st);
+int k_add_rowvec(const bf16* x, const bf16* pos, bf16* out, int B, int F, int H, hipStream_t st);
+int k_copy_rows_padded(const bf16* src, bf16* dst, int B, int F, int RS, int H, hipStream_t st);
+int k_col2im_k3s2(const bf16* dxcol, const bf16* pre, bf16* out, int B, int F, int Tin, int RS1, int H, hipStream_t st);
+int k_conv_wgrad_unrearrange(const float* dwr, float* g, int Co, int Ci, int k, hipStream_t st);
+
 // optim.hip
 int k_sumsq(const float* g, long n, float* out /*[1], zeroed by caller*/, hipStream_t st);
 int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, const float* gnorm_sq, float max_norm,

@@ -59,6 +59,9 @@ struct Plan {
   std::vector<LayerBuf> lb;
   // backward temporaries
   size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH, lnpart;
+  // Whisper front end: RS2 rows per utterance after conv2, RS1 = 2*RS2 before it
+  int Tin = 0, RS1 = 0, RS2 = 0;
+  size_t melcl, h1pad, pre1, wpre2, we, dpre2pad, dxcol, dpre1pad, dwr;
   size_t slab_bytes = 0;
   size_t total = 0;
 };
@@ -71,7 +74,8 @@ struct ssak_w2v2 {
   long n_total = 0, n_train = 0;
   // parameter offsets (elements into the flat buffers)
   long p_mse, p_fpln_w, p_fpln_b, p_fp_w, p_fp_b, p_pc_b, p_pc_g, p_pc_v, p_eln_w, p_eln_b, p_lm_w, p_lm_b;
-  long p_conv_w[8], p_conv_b[8], p_cln_w[8], p_cln_b[8];  // conv weight / bias / per-layer norm (group: layer 0 only)
+  long p_conv_w[8], p_conv_b[8], p_cln_w[8], p_cln_b[8];
+  long p_c1w = 0, p_c1b = 0, p_c2w = 0, p_c2b = 0, p_pos = 0;  // Whisper front end  // conv weight / bias / per-layer norm (group: layer 0 only)
   std::vector<size_t> hres;  // stable-LN: residual-stream buffer that feeds the LayerNorm producing x[l]
   std::vector<LayerP> lp;
   // bound buffers (caller-owned)
@@ -117,7 +121,52 @@ void add_param(ssak_w2v2* e, long& cursor, const std::string& name, std::vector<
   e->params.push_back(pi);
 }
 
+void build_param_table_whisper(ssak_w2v2* e) {
+  const ssak_w2v2_config& c = e->cfg;
+  const long H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, NM = c.num_mel_bins;
+  long cur = 0, dummy;
+  e->lp.resize(c.num_layers);
+  add_param(e, cur, "encoder.conv1.weight", {H, NM, 3}, 0, &e->p_c1w);
+  add_param(e, cur, "encoder.conv2.weight", {H, H, 3}, 0, &e->p_c2w);
+  for (int l = 0; l < c.num_layers; ++l) {
+    const std::string p = "encoder.layers." + std::to_string(l) + ".";
+    LayerP& L = e->lp[l];
+    add_param(e, cur, p + "self_attn.q_proj.weight", {H, H}, 0, &L.wqkv);
+    add_param(e, cur, p + "self_attn.k_proj.weight", {H, H}, 0, &dummy);
+    add_param(e, cur, p + "self_attn.v_proj.weight", {H, H}, 0, &dummy);
+    add_param(e, cur, p + "self_attn.out_proj.weight", {H, H}, 0, &L.wo);
+    add_param(e, cur, p + "fc1.weight", {I, H}, 0, &L.w1);
+    add_param(e, cur, p + "fc2.weight", {H, I}, 0, &L.w2);
+  }
+  add_param(e, cur, "ctc_head.weight", {V, H}, 0, &e->p_lm_w);
+  add_param(e, cur, "encoder.conv1.bias", {H}, 0, &e->p_c1b);
+  add_param(e, cur, "encoder.conv2.bias", {H}, 0, &e->p_c2b);
+  for (int l = 0; l < c.num_layers; ++l) {
+    const std::string p = "encoder.layers." + std::to_string(l) + ".";
+    LayerP& L = e->lp[l];
+    add_param(e, cur, p + "self_attn.q_proj.bias", {H}, 0, &L.bqkv);
+    // Whisper's k_proj has no bias: the slot exists only so that q|k|v biases form one [3H] vector; it stays zero
+    // (its gradient is cleared after every backward) and is not part of the HF state dict.
+    add_param(e, cur, p + "self_attn.k_proj.bias", {H}, 0, &dummy);
+    add_param(e, cur, p + "self_attn.v_proj.bias", {H}, 0, &dummy);
+    add_param(e, cur, p + "self_attn.out_proj.bias", {H}, 0, &L.bo);
+    add_param(e, cur, p + "self_attn_layer_norm.weight", {H}, 0, &L.ln1w);
+    add_param(e, cur, p + "self_attn_layer_norm.bias", {H}, 0, &L.ln1b);
+    add_param(e, cur, p + "fc1.bias", {I}, 0, &L.b1);
+    add_param(e, cur, p + "fc2.bias", {H}, 0, &L.b2);
+    add_param(e, cur, p + "final_layer_norm.weight", {H}, 0, &L.ln2w);
+    add_param(e, cur, p + "final_layer_norm.bias", {H}, 0, &L.ln2b);
+  }
+  add_param(e, cur, "encoder.layer_norm.weight", {H}, 0, &e->p_eln_w);
+  add_param(e, cur, "encoder.layer_norm.bias", {H}, 0, &e->p_eln_b);
+  add_param(e, cur, "ctc_head.bias", {V}, 0, &e->p_lm_b);
+  e->n_train = cur;
+  add_param(e, cur, "encoder.embed_positions.weight", {c.max_source_positions, H}, 1, &e->p_pos);  // fixed sinusoids
+  e->n_total = cur;
+}
+
 void build_param_table(ssak_w2v2* e) {
+  if (e->cfg.arch == 1) return build_param_table_whisper(e);
   const ssak_w2v2_config& c = e->cfg;
   const long H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, C = c.conv_dim[c.num_conv_layers - 1];
   const long K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
@@ -180,6 +229,14 @@ void build_param_table(ssak_w2v2* e) {
 }
 
 int check_config(const ssak_w2v2_config& c) {
+  if (c.arch == 1) {
+    SSAK_REQUIRE(c.num_mel_bins > 0 && c.num_mel_bins % 8 == 0 && c.max_source_positions > 0, "whisper: num_mel_bins must be a multiple of 8");
+    SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "whisper: head_dim must be a multiple of 8");
+    SSAK_REQUIRE(c.hidden_size % 8 == 0 && c.intermediate_size % 8 == 0 && c.vocab_size % 8 == 0, "whisper: d_model / ffn / vocab must be multiples of 8");
+    SSAK_REQUIRE(c.num_layers >= 1 && c.num_layers <= 64, "whisper: num_layers out of range");
+    return SSAK_OK;
+  }
+  SSAK_REQUIRE(c.arch == 0, "w2v2: arch must be 0 (wav2vec2) or 1 (whisper encoder)");
   SSAK_REQUIRE(c.num_conv_layers >= 2 && c.num_conv_layers <= 8, "w2v2: num_conv_layers %d unsupported", c.num_conv_layers);
   SSAK_REQUIRE(c.feat_extract_norm == 0 || c.feat_extract_norm == 1, "w2v2: feat_extract_norm must be 0 (group) or 1 (layer)");
   SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "w2v2: head_dim must be a multiple of 8");
@@ -200,25 +257,49 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
   p.B = B;
   p.T = T;
   p.training = training;
+  const bool whisper = c.arch == 1;
   int L = T;
-  for (int i = 0; i < c.num_conv_layers; ++i) {
-    L = conv_len(L, c.conv_kernel[i], c.conv_stride[i]);
-    SSAK_REQUIRE(L > 0, "w2v2: input of %d samples is too short for the feature encoder", T);
-    p.Tl[i] = L;
+  if (!whisper) {
+    for (int i = 0; i < c.num_conv_layers; ++i) {
+      L = conv_len(L, c.conv_kernel[i], c.conv_stride[i]);
+      SSAK_REQUIRE(L > 0, "w2v2: input of %d samples is too short for the feature encoder", T);
+      p.Tl[i] = L;
+    }
+  } else {
+    SSAK_REQUIRE(T >= 2 && (T & 1) == 0 && T / 2 <= c.max_source_positions, "whisper: %d feature frames (need even, <= %d)", T, 2 * c.max_source_positions);
+    L = T / 2;
+    p.Tin = T;
+    p.RS2 = (int)align_up(L + 1, 4);
+    p.RS1 = 2 * p.RS2;
   }
   p.F = L;
   p.M = B * L;
   p.Fp = (int)align_up(L, 8);
   const long H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads;
-  const long C = c.conv_dim[c.num_conv_layers - 1], K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups;
+  const long C = whisper ? 8 : c.conv_dim[c.num_conv_layers - 1], K = whisper ? 8 : c.num_conv_pos_embeddings;
+  const long G = whisper ? 1 : c.num_conv_pos_embedding_groups;
   const long M = p.M;
   p.pg_rows = K / 2 + (long)B * (p.F + K) + K;
   Carver cv;
   const size_t b2 = sizeof(bf16);
-  p.bufA = cv.take((size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
-  p.bufB = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
+  if (whisper) {
+    const long NM = c.num_mel_bins;
+    p.melcl = cv.take(((size_t)B * p.RS1 + 8) * NM * b2);
+    p.h1pad = cv.take((size_t)B * p.RS1 * H * b2);
+    p.pre1 = cv.take((size_t)B * p.RS1 * H * b2);
+    p.we = cv.take((size_t)M * H * b2);
+    p.wpre2 = cv.take((size_t)M * H * b2);
+    if (training) {
+      p.dpre2pad = cv.take((size_t)B * p.RS2 * H * b2);
+      p.dxcol = cv.take((size_t)M * 3 * H * b2);
+      p.dpre1pad = cv.take((size_t)B * p.RS1 * H * b2);
+      p.dwr = cv.take((size_t)H * 3 * std::max(H, NM) * sizeof(float));
+    }
+  }
+  p.bufA = cv.take(whisper ? 256 : (size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
+  p.bufB = cv.take(whisper ? 256 : (size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
   p.feat = cv.take((size_t)M * C * b2);
-  p.stats0 = cv.take(k_conv0_stats_doubles(B, p.Tl[0], c.conv_dim[0]) * sizeof(double));
+  p.stats0 = cv.take(whisper ? 256 : k_conv0_stats_doubles(B, p.Tl[0], c.conv_dim[0]) * sizeof(double));
   p.flens = cv.take((size_t)B * sizeof(int32_t));
   p.ln0 = cv.take((size_t)M * C * b2);
   p.st0 = cv.take((size_t)2 * M * sizeof(float));
@@ -388,7 +469,14 @@ extern "C" int ssak_w2v2_create(const ssak_w2v2_config* cfg, ssak_w2v2** out) {
   e->cfg = *cfg;
   build_param_table(e);
   const ssak_w2v2_config& c = e->cfg;
-  const long H = c.hidden_size, K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
+  const long H = c.hidden_size, K = c.num_conv_pos_embeddings;
+  const long cg = c.arch == 1 ? 8 : H / c.num_conv_pos_embedding_groups;
+  if (c.arch == 1) {
+    SSAK_HIP(hipMalloc((void**)&e->conv_w[1], (size_t)H * 3 * c.num_mel_bins * sizeof(bf16)));
+    SSAK_HIP(hipMalloc((void**)&e->conv_w[2], (size_t)H * 3 * H * sizeof(bf16)));
+    *out = e;
+    return SSAK_OK;
+  }
   long cin = 1;
   for (int i = 0; i < c.num_conv_layers; ++i) {
     if (i > 0) SSAK_HIP(hipMalloc((void**)&e->conv_w[i], (size_t)c.conv_dim[i] * cin * c.conv_kernel[i] * sizeof(bf16)));
@@ -414,6 +502,7 @@ extern "C" void ssak_w2v2_destroy(ssak_w2v2* e) {
 extern "C" long ssak_w2v2_num_params(const ssak_w2v2* e) { return e ? e->n_total : 0; }
 extern "C" long ssak_w2v2_num_trainable(const ssak_w2v2* e) {
   if (!e) return 0;
+  if (e->cfg.arch == 1) return e->n_train;  // everything but the fixed position table
   return e->cfg.freeze_feature_encoder ? e->n_train : e->n_total;
 }
 extern "C" int ssak_w2v2_param_count(const ssak_w2v2* e) { return e ? (int)e->params.size() : 0; }
@@ -450,6 +539,13 @@ extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
   SSAK_REQUIRE(e && e->P && e->W, "w2v2_sync_weights: bind the parameter buffers first");
   hipStream_t st = (hipStream_t)stream;
   const ssak_w2v2_config& c = e->cfg;
+  if (c.arch == 1) {
+    if (full) TRY(k_cast_f32_bf16(e->P, e->W, e->n_total, st));
+    // the conv weights are trainable here: their [Co][k][Ci] GEMM layouts follow every optimizer step
+    TRY(k_conv_weight_rearrange(e->P + e->p_c1w, e->conv_w[1], c.hidden_size, c.num_mel_bins, 3, st));
+    TRY(k_conv_weight_rearrange(e->P + e->p_c2w, e->conv_w[2], c.hidden_size, c.hidden_size, 3, st));
+    return SSAK_OK;
+  }
   if (full) {
     TRY(k_cast_f32_bf16(e->P, e->W, e->n_total, st));
     long cin = c.conv_dim[0];
@@ -472,6 +568,7 @@ extern "C" size_t ssak_w2v2_workspace_bytes(const ssak_w2v2* e, int B, int T, in
 
 extern "C" int ssak_w2v2_num_frames(const ssak_w2v2* e, int T) {
   if (!e) return 0;
+  if (e->cfg.arch == 1) return (T >= 2 && (T & 1) == 0) ? T / 2 : 0;
   int L = T;
   for (int i = 0; i < e->cfg.num_conv_layers; ++i) {
     if (L < e->cfg.conv_kernel[i]) return 0;
@@ -498,8 +595,9 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   auto BF = [&](size_t off) { return (bf16*)(ws + off); };
   auto FP = [&](size_t off) { return (float*)(ws + off); };
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads, hd = H / nh;
-  const int nc = c.num_conv_layers, C = c.conv_dim[nc - 1], K = c.num_conv_pos_embeddings;
-  const int G = c.num_conv_pos_embedding_groups, cg = H / G;
+  const bool whisper = c.arch == 1;
+  const int nc = whisper ? 1 : c.num_conv_layers, C = whisper ? 8 : c.conv_dim[nc - 1], K = whisper ? 8 : c.num_conv_pos_embeddings;
+  const int G = whisper ? 1 : c.num_conv_pos_embedding_groups, cg = H / G;
   const int F = p.F, M = p.M, Fp = p.Fp;
   const float* P = e->P;
   const bf16* W = e->W;
@@ -516,8 +614,27 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   };
   const DropSpec none;
 
-  // frame lengths (attention / CTC masks) from sample lengths: integer floor-div chain (modeling_wav2vec2.py:997-1016)
   int32_t* flens = nullptr;
+  const bool stable = whisper || c.do_stable_layer_norm != 0;
+  if (whisper) {
+    // ---- a14 front end: mel [B, NM, Tin] -> channels-last padded -> conv1+GELU -> conv2(s2)+GELU -> + positions
+    const int NM = c.num_mel_bins, Tin = p.Tin, RS1 = p.RS1;
+    SSAK_REQUIRE(!lens, "whisper: fixed-length windows, no attention mask (modeling_whisper.py:605-607)");
+    SSAK_HIP(hipMemsetAsync(ws + p.melcl, 0, ((size_t)B * RS1 + 8) * NM * sizeof(bf16), st));
+    SSAK_HIP(hipMemsetAsync(ws + p.h1pad, 0, (size_t)B * RS1 * H * sizeof(bf16), st));
+    TRY(k_mel_to_cl(input_values, BF(p.melcl), B, NM, Tin, RS1, 1, st));
+    TRY(Gemm(Tin, H, 3 * NM).a(BF(p.melcl), NM).b(e->conv_w[1], 3 * NM).c(BF(p.h1pad) + H, H)
+            .batch(B, 1, (long)RS1 * NM, 0, 0, 0, (long)RS1 * H, 0).with_bias(P + e->p_c1b)
+            .epi(SSAK_EPI_GELU, nullptr, BF(p.pre1) + H).run(st));
+    TRY(Gemm(F, H, 3 * H).a(BF(p.h1pad), 2 * H).b(e->conv_w[2], 3 * H).c(BF(p.we), H)
+            .batch(B, 1, (long)RS1 * H, 0, 0, 0, (long)F * H, 0).with_bias(P + e->p_c2b)
+            .epi(SSAK_EPI_GELU, nullptr, BF(p.wpre2)).run(st));
+    TRY(k_add_rowvec(BF(p.we), W + e->p_pos, BF(p.h1), B, F, H, st));
+    // residual stream r = dropout(conv + pos); x0 = self_attn_layer_norm of layer 0
+    TRY(k_layernorm_fwd(BF(p.h1), nullptr, P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
+                        FP(p.stE) + M, M, H, c.layer_norm_eps, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
+  } else {
+  // frame lengths (attention / CTC masks) from sample lengths: integer floor-div chain (modeling_wav2vec2.py:997-1016)
   if (lens) {
     flens = (int32_t*)(ws + p.flens);
     ConvChain cc;
@@ -577,7 +694,6 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
           .with_bias(P + e->p_pc_b, cg)
           .epi(SSAK_EPI_GELU, nullptr, BF(p.pc_pre))
           .run(st));
-  const bool stable = c.do_stable_layer_norm != 0;
   if (!stable) {
     // post-LN (base): x0 = dropout(LN(h0 + pos))                                       (modeling_wav2vec2.py:694-697)
     TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->p_eln_w, P + e->p_eln_b, BF(p.h1), BF(p.x[0]), FP(p.stE), FP(p.stE) + M,
@@ -586,6 +702,7 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
     // stable-LN (XLSR): residual stream r = dropout(h0 + pos); x0 = LN1 of layer 0 applied to r   (:763-771, :631-640)
     TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
                         FP(p.stE) + M, M, H, c.layer_norm_eps, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
+  }
   }
   // ---- a7: encoder layers with LayerDrop: post-LN (base, :591-608) or pre-LN "stable layer norm" (XLSR, :631-654)
   e->keep.assign(c.num_layers, 1);
@@ -662,7 +779,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     return SSAK_ERR_STATE;
   }
   SSAK_REQUIRE(e->G, "w2v2_backward: no gradient buffer bound");
-  SSAK_REQUIRE(e->cfg.freeze_feature_encoder, "w2v2_backward: feature-encoder gradients (--no_freeze) are not built in this round");
+  SSAK_REQUIRE(e->cfg.arch == 1 || e->cfg.freeze_feature_encoder, "w2v2_backward: feature-encoder gradients (--no_freeze) are not built in this round");
   Plan& p = e->plan;
   SSAK_REQUIRE(workspace_bytes >= p.total, "w2v2_backward: workspace too small");
   const ssak_w2v2_config& c = e->cfg;
@@ -671,8 +788,9 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   auto BF = [&](size_t off) { return (bf16*)(ws + off); };
   auto FP = [&](size_t off) { return (float*)(ws + off); };
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads, hd = H / nh;
-  const int nc = c.num_conv_layers, C = c.conv_dim[nc - 1], K = c.num_conv_pos_embeddings;
-  const int G = c.num_conv_pos_embedding_groups, cg = H / G;
+  const bool whisper = c.arch == 1;
+  const int nc = whisper ? 1 : c.num_conv_layers, C = whisper ? 8 : c.conv_dim[nc - 1], K = whisper ? 8 : c.num_conv_pos_embeddings;
+  const int G = whisper ? 1 : c.num_conv_pos_embedding_groups, cg = H / G;
   const int B = p.B, F = p.F, M = p.M, Fp = p.Fp;
   const float* P = e->P;
   float* Gd = e->G;
@@ -707,7 +825,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).drop(c.final_dropout, DS_FINAL, seed).run(st));
   // ---- encoder layers, last to first.  gA (+gB) = gradient w.r.t. x[l+1], the layer output (post-LN) or the
   // normalised input of the next layer (stable-LN); Gres = gradient of the residual stream (stable-LN only).
-  const bool stable = c.do_stable_layer_norm != 0;
+  const bool stable = whisper || c.do_stable_layer_norm != 0;
   const bool hdrop = c.hidden_dropout > 0.f;
   const bf16* Gres = nullptr;
   auto free_buf = [&](const bf16* u1, const bf16* u2, const bf16* u3) {
@@ -810,6 +928,27 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->lp[0].ln1w, Gres, dh1, nullptr, Gd + e->lp[0].ln1w,
                         Gd + e->lp[0].ln1b, FP(p.lnpart), M, H, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
   }
+  if (whisper) {
+    // ---- a14 front end backward: r = dropout(gelu(conv2(gelu(conv1(mel)))) + pos); positions are fixed
+    const int NM = c.num_mel_bins, Tin = p.Tin, RS1 = p.RS1, RS2 = p.RS2;
+    bf16* dpre2 = BF(p.dY);
+    TRY(k_gelu_grad_mul(dh1, BF(p.wpre2), dpre2, (long)M * H, st));
+    TRY(k_colsum(dpre2, H, M, H, Gd + e->p_c2b, st));
+    TRY(k_copy_rows_padded(dpre2, BF(p.dpre2pad), B, F, RS2, H, st));
+    // dW2[n][tap*H + c] = sum over rows kk = b*RS2 + t of dy[kk][n] * h1pad[2*kk + tap][c]   (one long-K GEMM)
+    TRY(Gemm(H, 3 * H, B * RS2).a(BF(p.dpre2pad), H, true).b(BF(p.h1pad), 2 * H, true).c(FP(p.dwr), 3 * H, true)
+            .run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_conv_wgrad_unrearrange(FP(p.dwr), Gd + e->p_c2w, H, H, 3, st));
+    // input gradient in column form, then col2im (+ GELU' of conv1's pre-activation)
+    TRY(Gemm(M, 3 * H, H).a(dpre2, H).b(e->conv_w[2], 3 * H, true).c(BF(p.dxcol), 3 * H).run(st));
+    TRY(k_col2im_k3s2(BF(p.dxcol), BF(p.pre1), BF(p.dpre1pad), B, F, Tin, RS1, H, st));
+    TRY(k_colsum(BF(p.dpre1pad), H, B * RS1, H, Gd + e->p_c1b, st));
+    TRY(Gemm(H, 3 * NM, B * RS1).a(BF(p.dpre1pad), H, true).b(BF(p.melcl), NM, true).c(FP(p.dwr), 3 * NM, true)
+            .run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_conv_wgrad_unrearrange(FP(p.dwr), Gd + e->p_c1w, H, NM, 3, st));
+    for (int l = 0; l < c.num_layers; ++l)  // k_proj has no bias in Whisper: keep its slot out of the optimizer
+      SSAK_HIP(hipMemsetAsync(Gd + e->lp[l].bqkv + H, 0, (size_t)H * sizeof(float), st));
+  } else {
   bf16* dpre = BF(p.dY);
   TRY(k_gelu_grad_mul(dh1, BF(p.pc_pre), dpre, (long)M * H, st));
   TRY(k_colsum(dpre, H, M, H, Gd + e->p_pc_b, st));
@@ -849,6 +988,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(Gemm(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
   TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, BF(p.ln0), nullptr,
                       Gd + e->p_fpln_w, Gd + e->p_fpln_b, FP(p.lnpart), M, C, none, none, st));
+  }
   // everything else: the leading small matrices and the whole vector region (biases, LayerNorm affine)
   announce(0, e->lp[0].wqkv);
   announce(e->p_lm_w + (long)V * H, e->n_train - (e->p_lm_w + (long)V * H));

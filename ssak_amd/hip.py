@@ -31,7 +31,8 @@ class W2V2Config(C.Structure):
                 ("num_conv_pos_embeddings", C.c_int), ("num_conv_pos_embedding_groups", C.c_int),
                 ("layer_norm_eps", C.c_float), ("attention_dropout", C.c_float), ("hidden_dropout", C.c_float),
                 ("activation_dropout", C.c_float), ("feat_proj_dropout", C.c_float), ("final_dropout", C.c_float),
-                ("freeze_feature_encoder", C.c_int)]
+                ("freeze_feature_encoder", C.c_int), ("arch", C.c_int), ("num_mel_bins", C.c_int),
+                ("max_source_positions", C.c_int)]
 
 
 class ProfEntry(C.Structure):

@@ -78,6 +78,11 @@ class Wav2Vec2ForCTC:
         self.device = torch.device(device)
         self.training = False
         self.freeze = freeze_feature_encoder
+        c = self._c_config(config, freeze_feature_encoder)
+        self._finish_init(c, seed)
+
+    @staticmethod
+    def _c_config(config, freeze_feature_encoder):
         c = hip.W2V2Config()
         c.vocab_size, c.hidden_size, c.num_layers = config.vocab_size, config.hidden_size, config.num_hidden_layers
         c.num_heads, c.intermediate_size = config.num_attention_heads, config.intermediate_size
@@ -94,6 +99,10 @@ class Wav2Vec2ForCTC:
         c.activation_dropout, c.feat_proj_dropout = config.activation_dropout, config.feat_proj_dropout
         c.final_dropout = config.final_dropout
         c.freeze_feature_encoder = int(freeze_feature_encoder)
+        return c
+
+    def _finish_init(self, c, seed):
+        config = self.config
         self._c = c
         h = C.c_void_p()
         hip.check(hip.lib.ssak_w2v2_create(C.byref(c), C.byref(h)))
@@ -190,7 +199,7 @@ class Wav2Vec2ForCTC:
                 labels: Optional[torch.Tensor] = None, mask_time_indices=None, layer_keep=None, lengths=None):
         cfg = self.config
         x = input_values.to(device=self.device, dtype=torch.float32).contiguous()
-        B, T = x.shape
+        B, T = x.shape[0], x.shape[-1]  # [B, samples] (wav2vec2) or [B, mel bins, feature frames] (Whisper encoder)
         if attention_mask is not None and lengths is None:
             lengths = attention_mask.to(self.device).sum(-1)
         lens_dev = None

@@ -241,3 +241,30 @@ def test_trainer_bucketed_allreduce_single_rank(mods):
     n_train = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).num_trainable
     assert spans[-1][0] + spans[-1][1] == n_train
     assert sum(c for _, c in spans) >= n_train - 8 * len(spans)  # only alignment padding is left out
+
+
+def test_whisper_encoder_ctc_vs_hf(gold):
+    """BASELINE config 4 composition (WhisperEncoder -> Linear -> CTC; no reference call site): tiny
+    dimensions, log-mel features computed by the HIP front end (a13) from the waveform, against the golden made with
+    transformers.WhisperEncoder."""
+    import ssak_amd.hip as hip
+    from ssak_amd.whisper import WhisperCTCConfig, WhisperEncoderForCTC
+    from oracle import whisper_ref as WR
+    z = gold("whisper_tiny.npz")
+    oc = WR.WhisperCTCConfig.tiny()
+    cfg = WhisperCTCConfig(vocab_size=oc.vocab_size, d_model=oc.d_model, encoder_layers=oc.encoder_layers,
+                           encoder_attention_heads=oc.encoder_attention_heads, encoder_ffn_dim=oc.encoder_ffn_dim,
+                           max_source_positions=oc.max_source_positions)
+    model = WhisperEncoderForCTC(cfg).train()
+    model.load_state_dict(WR.init_params(oc, 69))
+    mel = hip.logmel_whisper(torch.tensor(z["wav"]).cuda(), n_samples=16000)
+    assert np.abs(mel.cpu().numpy() - z["mel"]).max() < 2e-4
+    out = model(mel, labels=torch.tensor(z["labels"]))
+    assert out.logits.shape == (2, 50, 32)
+    assert rel_l2(out.logits.cpu().numpy(), z["logits"]) < 2e-2
+    assert abs(out.loss.item() - float(z["loss"])) < 2e-2 * float(z["loss"])
+    model.backward()
+    grads = {k[5:]: z[k] for k in z.files if k.startswith("grad/")}
+    worst = _check_grads(model, grads, 6e-2)
+    print("whisper tiny worst grad", worst)
+    assert float(model.grad("encoder.layers.0.self_attn.k_proj.bias").abs().max()) == 0.0
