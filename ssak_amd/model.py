@@ -130,8 +130,9 @@ class Wav2Vec2ForCTC:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            hip.lib.ssak_w2v2_destroy(h)
+        lib = getattr(hip, "lib", None)  # may already be gone at interpreter shutdown
+        if h and lib is not None:
+            lib.ssak_w2v2_destroy(h)
             self._h = None
 
     # ------------------------------------------------------------------ parameters
