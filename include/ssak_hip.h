@@ -122,6 +122,17 @@ typedef struct {
 int ssak_prof_enable(int on);
 int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 20; returns the number of entries (20) */
 
+/* ---- a7 (part): fused self-attention, head_dim 64 --------------------------------------------
+ * Replaces Wav2Vec2Attention's softmax(QK^T d^-0.5 + key mask) -> dropout -> .V and its autograd
+ * (transformers modeling_wav2vec2.py:438-463,500-548) for one layer.  qkv [B*F, 3H] bf16 (q | k | v, heads
+ * interleaved in the channel dimension), ctx [B*F, H] bf16, lse [B, nh, F] fp32 (saved for the backward),
+ * klens [B] valid keys or NULL.  Backward: dctx [B*F, H] -> dqkv [B*F, 3H]; delta [B, nh, F] fp32 scratch.
+ * Exported for per-op parity tests; the engine calls the same kernels. */
+int ssak_attention_fwd(const void* qkv, void* ctx, float* lse, const int32_t* klens, int B, int F, int nh, int H, float drop_p,
+                       uint64_t seed, uint32_t stream_id, void* stream);
+int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx, float* delta,
+                       void* dqkv, int B, int F, int nh, int H, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
+
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer
  * (docker/transformers_modified/trainer.py:1827-1855; ssak/train/transformers/wav2vec_train.py:353-384).

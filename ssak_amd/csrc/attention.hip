@@ -1,0 +1,586 @@
+// Fused multi-head self-attention (head_dim 64), forward and backward.  gfx950.
+//
+// Stands behind Wav2Vec2Attention / eager_attention_forward (transformers modeling_wav2vec2.py:438-463,500-548) and
+// WhisperAttention inside the encoder layers: softmax(Q K^T * d^-0.5 + key mask) -> dropout -> . V, per (utterance,
+// head), and its autograd.  The unfused path (GEMM -> softmax kernel -> GEMM) moved every [frames x frames] score
+// matrix through HBM four times per layer; here scores live only in MFMA accumulators:
+//
+//  forward : one workgroup = 128 queries of one (b, h); 4 waves x 32 queries.  K/V tiles of 64 keys stream through
+//            LDS by LDS-DMA (double buffered, source-side swizzle).  S^T = K Q^T is computed with the KEY on the
+//            accumulator row and the QUERY on the lane, so the online-softmax statistics (running max / sum) are
+//            per-lane scalars and the probabilities are already the B operand of O^T = V^T P^T (the k order inside an
+//            MFMA step is permuted identically on both operands).  Only O and the log-sum-exp per row are written.
+//  backward: recompute P from Q, K and the saved log-sum-exp (flash-attention style), two kernels so that no
+//            gradient needs cross-workgroup atomics: dQ (workgroup owns 128 queries, sweeps keys; same orientation
+//            as the forward) and dK/dV (workgroup owns 128 keys, sweeps queries; S = Q K^T orientation so that P and
+//            dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS).
+// Dropout bits come from a counter hash of (seed, stream, row, key pair): 16-bit uniforms, two per hash; the
+// forward and both backward kernels regenerate identical masks.  Key-padding masks (ragged batches) are applied as
+// -inf before the softmax, as create_bidirectional_mask does.
+#include "kernels.h"
+
+namespace {
+
+constexpr int HD = 64;    // head dim
+constexpr int QB = 128;   // queries (or keys in dkv) per workgroup
+constexpr int KT = 64;    // keys (or queries in dkv) per streamed tile
+constexpr int TILE_BYTES = KT * HD * 2;  // 8 KiB
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+struct AttnParams {
+  const bf16* qkv;     // [B*F, 3H]: q | k | v
+  bf16* ctx;           // [B*F, H]    forward output
+  float* lse;          // [B, nh, F]  log-sum-exp of the scaled, masked scores
+  const int32_t* klens;
+  const bf16* dctx;    // [B*F, H]    backward input
+  float* delta;        // [B, nh, F]  rowsum(dO * O)
+  bf16* dqkv;          // [B*F, 3H]   backward output
+  int B, F, nh, H, Fp;
+  float scale;
+  uint64_t seed;
+  uint32_t stream, thresh16;
+  float drop_scale;
+};
+
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+
+// two 16-bit uniforms for keys (2w', 2w'+1) of one query row; keep iff u >= thresh16
+__device__ __forceinline__ uint32_t drop_word(const AttnParams& p, uint64_t rowbase, int key) {
+  return hash_u32(p.seed, p.stream, rowbase + (uint64_t)(key >> 1));
+}
+
+// LDS tile images (64 rows x 128 B each):
+//   row-read image  : chunk c of row r at c ^ ((r >> 1) & 7)      -> ds_read_b128 fragments (row on the lane)
+//   transpose image : chunk c of row r at c ^ (r & 6)             -> ds_read_b64_tr_b16 fragments (column on the lane)
+__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, uint32_t col_byte, long ld_bytes,
+                                         int row0, int nrows_total, bool transpose_image, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int S = (wave * 2 + j) * 64 + lane;
+    const int r = S >> 3, pc = S & 7;
+    const int c = transpose_image ? (pc ^ (r & 6)) : (pc ^ ((r >> 1) & 7));
+    const int gr = row0 + r;
+    const uint32_t off = gr < nrows_total ? (uint32_t)((long)gr * ld_bytes + col_byte + c * 16) : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+// row-read fragment: rows 16*sub + (lane&15), k = 32*kk + 8*(lane>>4) + j
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int sub, int kk, int lane) {
+  const int r = 16 * sub + (lane & 15);
+  const int c = kk * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+}
+// transpose fragment from the transpose image: A[row = column 16*ci + (lane&15) of the tile][k = tile rows]:
+//   element j < 4: tile row rbase + 4*(lane>>4) + j, j >= 4: tile row rbase + 16 + 4*(lane>>4) + (j-4)
+// (this is the k permutation of an accumulator tile used as the other operand)
+__device__ __forceinline__ bf16x8 frag_cols_perm(const char* tile, int ci, int rbase, int lane) {
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int r = rbase + 4 * g + q4;
+  const int ch = 2 * ci + (p4 >> 1);
+  const char* a = tile + r * 128 + ((ch ^ (r & 6)) << 4) + (p4 & 1) * 8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a + 16 * 128));
+  s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack_p(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+  r[0] = (bf16)a[0];
+  r[1] = (bf16)a[1];
+  r[2] = (bf16)a[2];
+  r[3] = (bf16)a[3];
+  r[4] = (bf16)b[0];
+  r[5] = (bf16)b[1];
+  r[6] = (bf16)b[2];
+  r[7] = (bf16)b[3];
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 load_row_frag(const bf16* base, long ld, int row, int nrows, int kk, int lane) {
+  // global -> register fragment: row `row`, k = 32*kk + 8*(lane>>4) + j   (zero beyond nrows)
+  bf16x8 z = {};
+  if (row >= nrows) return z;
+  return *reinterpret_cast<const bf16x8*>(base + (long)row * ld + 32 * kk + 8 * (lane >> 4));
+}
+
+// ================================================================================================ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K | V)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+  const int F = p.F, H = p.H;
+  const long ld = 3L * H;
+  const bf16* base = p.qkv + (long)b * F * ld;
+  const int kl = p.klens ? min(max(p.klens[b], 0), F) : F;
+  const int nkt = (kl + KT - 1) / KT;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
+  const uint32_t kcol = (uint32_t)((H + h * HD) * 2), vcol = (uint32_t)((2 * H + h * HD) * 2);
+
+  // this lane's two query rows (one per 16-row sub-tile) and their Q fragments
+  int qrow[2];
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    qrow[qs] = q0 + 32 * wave + 16 * qs + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[qs][kk] = load_row_frag(base + h * HD, ld, qrow[qs], F, kk, lane);
+  }
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  f32x4 oacc[2][4];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oacc[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nkt > 0) {
+    dma_tile(rsrc, smem, kcol, ld * 2, 0, F, false, wave, lane);
+    dma_tile(rsrc, smem + TILE_BYTES, vcol, ld * 2, 0, F, true, wave, lane);
+  }
+  const int g = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES, kcol, ld * 2, (kt + 1) * KT, F, false, wave, lane);
+      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, vcol, ld * 2, (kt + 1) * KT, F, true, wave, lane);
+    }
+    const char* kt_lds = smem + cur * 2 * TILE_BYTES;
+    const char* vt_lds = kt_lds + TILE_BYTES;
+    const int k0 = kt * KT;
+    // ---- S^T = K Q^T : rows = keys (16*ks + 4g + r), column = this lane's query
+    f32x4 s[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 ka = frag_rows(kt_lds, ks, 0, lane), kb = frag_rows(kt_lds, ks, 1, lane);
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qs][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[qs][1], a, 0, 0, 0);
+        s[qs][ks] = a;
+      }
+    }
+    // ---- online softmax per query (lane-local column), dropout, pack P^T as the B operand of the PV product
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + 16 * ks + 4 * g + r;
+          const float v = key < kl ? s[qs][ks][r] * p.scale : -INFINITY;
+          s[qs][ks][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, shfl_xor_f(mx, 16));
+      mx = fmaxf(mx, shfl_xor_f(mx, 32));
+      const float m_new = fmaxf(m_run[qs], mx);
+      const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run[qs] - m_new);
+      float rs = 0.f;
+      const uint64_t rowbase = ((uint64_t)((long)b * p.nh + h) * F + (uint64_t)min(qrow[qs], F - 1)) * (uint64_t)(p.Fp >> 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int r2 = 0; r2 < 4; r2 += 2) {
+          const int key = k0 + 16 * ks + 4 * g + r2;
+          float e0 = (m_new == -INFINITY) ? 0.f : __expf(s[qs][ks][r2] - m_new);
+          float e1 = (m_new == -INFINITY) ? 0.f : __expf(s[qs][ks][r2 + 1] - m_new);
+          rs += e0 + e1;
+          if (p.thresh16) {
+            const uint32_t w = drop_word(p, rowbase, key);
+            e0 = ((w & 0xffffu) >= p.thresh16) ? e0 * p.drop_scale : 0.f;
+            e1 = ((w >> 16) >= p.thresh16) ? e1 * p.drop_scale : 0.f;
+          }
+          s[qs][ks][r2] = e0;
+          s[qs][ks][r2 + 1] = e1;
+        }
+      }
+      rs += shfl_xor_f(rs, 16);
+      rs += shfl_xor_f(rs, 32);
+      l_run[qs] = l_run[qs] * alpha + rs;
+      m_run[qs] = m_new;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) oacc[qs][i] *= alpha;
+      pb[qs][0] = pack_p(s[qs][0], s[qs][1]);
+      pb[qs][1] = pack_p(s[qs][2], s[qs][3]);
+    }
+    // ---- O^T += V^T P^T : rows = d (16*i + 4g + r), column = query; k = keys in the permuted order of pb
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 va = frag_cols_perm(vt_lds, i, 32 * t2, lane);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) oacc[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qs][t2], oacc[qs][i], 0, 0, 0);
+      }
+  }
+  // ---- epilogue: O = acc / l, log-sum-exp for the backward
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int q = qrow[qs];
+    if (q >= F) continue;
+    const float inv = l_run[qs] > 0.f ? 1.f / l_run[qs] : 0.f;
+    if (g == 0 && p.lse) p.lse[((long)b * p.nh + h) * F + q] = l_run[qs] > 0.f ? m_run[qs] + __logf(l_run[qs]) : -INFINITY;
+    bf16* dst = p.ctx + ((long)b * F + q) * H + h * HD + 4 * g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x4 o = {(bf16)(oacc[qs][i][0] * inv), (bf16)(oacc[qs][i][1] * inv), (bf16)(oacc[qs][i][2] * inv),
+                        (bf16)(oacc[qs][i][3] * inv)};
+      *reinterpret_cast<bf16x4*>(dst + 16 * i) = o;
+    }
+  }
+}
+
+// ================================================================================================ backward
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per row of [B*F, H], 64 lanes = 64 d of one head at a time)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ dctx, const bf16* __restrict__ ctx,
+                                                         float* __restrict__ delta, int B, int F, int nh, int H) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * F) return;
+  const int b = (int)(row / F), q = (int)(row % F);
+  for (int h = 0; h < nh; ++h) {
+    const long o = row * H + h * HD + lane;
+    float v = (float)dctx[o] * (float)ctx[o];
+    v = wave_sum(v);
+    if (lane == 0) delta[((long)b * nh + h) * F + q] = v;
+  }
+}
+
+// dQ: workgroup = 128 queries of one (b, h); sweeps the keys.  Same orientation as the forward:
+//   S^T[key][q], dP^T[key][q] = V dO^T, dS^T = P^T * (dP^T * mask/(1-p) - delta[q]); dQ^T[d][q] += K^T[d][key] dS^T[key][q].
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K rows | K transpose | V rows)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+  const int F = p.F, H = p.H;
+  const long ld = 3L * H;
+  const bf16* base = p.qkv + (long)b * F * ld;
+  const int kl = p.klens ? min(max(p.klens[b], 0), F) : F;
+  const int nkt = (kl + KT - 1) / KT;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
+  const uint32_t kcol = (uint32_t)((H + h * HD) * 2), vcol = (uint32_t)((2 * H + h * HD) * 2);
+  const int g = lane >> 4;
+  int qrow[2];
+  bf16x8 qf[2][2], dof[2][2];
+  float lse[2], dl[2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    qrow[qs] = q0 + 32 * wave + 16 * qs + (lane & 15);
+    const int qc = min(qrow[qs], F - 1);
+    lse[qs] = p.lse[((long)b * p.nh + h) * F + qc];
+    dl[qs] = p.delta[((long)b * p.nh + h) * F + qc];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[qs][kk] = load_row_frag(base + h * HD, ld, qrow[qs], F, kk, lane);
+      dof[qs][kk] = load_row_frag(p.dctx + (long)b * F * H + h * HD, H, qrow[qs], F, kk, lane);
+    }
+  }
+  f32x4 dq[2][4];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int kt, int stage) {
+    char* s0 = smem + stage * 3 * TILE_BYTES;
+    dma_tile(rsrc, s0, kcol, ld * 2, kt * KT, F, false, wave, lane);
+    dma_tile(rsrc, s0 + TILE_BYTES, kcol, ld * 2, kt * KT, F, true, wave, lane);
+    dma_tile(rsrc, s0 + 2 * TILE_BYTES, vcol, ld * 2, kt * KT, F, false, wave, lane);
+  };
+  if (nkt > 0) issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (kt + 1 < nkt) issue(kt + 1, cur ^ 1);
+    const char* k_rows = smem + cur * 3 * TILE_BYTES;
+    const char* k_tr = k_rows + TILE_BYTES;
+    const char* v_rows = k_rows + 2 * TILE_BYTES;
+    const int k0 = kt * KT;
+    bf16x8 dsb[2][2];
+    {
+      f32x4 s[2][4], dp[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 ka = frag_rows(k_rows, ks, 0, lane), kb = frag_rows(k_rows, ks, 1, lane);
+        const bf16x8 va = frag_rows(v_rows, ks, 0, lane), vb = frag_rows(v_rows, ks, 1, lane);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qs][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[qs][1], a, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qs][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, dof[qs][1], c, 0, 0, 0);
+          s[qs][ks] = a;
+          dp[qs][ks] = c;
+        }
+      }
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        const uint64_t rowbase = ((uint64_t)((long)b * p.nh + h) * F + (uint64_t)min(qrow[qs], F - 1)) * (uint64_t)(p.Fp >> 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int r2 = 0; r2 < 4; r2 += 2) {
+            const int key = k0 + 16 * ks + 4 * g + r2;
+            float keep0 = 1.f, keep1 = 1.f;
+            if (p.thresh16) {
+              const uint32_t w = drop_word(p, rowbase, key);
+              keep0 = ((w & 0xffffu) >= p.thresh16) ? p.drop_scale : 0.f;
+              keep1 = ((w >> 16) >= p.thresh16) ? p.drop_scale : 0.f;
+            }
+            const float p0 = (key < kl && lse[qs] > -INFINITY) ? __expf(s[qs][ks][r2] * p.scale - lse[qs]) : 0.f;
+            const float p1 = (key + 1 < kl && lse[qs] > -INFINITY) ? __expf(s[qs][ks][r2 + 1] * p.scale - lse[qs]) : 0.f;
+            s[qs][ks][r2] = p0 * (dp[qs][ks][r2] * keep0 - dl[qs]) * p.scale;
+            s[qs][ks][r2 + 1] = p1 * (dp[qs][ks][r2 + 1] * keep1 - dl[qs]) * p.scale;
+          }
+        dsb[qs][0] = pack_p(s[qs][0], s[qs][1]);
+        dsb[qs][1] = pack_p(s[qs][2], s[qs][3]);
+      }
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 ka = frag_cols_perm(k_tr, i, 32 * t2, lane);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) dq[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb[qs][t2], dq[qs][i], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int q = qrow[qs];
+    if (q >= F) continue;
+    bf16* dst = p.dqkv + ((long)b * F + q) * ld + h * HD + 4 * g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x4 o = {(bf16)dq[qs][i][0], (bf16)dq[qs][i][1], (bf16)dq[qs][i][2], (bf16)dq[qs][i][3]};
+      *reinterpret_cast<bf16x4*>(dst + 16 * i) = o;
+    }
+  }
+}
+
+// dK, dV: workgroup = 128 keys of one (b, h) (4 waves x 32 keys); sweeps the queries in tiles of 64.
+//   S[q][key] = Q K^T (query on the accumulator row, key on the lane), dP[q][key] = dO V^T,
+//   Pd = P * mask/(1-p), dS = P * (dP * mask/(1-p) - delta[q]) * scale,
+//   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key].
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q rows|Q tr|dO rows|dO tr), then lse|delta per stage
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * QB;
+  const int F = p.F, H = p.H;
+  const long ld = 3L * H;
+  const bf16* base = p.qkv + (long)b * F * ld;
+  const int kl = p.klens ? min(max(p.klens[b], 0), F) : F;
+  const int nqt = (F + KT - 1) / KT;
+  __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dctx + (long)b * F * H), 0, (int)((long)F * H * 2), 0x00020000);
+  const uint32_t qcol = (uint32_t)(h * HD * 2);
+  const int g = lane >> 4;
+  float* stat = reinterpret_cast<float*>(smem + 2 * 4 * TILE_BYTES);  // [stage][lse KT | delta KT]
+  int krow[2];
+  bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    krow[ks] = key0 + 32 * wave + 16 * ks + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[ks][kk] = load_row_frag(base + H + h * HD, ld, krow[ks], F, kk, lane);
+      vf[ks][kk] = load_row_frag(base + 2 * H + h * HD, ld, krow[ks], F, kk, lane);
+    }
+  }
+  f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dk[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  auto issue = [&](int qt, int stage) {
+    char* s0 = smem + stage * 4 * TILE_BYTES;
+    dma_tile(rs_qkv, s0, qcol, ld * 2, qt * KT, F, false, wave, lane);
+    dma_tile(rs_qkv, s0 + TILE_BYTES, qcol, ld * 2, qt * KT, F, true, wave, lane);
+    dma_tile(rs_do, s0 + 2 * TILE_BYTES, qcol, (long)H * 2, qt * KT, F, false, wave, lane);
+    dma_tile(rs_do, s0 + 3 * TILE_BYTES, qcol, (long)H * 2, qt * KT, F, true, wave, lane);
+    if (threadIdx.x < KT) {
+      const int q = qt * KT + threadIdx.x;
+      const long o = ((long)b * p.nh + h) * F + min(q, F - 1);
+      stat[stage * 2 * KT + threadIdx.x] = q < F ? p.lse[o] : -INFINITY;
+      stat[stage * 2 * KT + KT + threadIdx.x] = q < F ? p.delta[o] : 0.f;
+    }
+  };
+  issue(0, 0);
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int cur = qt & 1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (qt + 1 < nqt) issue(qt + 1, cur ^ 1);
+    const char* q_rows = smem + cur * 4 * TILE_BYTES;
+    const char* q_tr = q_rows + TILE_BYTES;
+    const char* do_rows = q_rows + 2 * TILE_BYTES;
+    const char* do_tr = q_rows + 3 * TILE_BYTES;
+    const float* lse_s = stat + cur * 2 * KT;
+    const float* dl_s = lse_s + KT;
+    const int qq0 = qt * KT;
+    bf16x8 pdb[2][2], dsb[2][2];  // [key sub-tile][32-query k-step]
+    {
+      f32x4 s[2][4], dp[2][4];  // [key sub-tile][query sub-tile]: rows = queries 16*qsb + 4g + r, column = key
+#pragma unroll
+      for (int qsb = 0; qsb < 4; ++qsb) {
+        const bf16x8 qa = frag_rows(q_rows, qsb, 0, lane), qb = frag_rows(q_rows, qsb, 1, lane);
+        const bf16x8 da = frag_rows(do_rows, qsb, 0, lane), db = frag_rows(do_rows, qsb, 1, lane);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf[ks][1], a, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db, vf[ks][1], c, 0, 0, 0);
+          s[ks][qsb] = a;
+          dp[ks][qsb] = c;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int key = krow[ks];
+        const bool kvalid = key < kl;
+#pragma unroll
+        for (int qsb = 0; qsb < 4; ++qsb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ql = 16 * qsb + 4 * g + r;  // query inside the tile
+            const int q = qq0 + ql;
+            const float ls = lse_s[ql], dl = dl_s[ql];
+            float keep = 1.f;
+            if (p.thresh16) {
+              const uint64_t rowbase = ((uint64_t)((long)b * p.nh + h) * F + (uint64_t)min(q, F - 1)) * (uint64_t)(p.Fp >> 1);
+              const uint32_t w = drop_word(p, rowbase, key);
+              const uint32_t u = (key & 1) ? (w >> 16) : (w & 0xffffu);
+              keep = (u >= p.thresh16) ? p.drop_scale : 0.f;
+            }
+            const float pr = (kvalid && q < F && ls > -INFINITY) ? __expf(s[ks][qsb][r] * p.scale - ls) : 0.f;
+            const float dpv = dp[ks][qsb][r] * keep;
+            s[ks][qsb][r] = pr * keep;                    // Pd
+            dp[ks][qsb][r] = pr * (dpv - dl) * p.scale;   // dS
+          }
+        pdb[ks][0] = pack_p(s[ks][0], s[ks][1]);
+        pdb[ks][1] = pack_p(s[ks][2], s[ks][3]);
+        dsb[ks][0] = pack_p(dp[ks][0], dp[ks][1]);
+        dsb[ks][1] = pack_p(dp[ks][2], dp[ks][3]);
+      }
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 doa = frag_cols_perm(do_tr, i, 32 * t2, lane);
+        const bf16x8 qa = frag_cols_perm(q_tr, i, 32 * t2, lane);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          dv[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa, pdb[ks][t2], dv[ks][i], 0, 0, 0);
+          dk[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, dsb[ks][t2], dk[ks][i], 0, 0, 0);
+        }
+      }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int key = krow[ks];
+    if (key >= F) continue;
+    bf16* dkd = p.dqkv + ((long)b * F + key) * ld + H + h * HD + 4 * g;
+    bf16* dvd = dkd + H;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x4 a = {(bf16)dk[ks][i][0], (bf16)dk[ks][i][1], (bf16)dk[ks][i][2], (bf16)dk[ks][i][3]};
+      const bf16x4 c = {(bf16)dv[ks][i][0], (bf16)dv[ks][i][1], (bf16)dv[ks][i][2], (bf16)dv[ks][i][3]};
+      *reinterpret_cast<bf16x4*>(dkd + 16 * i) = a;
+      *reinterpret_cast<bf16x4*>(dvd + 16 * i) = c;
+    }
+  }
+}
+
+AttnParams make_params(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens, const bf16* dctx, float* delta, bf16* dqkv,
+                       int B, int F, int nh, int H, const DropSpec& drop) {
+  AttnParams p;
+  p.qkv = qkv;
+  p.ctx = ctx;
+  p.lse = lse;
+  p.klens = klens;
+  p.dctx = dctx;
+  p.delta = delta;
+  p.dqkv = dqkv;
+  p.B = B;
+  p.F = F;
+  p.nh = nh;
+  p.H = H;
+  p.Fp = (F + 7) & ~7;
+  p.scale = 1.f / sqrtf((float)HD);
+  p.seed = drop.seed;
+  p.stream = drop.stream;
+  p.thresh16 = drop.p > 0.f ? (uint32_t)fminf(65535.f, roundf(drop.p * 65536.f)) : 0u;
+  p.drop_scale = p.thresh16 ? 1.f / (1.f - (float)p.thresh16 / 65536.f) : 1.f;
+  return p;
+}
+
+}  // namespace
+
+bool k_attention_supported(int H, int nh) { return nh > 0 && H / nh == HD && H % nh == 0; }
+
+int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens, int B, int F, int nh, int H,
+                    const DropSpec& drop, hipStream_t st) {
+  SSAK_REQUIRE(k_attention_supported(H, nh), "attention: fused kernels are built for head_dim 64 (got %d)", nh ? H / nh : 0);
+  SSAK_REQUIRE((long)F * 3 * H * 2 < 2000000000L, "attention: one utterance of q|k|v must span < 2 GB");
+  const AttnParams p = make_params(qkv, ctx, lse, klens, nullptr, nullptr, nullptr, B, F, nh, H, drop);
+  attn_fwd_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const int32_t* klens, const bf16* dctx, float* delta,
+                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, hipStream_t st) {
+  SSAK_REQUIRE(k_attention_supported(H, nh), "attention: fused kernels are built for head_dim 64 (got %d)", nh ? H / nh : 0);
+  const AttnParams p = make_params(qkv, const_cast<bf16*>(ctx), const_cast<float*>(lse), klens, dctx, delta, dqkv, B, F, nh, H, drop);
+  attn_delta_kernel<<<ssak_cdiv((long)B * F, 4), 256, 0, st>>>(dctx, ctx, delta, B, F, nh, H);
+  SSAK_LAUNCH_CHECK();
+  attn_bwd_dq_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 2 * KT * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+    attr_done = true;
+  }
+  attn_bwd_dkv_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, dkv_lds, st>>>(p);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+// exported for per-op parity tests
+extern "C" int ssak_attention_fwd(const void* qkv, void* ctx, float* lse, const int32_t* klens, int B, int F, int nh, int H,
+                                  float drop_p, uint64_t seed, uint32_t stream_id, void* stream) {
+  SSAK_REQUIRE(qkv && ctx && lse, "attention_fwd: null pointer");
+  DropSpec d;
+  d.p = drop_p;
+  d.seed = seed;
+  d.stream = stream_id;
+  return k_attention_fwd((const bf16*)qkv, (bf16*)ctx, lse, klens, B, F, nh, H, d, (hipStream_t)stream);
+}
+
+extern "C" int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx,
+                                  float* delta, void* dqkv, int B, int F, int nh, int H, float drop_p, uint64_t seed,
+                                  uint32_t stream_id, void* stream) {
+  SSAK_REQUIRE(qkv && ctx && lse && dctx && delta && dqkv, "attention_bwd: null pointer");
+  DropSpec d;
+  d.p = drop_p;
+  d.seed = seed;
+  d.stream = stream_id;
+  return k_attention_bwd((const bf16*)qkv, (const bf16*)ctx, lse, klens, (const bf16*)dctx, delta, (bf16*)dqkv, B, F, nh, H, d,
+                         (hipStream_t)stream);
+}

@@ -44,6 +44,13 @@ int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const 
                          int H, int G, int K, hipStream_t st);
 int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, hipStream_t st);
 
+// attention.hip (fused, head_dim 64)
+bool k_attention_supported(int H, int nh);
+int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens, int B, int F, int nh, int H,
+                    const DropSpec& drop, hipStream_t st);
+int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const int32_t* klens, const bf16* dctx, float* delta,
+                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, hipStream_t st);
+
 // whisper_frontend.hip
 int k_mel_to_cl(const float* mel, bf16* cl, int B, int C, int T, int RS, int lead, hipStream_t st);
 int k_add_rowvec(const bf16* x, const bf16* pos, bf16* out, int B, int F, int H, hipStream_t st);

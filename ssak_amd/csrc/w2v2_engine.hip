@@ -48,6 +48,7 @@ struct Carver {
 
 struct LayerBuf {
   size_t qkv, P, Pd, ctx, r1, x1, f1pre, f1, r2, st;  // st: mean1|rstd1|mean2|rstd2 (4*M floats)
+  size_t lse;  // fused attention: log-sum-exp per (b, head, query) instead of the probability matrices
 };
 
 struct Plan {
@@ -61,6 +62,8 @@ struct Plan {
   size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH, lnpart;
   // Whisper front end: RS2 rows per utterance after conv2, RS1 = 2*RS2 before it
   int Tin = 0, RS1 = 0, RS2 = 0;
+  bool fused_attn = false;
+  size_t delta = 0;
   size_t melcl, h1pad, pre1, wpre2, we, dpre2pad, dxcol, dpre1pad, dwr;
   size_t slab_bytes = 0;
   size_t total = 0;
@@ -310,7 +313,8 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
   p.h1 = cv.take((size_t)M * H * b2);
   p.stE = cv.take((size_t)2 * M * sizeof(float));
   p.tmpH = cv.take((size_t)M * H * b2);
-  p.S = cv.take((size_t)B * nh * p.F * p.Fp * b2);
+  p.fused_attn = k_attention_supported((int)H, (int)nh);
+  p.S = cv.take(p.fused_attn ? 256 : (size_t)B * nh * p.F * p.Fp * b2);
   p.xf = cv.take((size_t)M * H * b2);
   const int nl = c.num_layers;
   p.x.resize(nl + 1);
@@ -322,8 +326,9 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     LayerBuf& lb = p.lb[l];
     if (training || l == 0) {
       lb.qkv = cv.take((size_t)M * 3 * H * b2);
-      lb.P = cv.take((size_t)B * nh * p.F * p.Fp * b2);
-      lb.Pd = drop_attn ? cv.take((size_t)B * nh * p.F * p.Fp * b2) : lb.P;
+      lb.P = cv.take(p.fused_attn ? 256 : (size_t)B * nh * p.F * p.Fp * b2);
+      lb.Pd = (drop_attn && !p.fused_attn) ? cv.take((size_t)B * nh * p.F * p.Fp * b2) : lb.P;
+      lb.lse = cv.take((size_t)B * nh * p.F * sizeof(float));
       lb.ctx = cv.take((size_t)M * H * b2);
       lb.r1 = cv.take((size_t)M * H * b2);
       lb.x1 = cv.take((size_t)M * H * b2);
@@ -344,7 +349,8 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.scratchH = cv.take((size_t)M * H * b2);
     p.dI = cv.take((size_t)M * I * b2);
     p.dqkv = cv.take((size_t)M * 3 * H * b2);
-    p.dSb = cv.take((size_t)B * nh * p.F * p.Fp * b2);
+    p.dSb = cv.take(p.fused_attn ? 256 : (size_t)B * nh * p.F * p.Fp * b2);
+    p.delta = cv.take((size_t)B * nh * p.F * sizeof(float));
     p.pgdy = cv.take((size_t)G * p.pg_rows * (H / G) * b2);
     p.dwf = cv.take((size_t)H * K * (H / G) * sizeof(float));
     p.dln0 = cv.take((size_t)M * C * b2);
@@ -731,12 +737,17 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
     const bf16* x = BF(p.x[l]);
     bf16* qkv = BF(lb.qkv);
     TRY(Gemm(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
-    TRY(Gemm(F, F, hd).a(qkv, 3 * H).b(qkv + H, 3 * H).c(BF(p.S), Fp).alpha(scale)
-            .batch(B, nh, (long)F * 3 * H, hd, (long)F * 3 * H, hd, (long)nh * F * Fp, (long)F * Fp).run(st));
-    TRY(k_softmax_fwd(BF(p.S), BF(lb.P), lb.Pd != lb.P ? BF(lb.Pd) : nullptr, flens, B * nh * F, F, Fp, nh * F,
-                      DS(c.attention_dropout, ds_attn(l)), st));
-    TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
-            .batch(B, nh, (long)nh * F * Fp, (long)F * Fp, (long)F * 3 * H, hd, (long)F * H, hd).run(st));
+    if (p.fused_attn) {
+      // scores never leave the MFMA accumulators (attention.hip); only ctx and the per-row log-sum-exp are written
+      TRY(k_attention_fwd(qkv, BF(lb.ctx), FP(lb.lse), flens, B, F, nh, H, DS(c.attention_dropout, ds_attn(l)), st));
+    } else {
+      TRY(Gemm(F, F, hd).a(qkv, 3 * H).b(qkv + H, 3 * H).c(BF(p.S), Fp).alpha(scale)
+              .batch(B, nh, (long)F * 3 * H, hd, (long)F * 3 * H, hd, (long)nh * F * Fp, (long)F * Fp).run(st));
+      TRY(k_softmax_fwd(BF(p.S), BF(lb.P), lb.Pd != lb.P ? BF(lb.Pd) : nullptr, flens, B * nh * F, F, Fp, nh * F,
+                        DS(c.attention_dropout, ds_attn(l)), st));
+      TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
+              .batch(B, nh, (long)nh * F * Fp, (long)F * Fp, (long)F * 3 * H, hd, (long)F * H, hd).run(st));
+    }
     TRY(Gemm(M, H, H).a(BF(lb.ctx), H).b(W + L.wo, H).c(BF(p.tmpH), H).with_bias(P + L.bo).run(st));
     if (!stable) {
       TRY(k_layernorm_fwd(BF(p.tmpH), x, P + L.ln1w, P + L.ln1b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
@@ -894,15 +905,20 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     bf16* qkv = BF(lb.qkv);
     bf16* dqkv = BF(p.dqkv);
     const long sq1 = (long)F * 3 * H, sp1 = (long)nh * F * Fp, sp2 = (long)F * Fp, sh1 = (long)F * H;
-    TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
-            .batch(B, nh, sp1, sp2, sh1, hd, sq1, hd).run(st));  // dV = Pd^T dctx
-    TRY(Gemm(F, F, hd).a(dctx, H).b(qkv + 2 * H, 3 * H).c(BF(p.S), Fp)
-            .batch(B, nh, sh1, hd, sq1, hd, sp1, sp2).run(st));  // dPd = dctx V^T
-    TRY(k_softmax_bwd(BF(p.S), BF(lb.P), BF(p.dSb), B * nh * F, F, Fp, DS(c.attention_dropout, ds_attn(l)), st));
-    TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp).b(qkv + H, 3 * H, true).c(dqkv, 3 * H).alpha(scale)
-            .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dQ = scale dS K
-    TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
-            .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
+    if (p.fused_attn) {
+      TRY(k_attention_bwd(qkv, BF(lb.ctx), FP(lb.lse), flens, dctx, FP(p.delta), dqkv, B, F, nh, H,
+                          DS(c.attention_dropout, ds_attn(l)), st));
+    } else {
+      TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
+              .batch(B, nh, sp1, sp2, sh1, hd, sq1, hd).run(st));  // dV = Pd^T dctx
+      TRY(Gemm(F, F, hd).a(dctx, H).b(qkv + 2 * H, 3 * H).c(BF(p.S), Fp)
+              .batch(B, nh, sh1, hd, sq1, hd, sp1, sp2).run(st));  // dPd = dctx V^T
+      TRY(k_softmax_bwd(BF(p.S), BF(lb.P), BF(p.dSb), B * nh * F, F, Fp, DS(c.attention_dropout, ds_attn(l)), st));
+      TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp).b(qkv + H, 3 * H, true).c(dqkv, 3 * H).alpha(scale)
+              .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dQ = scale dS K
+      TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
+              .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
+    }
     TRY(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st));
     TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));

@@ -63,6 +63,8 @@ def _load():
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_prof_enable": (i32, [i32]),
         "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
+        "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
+        "ssak_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
         "ssak_grad_sumsq": (i32, [vp, C.c_long, vp, vp]),
         "ssak_adamw_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
         "ssak_w2v2_create": (i32, [C.POINTER(W2V2Config), C.POINTER(vp)]),
@@ -213,3 +215,25 @@ def prof_collect():
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops) for i in range(n)]
+
+
+def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0):
+    """qkv [B*F, 3H] bf16 -> (ctx [B*F, H] bf16, lse [B, nh, F] fp32)."""
+    H = qkv.shape[1] // 3
+    ctx = torch.empty((B * F, H), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, nh, F), dtype=torch.float32, device=qkv.device)
+    if klens is not None:
+        klens = klens.to(device=qkv.device, dtype=torch.int32).contiguous()
+    check(lib.ssak_attention_fwd(ptr(qkv), ptr(ctx), ptr(lse), ptr(klens), B, F, nh, H, float(drop_p), seed, stream_id, stream()))
+    return ctx, lse
+
+
+def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0):
+    H = qkv.shape[1] // 3
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty((B, nh, F), dtype=torch.float32, device=qkv.device)
+    if klens is not None:
+        klens = klens.to(device=qkv.device, dtype=torch.int32).contiguous()
+    check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), ptr(klens), ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H,
+                                 float(drop_p), seed, stream_id, stream()))
+    return dqkv
