@@ -47,8 +47,12 @@ struct AttnParams {
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
 // two 16-bit uniforms for keys (2w', 2w'+1) of one query row; keep iff u >= thresh16
-__device__ __forceinline__ uint32_t drop_word(const AttnParams& p, uint64_t rowbase, int key) {
-  return hash_u32(p.seed, p.stream, rowbase + (uint64_t)(key >> 1));
+__device__ __forceinline__ uint32_t drop_word(const AttnParams& p, uint32_t rowbase, int key) {
+  return hash_u32(p.seed, p.stream, (uint64_t)(rowbase + (uint32_t)(key >> 1)));
+}
+__device__ __forceinline__ uint32_t drop_rowbase(const AttnParams& p, int b, int h, int q) {
+  // counter of the first key pair of query row q of head (b, h); 32-bit wrap-around only aliases far-apart rows
+  return ((uint32_t)(b * p.nh + h) * (uint32_t)p.F + (uint32_t)min(q, p.F - 1)) * (uint32_t)(p.Fp >> 1);
 }
 
 // LDS tile images (64 rows x 128 B each):
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       const float m_new = fmaxf(m_run[qs], mx);
       const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run[qs] - m_new);
       float rs = 0.f;
-      const uint64_t rowbase = ((uint64_t)((long)b * p.nh + h) * F + (uint64_t)min(qrow[qs], F - 1)) * (uint64_t)(p.Fp >> 1);
+      const uint32_t rowbase = drop_rowbase(p, b, h, qrow[qs]);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 
 // dQ: workgroup = 128 queries of one (b, h); sweeps the keys.  Same orientation as the forward:
 //   S^T[key][q], dP^T[key][q] = V dO^T, dS^T = P^T * (dP^T * mask/(1-p) - delta[q]); dQ^T[d][q] += K^T[d][key] dS^T[key][q].
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K rows | K transpose | V rows)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
@@ -271,9 +275,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   int qrow[2];
   bf16x8 qf[2][2], dof[2][2];
   float lse[2], dl[2];
+  uint32_t rowbase[2];
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
     qrow[qs] = q0 + 32 * wave + 16 * qs + (lane & 15);
+    rowbase[qs] = drop_rowbase(p, b, h, qrow[qs]);
     const int qc = min(qrow[qs], F - 1);
     lse[qs] = p.lse[((long)b * p.nh + h) * F + qc];
     dl[qs] = p.delta[((long)b * p.nh + h) * F + qc];
@@ -304,55 +310,56 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     const char* k_tr = k_rows + TILE_BYTES;
     const char* v_rows = k_rows + 2 * TILE_BYTES;
     const int k0 = kt * KT;
-    bf16x8 dsb[2][2];
-    {
-      f32x4 s[2][4], dp[2][4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 ka = frag_rows(k_rows, ks, 0, lane), kb = frag_rows(k_rows, ks, 1, lane);
-        const bf16x8 va = frag_rows(v_rows, ks, 0, lane), vb = frag_rows(v_rows, ks, 1, lane);
+    for (int t2 = 0; t2 < 2; ++t2) {
+      bf16x8 dsb[2];
+      {
+        f32x4 s[2][2], dp[2][2];  // [query sub-tile][key sub-tile of this half]
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          const int ks = 2 * t2 + kh;
+          const bf16x8 ka = frag_rows(k_rows, ks, 0, lane), kb = frag_rows(k_rows, ks, 1, lane);
+          const bf16x8 va = frag_rows(v_rows, ks, 0, lane), vb = frag_rows(v_rows, ks, 1, lane);
+#pragma unroll
+          for (int qs = 0; qs < 2; ++qs) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qs][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[qs][1], a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qs][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, dof[qs][1], c, 0, 0, 0);
+            s[qs][kh] = a;
+            dp[qs][kh] = c;
+          }
+        }
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qs][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[qs][1], a, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qs][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, dof[qs][1], c, 0, 0, 0);
-          s[qs][ks] = a;
-          dp[qs][ks] = c;
+          const bool rowok = lse[qs] > -INFINITY;
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r2 = 0; r2 < 4; r2 += 2) {
+              const int key = k0 + 16 * (2 * t2 + kh) + 4 * g + r2;
+              float keep0 = 1.f, keep1 = 1.f;
+              if (p.thresh16) {
+                const uint32_t w = drop_word(p, rowbase[qs], key);
+                keep0 = ((w & 0xffffu) >= p.thresh16) ? p.drop_scale : 0.f;
+                keep1 = ((w >> 16) >= p.thresh16) ? p.drop_scale : 0.f;
+              }
+              const float p0 = (key < kl && rowok) ? __expf(s[qs][kh][r2] * p.scale - lse[qs]) : 0.f;
+              const float p1 = (key + 1 < kl && rowok) ? __expf(s[qs][kh][r2 + 1] * p.scale - lse[qs]) : 0.f;
+              s[qs][kh][r2] = p0 * (dp[qs][kh][r2] * keep0 - dl[qs]) * p.scale;
+              s[qs][kh][r2 + 1] = p1 * (dp[qs][kh][r2 + 1] * keep1 - dl[qs]) * p.scale;
+            }
+          dsb[qs] = pack_p(s[qs][0], s[qs][1]);
         }
       }
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        const uint64_t rowbase = ((uint64_t)((long)b * p.nh + h) * F + (uint64_t)min(qrow[qs], F - 1)) * (uint64_t)(p.Fp >> 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int r2 = 0; r2 < 4; r2 += 2) {
-            const int key = k0 + 16 * ks + 4 * g + r2;
-            float keep0 = 1.f, keep1 = 1.f;
-            if (p.thresh16) {
-              const uint32_t w = drop_word(p, rowbase, key);
-              keep0 = ((w & 0xffffu) >= p.thresh16) ? p.drop_scale : 0.f;
-              keep1 = ((w >> 16) >= p.thresh16) ? p.drop_scale : 0.f;
-            }
-            const float p0 = (key < kl && lse[qs] > -INFINITY) ? __expf(s[qs][ks][r2] * p.scale - lse[qs]) : 0.f;
-            const float p1 = (key + 1 < kl && lse[qs] > -INFINITY) ? __expf(s[qs][ks][r2 + 1] * p.scale - lse[qs]) : 0.f;
-            s[qs][ks][r2] = p0 * (dp[qs][ks][r2] * keep0 - dl[qs]) * p.scale;
-            s[qs][ks][r2 + 1] = p1 * (dp[qs][ks][r2 + 1] * keep1 - dl[qs]) * p.scale;
-          }
-        dsb[qs][0] = pack_p(s[qs][0], s[qs][1]);
-        dsb[qs][1] = pack_p(s[qs][2], s[qs][3]);
-      }
-    }
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bf16x8 ka = frag_cols_perm(k_tr, i, 32 * t2, lane);
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) dq[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb[qs][t2], dq[qs][i], 0, 0, 0);
+        for (int qs = 0; qs < 2; ++qs) dq[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb[qs], dq[qs][i], 0, 0, 0);
       }
+    }
   }
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 //   S[q][key] = Q K^T (query on the accumulator row, key on the lane), dP[q][key] = dO V^T,
 //   Pd = P * mask/(1-p), dS = P * (dP * mask/(1-p) - delta[q]) * scale,
 //   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key].
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q rows|Q tr|dO rows|dO tr), then lse|delta per stage
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * QB;
@@ -430,65 +437,68 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     const float* lse_s = stat + cur * 2 * KT;
     const float* dl_s = lse_s + KT;
     const int qq0 = qt * KT;
-    bf16x8 pdb[2][2], dsb[2][2];  // [key sub-tile][32-query k-step]
-    {
-      f32x4 s[2][4], dp[2][4];  // [key sub-tile][query sub-tile]: rows = queries 16*qsb + 4g + r, column = key
 #pragma unroll
-      for (int qsb = 0; qsb < 4; ++qsb) {
-        const bf16x8 qa = frag_rows(q_rows, qsb, 0, lane), qb = frag_rows(q_rows, qsb, 1, lane);
-        const bf16x8 da = frag_rows(do_rows, qsb, 0, lane), db = frag_rows(do_rows, qsb, 1, lane);
+    for (int t2 = 0; t2 < 2; ++t2) {
+      bf16x8 pdb[2], dsb[2];  // per key sub-tile, for the 32 queries of this half
+      {
+        f32x4 s[2][2], dp[2][2];  // [key sub-tile][query sub-tile of this half]: rows = queries, column = key
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf[ks][1], a, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db, vf[ks][1], c, 0, 0, 0);
-          s[ks][qsb] = a;
-          dp[ks][qsb] = c;
+        for (int qh = 0; qh < 2; ++qh) {
+          const int qsb = 2 * t2 + qh;
+          const bf16x8 qa = frag_rows(q_rows, qsb, 0, lane), qb = frag_rows(q_rows, qsb, 1, lane);
+          const bf16x8 da = frag_rows(do_rows, qsb, 0, lane), db = frag_rows(do_rows, qsb, 1, lane);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf[ks][1], a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db, vf[ks][1], c, 0, 0, 0);
+            s[ks][qh] = a;
+            dp[ks][qh] = c;
+          }
         }
-      }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int key = krow[ks];
-        const bool kvalid = key < kl;
-#pragma unroll
-        for (int qsb = 0; qsb < 4; ++qsb)
+        for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int ql = 16 * qsb + 4 * g + r;  // query inside the tile
+            const int ql = 16 * (2 * t2 + qh) + 4 * g + r;  // query inside the tile
             const int q = qq0 + ql;
             const float ls = lse_s[ql], dl = dl_s[ql];
-            float keep = 1.f;
-            if (p.thresh16) {
-              const uint64_t rowbase = ((uint64_t)((long)b * p.nh + h) * F + (uint64_t)min(q, F - 1)) * (uint64_t)(p.Fp >> 1);
-              const uint32_t w = drop_word(p, rowbase, key);
-              const uint32_t u = (key & 1) ? (w >> 16) : (w & 0xffffu);
-              keep = (u >= p.thresh16) ? p.drop_scale : 0.f;
-            }
-            const float pr = (kvalid && q < F && ls > -INFINITY) ? __expf(s[ks][qsb][r] * p.scale - ls) : 0.f;
-            const float dpv = dp[ks][qsb][r] * keep;
-            s[ks][qsb][r] = pr * keep;                    // Pd
-            dp[ks][qsb][r] = pr * (dpv - dl) * p.scale;   // dS
-          }
-        pdb[ks][0] = pack_p(s[ks][0], s[ks][1]);
-        pdb[ks][1] = pack_p(s[ks][2], s[ks][3]);
-        dsb[ks][0] = pack_p(dp[ks][0], dp[ks][1]);
-        dsb[ks][1] = pack_p(dp[ks][2], dp[ks][3]);
-      }
-    }
+            const bool rowok = q < F && ls > -INFINITY;
+            const uint32_t rowbase = drop_rowbase(p, b, h, q);
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+            for (int ks = 0; ks < 2; ++ks) {
+              const int key = krow[ks];
+              float keep = 1.f;
+              if (p.thresh16) {
+                const uint32_t w = drop_word(p, rowbase, key);
+                const uint32_t u = (key & 1) ? (w >> 16) : (w & 0xffffu);
+                keep = (u >= p.thresh16) ? p.drop_scale : 0.f;
+              }
+              const float pr = (rowok && key < kl) ? __expf(s[ks][qh][r] * p.scale - ls) : 0.f;
+              const float dpv = dp[ks][qh][r] * keep;
+              s[ks][qh][r] = pr * keep;                    // Pd
+              dp[ks][qh][r] = pr * (dpv - dl) * p.scale;   // dS
+            }
+          }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          pdb[ks] = pack_p(s[ks][0], s[ks][1]);
+          dsb[ks] = pack_p(dp[ks][0], dp[ks][1]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bf16x8 doa = frag_cols_perm(do_tr, i, 32 * t2, lane);
         const bf16x8 qa = frag_cols_perm(q_tr, i, 32 * t2, lane);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          dv[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa, pdb[ks][t2], dv[ks][i], 0, 0, 0);
-          dk[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, dsb[ks][t2], dk[ks][i], 0, 0, 0);
+          dv[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa, pdb[ks], dv[ks][i], 0, 0, 0);
+          dk[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, dsb[ks], dk[ks][i], 0, 0, 0);
         }
       }
+    }
   }
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
