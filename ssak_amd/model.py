@@ -84,7 +84,8 @@ class Wav2Vec2ForCTC:
     @staticmethod
     def _c_config(config, freeze_feature_encoder):
         c = hip.W2V2Config()
-        c.vocab_size, c.hidden_size, c.num_layers = config.vocab_size, config.hidden_size, config.num_hidden_layers
+        c.vocab_size = (config.vocab_size + 7) // 8 * 8  # engine wants a multiple of 8; see _pad_vocab
+        c.hidden_size, c.num_layers = config.hidden_size, config.num_hidden_layers
         c.num_heads, c.intermediate_size = config.num_attention_heads, config.intermediate_size
         c.num_conv_layers = len(config.conv_dim)
         for i, (d, k, s) in enumerate(zip(config.conv_dim, config.conv_kernel, config.conv_stride)):
@@ -145,9 +146,25 @@ class Wav2Vec2ForCTC:
         return self.grads[off:off + n].view(shape)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
-        return {n: self.param(n).detach().cpu().clone() for n in self.layout}
+        V = self.config.vocab_size
+        return {n: (self.param(n)[:V] if n in self._HEAD else self.param(n)).detach().cpu().clone() for n in self.layout}
+
+    _HEAD = ("lm_head.weight", "lm_head.bias")
+    _PAD_BIAS = -1.0e4  # padded vocabulary entries: probability exp(-1e4) = 0, hence exactly zero gradient
+
+    def _pad_vocab(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        """Real tokenizers rarely have a multiple of 8 symbols: the head is padded with inert classes."""
+        V, Vp = self.config.vocab_size, self.layout[name][2][0]
+        if name not in self._HEAD or t.shape[0] == Vp:
+            return t
+        if t.shape[0] != V:
+            return t  # size mismatch is reported by the caller
+        pad_shape = (Vp - V,) + tuple(t.shape[1:])
+        fill = 0.0 if name.endswith("weight") else self._PAD_BIAS
+        return torch.cat([t, torch.full(pad_shape, fill, dtype=t.dtype)], dim=0)
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        sd = {n: (self._pad_vocab(n, torch.as_tensor(t)) if n in self.layout else t) for n, t in sd.items()}
         missing = [n for n in self.layout if n not in sd]
         extra = [n for n in sd if n not in self.layout]
         if strict and (missing or extra):
@@ -246,7 +263,8 @@ class Wav2Vec2ForCTC:
         if layer_keep is not None:
             keep_arr = (C.c_uint8 * cfg.num_hidden_layers)(*[int(bool(k)) for k in layer_keep])
         self._step_seed = (int(self._step_seed) * 6364136223846793005 + 1442695040888963407) % (1 << 64)
-        logits = torch.empty((B, F, cfg.vocab_size), dtype=torch.float32, device=self.device)
+        Vp = self._c.vocab_size
+        logits = torch.empty((B, F, Vp), dtype=torch.float32, device=self.device)
         flens = torch.empty(B, dtype=torch.int32, device=self.device) if lens_dev is not None else None
         with torch.cuda.device(self.device):
             hip.check(hip.lib.ssak_w2v2_forward(self._h, hip.ptr(x), hip.ptr(lens_dev), B, T, hip.ptr(mask_dev), keep_arr,
@@ -257,6 +275,8 @@ class Wav2Vec2ForCTC:
                 loss, nll, dlogits = hip.ctc_loss(logits, flens, labels, cfg.pad_token_id, cfg.ctc_loss_reduction,
                                                   cfg.ctc_zero_infinity, 1.0, want_grad=training)
         self._last = (dlogits, mask_dev, lens_dev, x) if training else None
+        if Vp != cfg.vocab_size:
+            logits = logits[..., :cfg.vocab_size]  # view: the inert padding classes are not part of the contract
         return CTCOutput(loss, logits, nll, flens)
 
     def backward(self, grad_scale: float = 1.0):

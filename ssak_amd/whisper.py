@@ -57,6 +57,8 @@ class WhisperCTCConfig:
 
 
 class WhisperEncoderForCTC(Wav2Vec2ForCTC):
+    _HEAD = ("ctc_head.weight", "ctc_head.bias")
+
     """``model(input_features [B, 80, 2*frames], labels=...)`` -> ``.loss`` / ``.logits [B, frames, V]``."""
 
     def __init__(self, config: WhisperCTCConfig, device: str = "cuda:0", seed: int = 69):
@@ -68,7 +70,8 @@ class WhisperEncoderForCTC(Wav2Vec2ForCTC):
         self.freeze = True
         c = hip.W2V2Config()
         c.arch = 1
-        c.vocab_size, c.hidden_size, c.num_layers = config.vocab_size, config.d_model, config.encoder_layers
+        c.vocab_size = (config.vocab_size + 7) // 8 * 8
+        c.hidden_size, c.num_layers = config.d_model, config.encoder_layers
         c.num_heads, c.intermediate_size = config.encoder_attention_heads, config.encoder_ffn_dim
         c.num_mel_bins, c.max_source_positions = config.num_mel_bins, config.max_source_positions
         c.layer_norm_eps = 1e-5
