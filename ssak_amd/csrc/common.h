@@ -90,25 +90,38 @@ __device__ __forceinline__ float erf_fast(float x) {
 // exact-form (erf) GELU, the activation of both the conv feature encoder and the FFN
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  // d/dx [x Phi(x)] = Phi(x) + x phi(x); erf(x/sqrt2) and phi(x) share e = exp(-x^2/2)
+  const float e = __expf(-0.5f * x * x);
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erfv = copysignf(1.f - p * t * e, x);
+  return 0.5f * (1.f + erfv) + x * 0.39894228040143268f * e;
 }
-// counter-based RNG for dropout masks: the forward and backward kernels recompute the same bit
-// from (seed, stream, element index); no mask tensor is stored.  32-bit multiply-xorshift mixing (3 multiplies).
+// counter-based RNG for dropout masks: the forward and backward kernels recompute the same bits from
+// (seed, stream, element index); no mask tensor is stored.  "lowbias32" mixer: 2 integer multiplies (v_mul_lo_u32 is
+// a slow VALU op; the GEMM epilogues and the attention kernels were VALU-bound on a 3-multiply hash).
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint32_t stream, uint64_t idx) {
-  uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (stream * 0x85EBCA77u) ^
-                 ((uint32_t)(idx >> 32) * 0xC2B2AE3Du);
-  uint32_t h = (uint32_t)idx * 0x9E3779B1u ^ key;
+  const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (stream * 0x85EBCA77u) ^
+                       ((uint32_t)(idx >> 32) * 0xC2B2AE3Du);
+  uint32_t h = (uint32_t)idx ^ key;
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
   h ^= h >> 15;
-  h *= 0x85EBCA77u;
-  h ^= h >> 13;
-  h *= 0xC2B2AE3Du;
+  h *= 0x846CA68Bu;
   h ^= h >> 16;
   return h;
 }
 __device__ __forceinline__ bool keep_bit(uint64_t seed, uint32_t stream, uint64_t idx, uint32_t thresh) {
   // keep with probability 1-p where thresh = p * 2^32 (thresh == 0 -> always keep)
   return hash_u32(seed, stream, idx) >= thresh;
+}
+// two 16-bit uniforms per hash for a pair of adjacent elements (idx even): element idx keeps iff lo16 >= t16,
+// element idx+1 iff hi16 >= t16, with t16 = round(p * 65536)
+__device__ __forceinline__ uint32_t hash_pair16(uint64_t seed, uint32_t stream, uint64_t idx_even) {
+  return hash_u32(seed, stream, idx_even >> 1);
 }
 #endif

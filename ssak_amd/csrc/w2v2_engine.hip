@@ -687,7 +687,10 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   TRY(k_layernorm_fwd(BF(p.feat), nullptr, P + e->p_fpln_w, P + e->p_fpln_b, nullptr, BF(p.ln0), FP(p.st0),
                       FP(p.st0) + M, M, C, c.layer_norm_eps, none, none, st));
   TRY(Gemm(M, H, C).a(BF(p.ln0), C).b(W + e->p_fp_w, C).c(BF(p.h0), H).with_bias(P + e->p_fp_b)
-          .drop(tr ? c.feat_proj_dropout : 0.f, DS_FEATPROJ, seed).run(st));
+          .run(st));
+    if (tr && c.feat_proj_dropout > 0.f)  // same row kernel (and mask generator) as its replay in the backward
+      TRY(k_layernorm_fwd(BF(p.h0), nullptr, nullptr, nullptr, BF(p.h0), nullptr, nullptr, nullptr, M, H, 0.f,
+                          DS(c.feat_proj_dropout, DS_FEATPROJ), none, st));
   // ---- a5: SpecAugment scatter + zeroing of padded frames
   TRY(k_specaug_fwd(BF(p.h0), spec_mask, flens, P + e->p_mse, B, F, H, st));
   // ---- a6: positional conv (grouped, weight-normed) + GELU, residual, LayerNorm, dropout
@@ -833,7 +836,10 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   announce(e->p_lm_w, (long)V * H);
   bf16* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
   bf16* gB = nullptr;
-  TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).drop(c.final_dropout, DS_FINAL, seed).run(st));
+  TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).run(st));
+  if (c.final_dropout > 0.f)  // replay the final-dropout mask with the kernel that applied it in the forward
+    TRY(k_layernorm_fwd(gA, nullptr, nullptr, nullptr, gA, nullptr, nullptr, nullptr, M, H, 0.f, DS(c.final_dropout, DS_FINAL),
+                        none, st));
   // ---- encoder layers, last to first.  gA (+gB) = gradient w.r.t. x[l+1], the layer output (post-LN) or the
   // normalised input of the next layer (stable-LN); Gres = gradient of the residual stream (stable-LN only).
   const bool stable = whisper || c.do_stable_layer_norm != 0;

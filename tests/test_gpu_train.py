@@ -129,3 +129,50 @@ def test_train_and_infer_cli_on_kaldi_folder(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = open(tmp_path / "hyp.txt").read().splitlines()
     assert len(lines) == 8 and sorted(l.split()[0] for l in lines) == [f"utt{i}" for i in range(8)]
+
+
+@pytest.mark.parametrize("topology", ["base", "xlsr"])
+def test_dropout_masks_replayed_consistently(topology):
+    """All dropout sites on (feat_proj, encoder input, attention, hidden x2, activation, final) with a fixed step seed:
+    the loss is a deterministic function of the parameters, and a step of size eps along the analytic gradient g must
+    change it by eps*|g| to first order.  A mask regenerated differently in the backward at any site shrinks the
+    measured slope by roughly the keep probability of that site; tolerance 12 %."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    kw = dict(attention_dropout=0.25, hidden_dropout=0.25, activation_dropout=0.25, feat_proj_dropout=0.25, final_dropout=0.25,
+              layerdrop=0.0, mask_time_prob=0.0)
+    if topology == "xlsr":
+        kw.update(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
+    oc = R.W2V2Config.tiny(**kw)
+    p = R.init_params(oc, 21)
+    rng = np.random.default_rng(8)
+    x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(8000).astype(np.float32) for _ in range(4)]))
+    labels = torch.tensor(R.pad_labels([list(rng.integers(1, 32, n)) for n in (6, 4, 7, 5)]))
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
+    model.load_state_dict(p)
+
+    def loss_at(with_grad=False):
+        model._step_seed = 12345  # the same masks on every call
+        out = model(x, labels=labels)
+        if with_grad:
+            model.backward()
+        return float(out.loss.item())
+
+    l0 = loss_at(True)
+    assert loss_at() == l0
+    n = model.num_trainable
+    g = model.grads[:n].clone()
+    gn = float(g.norm())
+    base = model.params[:n].clone()
+    slopes = []
+    for eps in (0.02, 0.04):
+        model.params[:n] = base + eps * g / gn
+        model.sync_weights(full=True)
+        lp = loss_at()
+        model.params[:n] = base - eps * g / gn
+        model.sync_weights(full=True)
+        lm = loss_at()
+        slopes.append((lp - lm) / (2 * eps))
+    print(topology, "analytic |g|", gn, "measured slopes", slopes)
+    assert abs(slopes[0] - gn) < 0.12 * gn and abs(slopes[1] - gn) < 0.12 * gn
