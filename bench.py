@@ -170,8 +170,15 @@ def main():
             name, launches, ms, flops = prof[0]
             ach = flops / (ms * 1e-3) / 1e12
             gemm_ms = sum(p[2] for p in prof)
+            traffic, traffic_src = None, None
+            try:  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes of the same command
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+                traffic = tj["kernels"][name.replace(", ", ", ")]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of: " + tj["command"] + ")"
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": launches // args.steps, "avg_launch_us": round(ms * 1e3 / launches, 2),
                     "all_gemm_tflops": round(sum(p[3] for p in prof) / (gemm_ms * 1e-3) / 1e12, 1),
                     "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 3),

@@ -1,0 +1,37 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` into profiles/<round>_hbm_traffic.json.
+
+Passes (separate runs, as MI355X_MICROARCH.md prescribes -- TCC has 4 slots, FETCH_SIZE needs 3 and WRITE_SIZE 2):
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline
+Units: the counters are in KB; on gfx950 FETCH_SIZE reports exactly half of the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section), so it is doubled; WRITE_SIZE is taken as is.  Per launch = sum over launches / launches."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def agg(d, cname):
+    f = sorted(glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"))[-1]
+    a = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != cname:
+            continue
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        a[k][0] += 1
+        a[k][1] += float(r["Counter_Value"])
+    return a
+
+
+fe, wr = agg("pmc_fetch", "FETCH_SIZE"), agg("pmc_write", "WRITE_SIZE")
+out = {"command": "python3 bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline", "fetch_correction": 2.0, "kernels": {}}
+for k in fe:
+    n, v = fe[k]
+    nw, vw = wr.get(k, [0, 0.0])
+    rd = 2.0 * v * 1024 / n
+    w = vw * 1024 / max(nw, 1)
+    out["kernels"][k] = {"launches": n, "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(w),
+                         "hbm_bytes_per_launch": round(rd + w)}
+json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_hbm_traffic.json", "w"), indent=1)
+print("wrote", len(out["kernels"]), "kernels")
