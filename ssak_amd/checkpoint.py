@@ -39,14 +39,14 @@ def save_pretrained(model, tokenizer: CharTokenizer, folder: str):
                    "return_attention_mask": model.config.feat_extract_norm == "layer"}, f, indent=1)
 
 
-def load_pretrained(folder: str, device: str = "cuda:0", **config_overrides):
+def load_pretrained(folder: str, device: str = "cuda:0", freeze_feature_encoder: bool = True, **config_overrides):
     """-> (model, tokenizer).  Parameters absent from the checkpoint (e.g. a resized lm_head) keep their init."""
     from .model import Wav2Vec2ForCTC
     import dataclasses
     cfg = Wav2Vec2Config.from_json_file(os.path.join(folder, "config.json"))
     cfg = dataclasses.replace(cfg, **config_overrides)
     tok = CharTokenizer.from_vocab_json(os.path.join(folder, "vocab.json"))
-    model = Wav2Vec2ForCTC(cfg, device=device)
+    model = Wav2Vec2ForCTC(cfg, device=device, freeze_feature_encoder=freeze_feature_encoder)
     sd = load_state_dict_file(folder)
     sd = {k: v for k, v in sd.items() if k in model.layout}
     model.load_state_dict(sd, strict=False)

@@ -153,6 +153,161 @@ __global__ void conv0_stats_finalize_kernel(const double* __restrict__ partial, 
   sums[(size_t)b * 2 * C + e] = s;
 }
 
+// ---- feature-encoder backward (--no_freeze, ssak/train/transformers/wav2vec_train.py:326-327 off) -------------------
+// input gradient of a channels-last Conv1d(k, s, no padding) from the column form dxcol [B, Tout, k, C]:
+//   dx[u] = sum over taps kk with (u - kk) % s == 0 and t = (u - kk) / s in [0, Tout) of dxcol[t][kk]
+__global__ void col2im_kernel(const bf16* __restrict__ dxcol, bf16* __restrict__ dx, int Tin, int Tout, int C, int k, int s,
+                              long n8) {
+  const int hc = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / hc;
+    const int c = (int)(i % hc);
+    const long b = row / Tin;
+    const int u = (int)(row % Tin);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < k; ++kk) {
+      const int d = u - kk;
+      if (d < 0 || d % s) continue;
+      const int t = d / s;
+      if (t >= Tout) continue;
+      const uint4 q = reinterpret_cast<const uint4*>(dxcol)[(((long)b * Tout + t) * k + kk) * hc + c];
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += __uint_as_float(w[j] << 16);
+        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x2 t2 = {(bf16)acc[2 * j], (bf16)acc[2 * j + 1]};
+      o[j] = __builtin_bit_cast(uint32_t, t2);
+    }
+    reinterpret_cast<uint4*>(dx)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// out[e] = sum_b slabs[b][e]   (per-utterance weight-gradient slabs -> one gradient, fixed order)
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nb, long n, float* __restrict__ out) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += slabs[(long)b * n + e];
+    out[e] = s;
+  }
+}
+
+// conv0 + GroupNorm + GELU backward, recomputing the 10-tap dot products like the forward does.
+//   PASS 0: per (b, c) partial sums of g = dy * gelu'(y) and g * xhat over this workgroup's frames
+//   PASS 1: dv = gamma * rstd * (g - mean_t(g) - xhat * mean_t(g xhat)); partial dW[c][tap] = sum_t dv * x[5t + tap]
+template <int PASS>
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const bf16* __restrict__ dy, const double* __restrict__ sums,
+                                                        const double* __restrict__ gsums, float* __restrict__ partial, int T,
+                                                        int T0, int C) {
+  constexpr int FR0 = FR_STATS, NS0 = (FR0 - 1) * ST0 + KS0;
+  __shared__ float xs[NS0];
+  extern __shared__ float red[];  // [256][NACC + 1]
+  constexpr int NACC = PASS == 0 ? 8 : 4 * KS0;
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * FR0;
+  const int nq = C >> 2, fl = 256 / nq;
+  const int q = threadIdx.x % nq, fli = threadIdx.x / nq;
+  const int nfr = min(FR0, T0 - f0);
+  const float* xb = x + (size_t)b * T;
+  for (int i = threadIdx.x; i < NS0; i += 256) {
+    const int s = f0 * ST0 + i;
+    xs[i] = (s < T) ? xb[s] : 0.f;
+  }
+  float wr[4][KS0], mu[4], rs[4], ga[4], be[4], m1[4], m2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = q * 4 + j;
+#pragma unroll
+    for (int k = 0; k < KS0; ++k) wr[j][k] = w[c * KS0 + k];
+    const double s1 = sums[((size_t)b * C + c) * 2], s2 = sums[((size_t)b * C + c) * 2 + 1];
+    const double m = s1 / T0;
+    mu[j] = (float)m;
+    rs[j] = (float)(1.0 / sqrt(fmax(s2 / T0 - m * m, 0.0) + 1e-5));
+    ga[j] = gamma[c];
+    be[j] = beta[c];
+    m1[j] = PASS == 1 ? (float)(gsums[((size_t)b * C + c) * 2] / T0) : 0.f;
+    m2[j] = PASS == 1 ? (float)(gsums[((size_t)b * C + c) * 2 + 1] / T0) : 0.f;
+  }
+  __syncthreads();
+  float acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
+  for (int f = fli; f < nfr; f += fl) {
+    float xv[KS0];
+#pragma unroll
+    for (int k = 0; k < KS0; ++k) xv[k] = xs[f * ST0 + k];
+    const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(dy + ((size_t)b * T0 + f0 + f) * C + q * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS0; ++k) v = fmaf(wr[j][k], xv[k], v);
+      const float xh = (v - mu[j]) * rs[j];
+      const float g = (float)d4[j] * gelu_grad_f(xh * ga[j] + be[j]);
+      if (PASS == 0) {
+        acc[j] += g;
+        acc[4 + j] = fmaf(g, xh, acc[4 + j]);
+      } else {
+        const float dv = ga[j] * rs[j] * (g - m1[j] - xh * m2[j]);
+#pragma unroll
+        for (int k = 0; k < KS0; ++k) acc[j * KS0 + k] = fmaf(dv, xv[k], acc[j * KS0 + k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) red[threadIdx.x * (NACC + 1) + a] = acc[a];
+  __syncthreads();
+  if (fli == 0) {
+    float* dst = partial + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)(C / 4) * NACC + (size_t)q * NACC;
+    for (int a = 0; a < NACC; ++a) {
+      float s = 0.f;
+      for (int l = 0; l < fl; ++l) s += red[(l * nq + q) * (NACC + 1) + a];
+      dst[a] = s;
+    }
+  }
+}
+
+// gsums[b][c][0|1] = sum over workgroups of the PASS-0 partials (layout [b][blk][q][8]: g for 4 channels, then g*xhat)
+__global__ void conv0_bwd_gsums_kernel(const float* __restrict__ partial, int nblk, int C, double* __restrict__ gsums) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (c, which)
+  if (e >= 2 * C) return;
+  const int b = blockIdx.y, c = e >> 1, which = e & 1;
+  const int q = c >> 2, j = c & 3;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += partial[(((size_t)b * nblk + k) * (C / 4) + q) * 8 + which * 4 + j];
+  gsums[((size_t)b * C + c) * 2 + which] = s;
+}
+// dgamma[c] += sum_b gsums[b][c][1], dbeta[c] += sum_b gsums[b][c][0]
+__global__ void conv0_bwd_affine_kernel(const double* __restrict__ gsums, int B, int C, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, bb = 0.0;
+  for (int b = 0; b < B; ++b) {
+    bb += gsums[((size_t)b * C + c) * 2];
+    a += gsums[((size_t)b * C + c) * 2 + 1];
+  }
+  dgamma[c] += (float)a;
+  dbeta[c] += (float)bb;
+}
+// dW0[c][tap] += sum over (b, workgroup) of the PASS-1 partials (layout [slab][q][4*KS0])
+__global__ void conv0_bwd_dw_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ dw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // c * KS0 + tap
+  if (e >= C * KS0) return;
+  const int c = e / KS0, tap = e % KS0;
+  const int q = c >> 2, j = c & 3;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += partial[((size_t)k * (C / 4) + q) * (4 * KS0) + j * KS0 + tap];
+  dw[e] += s;
+}
+
 __global__ void conv_w_rearrange_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Co, int Ci, int k) {
   const long n = (long)Co * Ci * k;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -309,6 +464,53 @@ int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, h
   const long rows_total = lead + (long)B * RS + K;
   const long n = rows_total * G * (H / G / 8);
   posconv_pack_kernel<<<min(4096, ssak_cdiv(n, 256)), 256, 0, st>>>(h, pg, B, F, H, G, lead, RS, rows_total);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_col2im(const bf16* dxcol, bf16* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st) {
+  SSAK_REQUIRE((C & 7) == 0, "col2im: C must be a multiple of 8");
+  const long n8 = (long)B * Tin * C / 8;
+  col2im_kernel<<<min(8192, ssak_cdiv(n8, 256)), 256, 0, st>>>(dxcol, dx, Tin, Tout, C, k, s, n8);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+int k_sum_slabs(const float* slabs, int nb, long n, float* out, hipStream_t st) {
+  sum_slabs_kernel<<<min(4096, ssak_cdiv(n, 256)), 256, 0, st>>>(slabs, nb, n, out);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+size_t k_conv0_bwd_scratch_floats(int B, int T0, int C) {
+  const size_t nblk = ssak_cdiv(T0, FR_STATS);
+  return (size_t)B * nblk * (C / 4) * (4 * KS0) + (size_t)B * C * 2 * 2 /* gsums as doubles */ + 64;
+}
+
+// dy: gradient w.r.t. the conv0 block output (post GELU) [B, T0, C] bf16; sums: the forward's [B][2C] statistics
+int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, const float* beta, const bf16* dy,
+                        const double* sums, float* scratch, float* dw, float* dgamma, float* dbeta, int B, int T, int T0, int C,
+                        hipStream_t st) {
+  SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0_bwd: C=%d must divide into 256 threads as quads", C);
+  const int nblk = ssak_cdiv(T0, FR_STATS);
+  double* gsums = reinterpret_cast<double*>(scratch);  // [B][C][2]
+  float* partial = scratch + (size_t)B * C * 2 * 2 + 16;
+  dim3 grid(nblk, B);
+  conv0_bwd_kernel<0><<<grid, 256, 256 * 9 * sizeof(float), st>>>(x, w, gamma, beta, dy, sums, nullptr, partial, T, T0, C);
+  SSAK_LAUNCH_CHECK();
+  conv0_bwd_gsums_kernel<<<dim3(ssak_cdiv(2 * C, 256), B), 256, 0, st>>>(partial, nblk, C, gsums);
+  SSAK_LAUNCH_CHECK();
+  conv0_bwd_affine_kernel<<<ssak_cdiv(C, 256), 256, 0, st>>>(gsums, B, C, dgamma, dbeta);
+  SSAK_LAUNCH_CHECK();
+  constexpr int lds1 = 256 * (4 * KS0 + 1) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)conv0_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+    attr_done = true;
+  }
+  conv0_bwd_kernel<1><<<grid, 256, lds1, st>>>(x, w, gamma, beta, dy, sums, gsums, partial, T, T0, C);
+  SSAK_LAUNCH_CHECK();
+  conv0_bwd_dw_kernel<<<ssak_cdiv(C * KS0, 256), 256, 0, st>>>(partial, B * nblk, C, dw);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

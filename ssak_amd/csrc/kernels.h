@@ -37,6 +37,12 @@ int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const fl
                     int B, int T, int T0, int C, int ksize, int stride, hipStream_t st);
 int k_conv0_bias(const float* x, const float* w, const float* bias, bf16* out, int B, int T, int T0, int C, int ksize,
                  int stride, hipStream_t st);
+int k_col2im(const bf16* dxcol, bf16* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st);
+int k_sum_slabs(const float* slabs, int nb, long n, float* out, hipStream_t st);
+size_t k_conv0_bwd_scratch_floats(int B, int T0, int C);
+int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, const float* beta, const bf16* dy,
+                        const double* sums, float* scratch, float* dw, float* dgamma, float* dbeta, int B, int T, int T0, int C,
+                        hipStream_t st);
 int k_conv_weight_rearrange(const float* w, bf16* out, int Co, int Ci, int k, hipStream_t st);
 int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, float* norms, int H, int G, int K,
                       hipStream_t st);

@@ -64,6 +64,9 @@ struct Plan {
   int Tin = 0, RS1 = 0, RS2 = 0;
   bool fused_attn = false;
   size_t delta = 0;
+  // --no_freeze: every conv activation / pre-activation is kept, plus backward temporaries
+  bool fe_train = false;
+  size_t act[8] = {0}, cpre[8] = {0}, fe_dp = 0, fe_da = 0, fe_db = 0, fe_dxcol = 0, fe_slab = 0, fe_dwr = 0, fe_c0 = 0;
   size_t melcl, h1pad, pre1, wpre2, we, dpre2pad, dxcol, dpre1pad, dwr;
   size_t slab_bytes = 0;
   size_t total = 0;
@@ -95,6 +98,7 @@ struct ssak_w2v2 {
   uint64_t seed = 0;
   const uint8_t* spec_mask = nullptr;
   const int32_t* lens = nullptr;
+  const float* last_input = nullptr;  // input_values of the last forward (conv0 backward recomputes from it)
   std::vector<int> keep;  // LayerDrop decisions of the last forward
   ssak_grad_ready_fn on_ready = nullptr;  // announces finished gradient ranges during backward (bucketed all-reduce)
   void* on_ready_user = nullptr;
@@ -298,6 +302,26 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
       p.dpre1pad = cv.take((size_t)B * p.RS1 * H * b2);
       p.dwr = cv.take((size_t)H * 3 * std::max(H, NM) * sizeof(float));
     }
+  }
+  p.fe_train = !whisper && training && !c.freeze_feature_encoder;
+  if (p.fe_train) {
+    const int nc = c.num_conv_layers;
+    size_t max_col = 0, max_w = 0;
+    for (int i = 0; i < nc; ++i) {
+      if (i < nc - 1) p.act[i] = cv.take((size_t)B * p.Tl[i] * c.conv_dim[i] * b2);
+      if (i > 0) {
+        p.cpre[i] = cv.take((size_t)B * p.Tl[i] * c.conv_dim[i] * b2);
+        max_col = std::max(max_col, (size_t)B * p.Tl[i] * c.conv_kernel[i] * c.conv_dim[i - 1]);
+        max_w = std::max(max_w, (size_t)c.conv_dim[i] * c.conv_kernel[i] * c.conv_dim[i - 1]);
+      }
+    }
+    p.fe_dp = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
+    p.fe_da = cv.take((size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
+    p.fe_db = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
+    p.fe_dxcol = cv.take(max_col * b2);
+    p.fe_slab = cv.take((size_t)B * max_w * sizeof(float));
+    p.fe_dwr = cv.take(max_w * sizeof(float));
+    p.fe_c0 = cv.take(k_conv0_bwd_scratch_floats(B, p.Tl[0], c.conv_dim[0]) * sizeof(float));
   }
   p.bufA = cv.take(whisper ? 256 : (size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
   p.bufB = cv.take(whisper ? 256 : (size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
@@ -560,6 +584,13 @@ extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
       cin = c.conv_dim[i];
     }
   }
+  if (!full && !c.freeze_feature_encoder) {  // trainable feature encoder: the conv GEMM layouts follow the optimizer
+    long cin2 = c.conv_dim[0];
+    for (int i = 1; i < c.num_conv_layers; ++i) {
+      TRY(k_conv_weight_rearrange(e->P + e->p_conv_w[i], e->conv_w[i], c.conv_dim[i], (int)cin2, c.conv_kernel[i], st));
+      cin2 = c.conv_dim[i];
+    }
+  }
   TRY(k_posconv_prepare(e->P + e->p_pc_g, e->P + e->p_pc_v, e->pc_wf, e->pc_wb, e->pc_norms, c.hidden_size,
                         c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
   return SSAK_OK;
@@ -610,6 +641,7 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   e->seed = seed;
   e->spec_mask = spec_mask;
   e->lens = lens;
+  e->last_input = input_values;
   const bool tr = training != 0;
   auto DS = [&](float prob, uint32_t stream_id) {
     DropSpec d;
@@ -657,8 +689,9 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   // ---- a3: feature encoder (frozen: forward only)
   const bool ln_fe = c.feat_extract_norm == 1;
   if (!ln_fe) {
-    TRY(k_conv0_gn_gelu(input_values, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0], BF(p.bufA),
-                        (double*)(ws + p.stats0), B, T, p.Tl[0], c.conv_dim[0], c.conv_kernel[0], c.conv_stride[0], st));
+    TRY(k_conv0_gn_gelu(input_values, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0],
+                        p.fe_train ? BF(p.act[0]) : BF(p.bufA), (double*)(ws + p.stats0), B, T, p.Tl[0], c.conv_dim[0],
+                        c.conv_kernel[0], c.conv_stride[0], st));
   } else {
     // layer-norm variant (XLSR, modeling_wav2vec2.py:275-299): conv + bias -> LayerNorm over channels -> GELU
     TRY(k_conv0_bias(input_values, P + e->p_conv_w[0], c.conv_bias ? P + e->p_conv_b[0] : nullptr, BF(p.bufA), B, T,
@@ -667,15 +700,15 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
                         B * p.Tl[0], c.conv_dim[0], 1e-5f, none, none, st, none, true));
   }
   {
-    bf16* src = BF(p.bufA);
+    bf16* src = p.fe_train ? BF(p.act[0]) : BF(p.bufA);
     for (int i = 1; i < nc; ++i) {
-      bf16* dst = (i == nc - 1) ? BF(p.feat) : ((i & 1) ? BF(p.bufB) : BF(p.bufA));
+      bf16* dst = (i == nc - 1) ? BF(p.feat) : (p.fe_train ? BF(p.act[i]) : ((i & 1) ? BF(p.bufB) : BF(p.bufA)));
       const int Ci = c.conv_dim[i - 1], Co = c.conv_dim[i], k = c.conv_kernel[i], s = c.conv_stride[i];
       Gemm g(p.Tl[i], Co, k * Ci);
       g.a(src, (long)s * Ci).b(e->conv_w[i], (long)k * Ci).c(dst, Co)
           .batch(B, 1, (long)p.Tl[i - 1] * Ci, 0, 0, 0, (long)p.Tl[i] * Co, 0);
       if (c.conv_bias) g.with_bias(P + e->p_conv_b[i]);
-      if (!ln_fe) g.epi(SSAK_EPI_GELU);
+      if (!ln_fe) g.epi(SSAK_EPI_GELU, nullptr, p.fe_train ? BF(p.cpre[i]) : nullptr);
       TRY(g.run(st));
       if (ln_fe)
         TRY(k_layernorm_fwd(dst, nullptr, P + e->p_cln_w[i], P + e->p_cln_b[i], nullptr, dst, nullptr, nullptr, B * p.Tl[i], Co,
@@ -793,7 +826,8 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     return SSAK_ERR_STATE;
   }
   SSAK_REQUIRE(e->G, "w2v2_backward: no gradient buffer bound");
-  SSAK_REQUIRE(e->cfg.arch == 1 || e->cfg.freeze_feature_encoder, "w2v2_backward: feature-encoder gradients (--no_freeze) are not built in this round");
+  SSAK_REQUIRE(e->cfg.arch == 1 || e->cfg.freeze_feature_encoder || e->cfg.feat_extract_norm == 0,
+               "w2v2_backward: --no_freeze is built for the group-norm (base) feature encoder only");
   Plan& p = e->plan;
   SSAK_REQUIRE(workspace_bytes >= p.total, "w2v2_backward: workspace too small");
   const ssak_w2v2_config& c = e->cfg;
@@ -822,7 +856,8 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   void* slab = ws + p.slab;
   const float scale = 1.f / sqrtf((float)hd);
 
-  SSAK_HIP(hipMemsetAsync(Gd, 0, (size_t)e->n_train * sizeof(float), st));
+  const long n_grad = (e->cfg.arch == 1 || e->cfg.freeze_feature_encoder) ? e->n_train : e->n_total;
+  SSAK_HIP(hipMemsetAsync(Gd, 0, (size_t)n_grad * sizeof(float), st));
   // ---- lm_head
   bf16* dlog = BF(p.dlog);
   TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
@@ -1008,12 +1043,36 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(Gemm(H, C, M).a(dh0d, H, true).b(BF(p.ln0), C, true).c(Gd + e->p_fp_w, C, true).run_wgrad(st, slab, p.slab_bytes));
   TRY(k_colsum(dh0d, H, M, H, Gd + e->p_fp_b, st));
   TRY(Gemm(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
-  TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, BF(p.ln0), nullptr,
+  bf16* dfeat = p.fe_train ? (((nc - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da)) : BF(p.ln0);  // frozen: scratch, never read
+  TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, dfeat, nullptr,
                       Gd + e->p_fpln_w, Gd + e->p_fpln_b, FP(p.lnpart), M, C, none, none, st));
+  if (p.fe_train) {
+    // ---- a3 backward (--no_freeze): conv stack in reverse.  Per layer: GELU', weight gradient as per-utterance
+    // K-major GEMMs on the overlapping-row operand (slabs summed in a fixed order), input gradient in column form
+    // (one GEMM) + col2im; finally conv0 + GroupNorm + GELU backward by recomputation from the waveform.
+    for (int i = nc - 1; i >= 1; --i) {
+      const int Ci = c.conv_dim[i - 1], Co = c.conv_dim[i], k = c.conv_kernel[i], s = c.conv_stride[i];
+      const int Ti = p.Tl[i], Tp = p.Tl[i - 1];
+      const bf16* dact = (i & 1) ? BF(p.fe_db) : BF(p.fe_da);
+      bf16* dprev = ((i - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da);
+      const bf16* act_prev = BF(p.act[i - 1]);
+      TRY(k_gelu_grad_mul(dact, BF(p.cpre[i]), BF(p.fe_dp), (long)B * Ti * Co, st));
+      TRY(Gemm(Co, k * Ci, Ti).a(BF(p.fe_dp), Co, true).b(act_prev, (long)s * Ci, true).c(FP(p.fe_slab), (long)k * Ci, true)
+              .batch(B, 1, (long)Ti * Co, 0, (long)Tp * Ci, 0, (long)Co * k * Ci, 0).run(st));
+      TRY(k_sum_slabs(FP(p.fe_slab), B, (long)Co * k * Ci, FP(p.fe_dwr), st));
+      TRY(k_conv_wgrad_unrearrange(FP(p.fe_dwr), Gd + e->p_conv_w[i], Co, Ci, k, st));
+      TRY(Gemm(Ti, k * Ci, Co).a(BF(p.fe_dp), Co).b(e->conv_w[i], (long)k * Ci, true).c(BF(p.fe_dxcol), (long)k * Ci)
+              .batch(B, 1, (long)Ti * Co, 0, 0, 0, (long)Ti * k * Ci, 0).run(st));
+      TRY(k_col2im(BF(p.fe_dxcol), dprev, B, Tp, Ti, Ci, k, s, st));
+    }
+    TRY(k_conv0_gn_gelu_bwd(e->last_input, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0], BF(p.fe_da),
+                            (const double*)(ws + p.stats0), FP(p.fe_c0), Gd + e->p_conv_w[0], Gd + e->p_cln_w[0],
+                            Gd + e->p_cln_b[0], B, p.T, p.Tl[0], c.conv_dim[0], st));
+  }
   }
   // everything else: the leading small matrices and the whole vector region (biases, LayerNorm affine)
   announce(0, e->lp[0].wqkv);
-  announce(e->p_lm_w + (long)V * H, e->n_train - (e->p_lm_w + (long)V * H));
+  announce(e->p_lm_w + (long)V * H, n_grad - (e->p_lm_w + (long)V * H));
   e->have_fwd = false;
   return SSAK_OK;
 }

@@ -274,7 +274,7 @@ class Wav2Vec2ForCTC:
             if labels is not None:
                 loss, nll, dlogits = hip.ctc_loss(logits, flens, labels, cfg.pad_token_id, cfg.ctc_loss_reduction,
                                                   cfg.ctc_zero_infinity, 1.0, want_grad=training)
-        self._last = (dlogits, mask_dev, lens_dev, x) if training else None
+        self._last = (dlogits, mask_dev, lens_dev, x) if training else None  # x stays alive: conv0's backward re-reads it
         if Vp != cfg.vocab_size:
             logits = logits[..., :cfg.vocab_size]  # view: the inert padding classes are not part of the contract
         return CTCOutput(loss, logits, nll, flens)

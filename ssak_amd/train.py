@@ -140,12 +140,11 @@ def main(argv=None):
         train_u, valid_u = train_u[:64], valid_u[:16]
     name = "hf_" + hashmd5([u.path for u in train_u])[:8] + "_" + args_to_str(args)
     out_dir = os.path.join(args.output_dir, name)
-    model, tok = load_pretrained(args.base_model, device=dev, attention_dropout=args.attention_dropout,
+    model, tok = load_pretrained(args.base_model, device=dev, freeze_feature_encoder=not args.no_freeze,
+                                 attention_dropout=args.attention_dropout,
                                  hidden_dropout=args.hidden_dropout, feat_proj_dropout=args.feat_proj_dropout,
                                  mask_time_prob=args.mask_time_prob, layerdrop=args.layer_dropout,
                                  ctc_loss_reduction="mean", ctc_zero_infinity=True, pad_token_id=tok_pad(args.base_model))
-    if args.no_freeze:
-        raise NotImplementedError("--no_freeze: feature-encoder gradients are not built yet")
     model.train()
     tw, tl = prepare(train_u, tok)
     vw, vl = prepare(valid_u, tok)

@@ -268,3 +268,31 @@ def test_whisper_encoder_ctc_vs_hf(gold):
     worst = _check_grads(model, grads, 6e-2)
     print("whisper tiny worst grad", worst)
     assert float(model.grad("encoder.layers.0.self_attn.k_proj.bias").abs().max()) == 0.0
+
+
+def test_no_freeze_feature_encoder_gradients(mods):
+    """--no_freeze (ssak/train/transformers/wav2vec_train.py:326-327 off): gradients of the conv feature encoder
+    (conv weights, GroupNorm affine) against the oracle's autograd; tiny dims, 1599 conv0 frames per utterance."""
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    oc = R.W2V2Config.tiny().deterministic()
+    p = R.init_params(oc, 17)
+    rng = np.random.default_rng(6)
+    x = R.zero_mean_unit_var_norm([rng.standard_normal(8000).astype(np.float32) for _ in range(3)])
+    labels = R.pad_labels([list(rng.integers(1, 32, n)) for n in (8, 3, 6)])
+    loss, logits, grads = R.loss_and_grads(p, oc, torch.tensor(x), None, torch.tensor(labels), freeze_feature_encoder=False)
+    model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc), freeze_feature_encoder=False).train()
+    model.load_state_dict(p)
+    assert model.num_trainable == model.num_params
+    out = model(torch.tensor(x), labels=torch.tensor(labels))
+    assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
+    model.backward()
+    fe = {n: g.numpy() for n, g in grads.items() if n.startswith("wav2vec2.feature_extractor.")}
+    assert len(fe) == 9
+    worst = _check_grads(model, fe, 8e-2)
+    print("no_freeze worst FE grad", worst)
+    _check_grads(model, {n: g.numpy() for n, g in grads.items() if not n.startswith("wav2vec2.feature_extractor.")}, 6e-2)
+    # and the optimizer moves the conv weights (their GEMM layouts are refreshed after the step)
+    from ssak_amd.trainer import AdamW
+    w_before = model.param("wav2vec2.feature_extractor.conv_layers.3.conv.weight").clone()
+    AdamW(model, lr=1e-3, warmup_steps=0).step()
+    assert (model.param("wav2vec2.feature_extractor.conv_layers.3.conv.weight") - w_before).abs().max().item() > 0
