@@ -15,6 +15,7 @@
 // contiguous run of tiles sharing the same A row panel.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -423,9 +424,15 @@ __device__ __forceinline__ int km_swz(int kr) {
   return ((((kr >> 3) & 1) << 1) | ((kr >> 1) & 1)) << 1;  // R == 64: two k-rows share a 256-B bank row
 }
 
-template <int R, bool KM>
+// K-contiguous tile swizzle (XOR on the 16-byte chunk index of row r): 128-byte rows (BKT 64) / 64-byte rows (BKT 32)
+template <int BKT>
+__device__ __forceinline__ int kc_swz(int r) {
+  return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 2);  // both conflict-free for ds_read_b128 (searched exhaustively)
+}
+
+template <int R, bool KM, int BKT>
 struct DmaStager {
-  static constexpr int NINST = R / 32;  // 1-KiB wave-instructions per wave per tile (tile = R*128 bytes, 4 waves)
+  static constexpr int NINST = R * BKT / 2048;  // 1-KiB wave-instructions per wave per tile (tile = R*BKT*2 bytes, 4 waves)
   static constexpr uint32_t OOB = 0x80000000u;
   __amdgpu_buffer_rsrc_t rsrc;
   uint32_t off[NINST];   // byte offset of this lane's chunk in the current k-tile (OOB if its row is outside)
@@ -438,13 +445,14 @@ struct DmaStager {
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)extent_bytes, 0x00020000);
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    kstep = (uint32_t)((KM ? (long)BK * ld : (long)BK) * 2);
+    kstep = (uint32_t)((KM ? (long)BKT * ld : (long)BKT) * 2);
 #pragma unroll
     for (int j = 0; j < NINST; ++j) {
       const int S = (wave * NINST + j) * 64 + lane;
       if (!KM) {
-        const int r = S >> 3, pc = S & 7;
-        const int c = pc ^ ((r >> 1) & 7);
+        constexpr int CPK = BKT / 8;  // chunks per row
+        const int r = S / CPK, pc = S % CPK;
+        const int c = pc ^ kc_swz<BKT>(r);
         const int gr = row0 + r;
         kofs[j] = c * 8;
         off[j] = gr < rows_total ? (uint32_t)(((long)gr * ld + c * 8) * 2) : OOB;
@@ -460,8 +468,8 @@ struct DmaStager {
     }
   }
   __device__ __forceinline__ void issue(char* lds_tile, int kt, int K) {
-    const int k0 = kt * BK;
-    const bool full = k0 + BK <= K;  // uniform
+    const int k0 = kt * BKT;
+    const bool full = k0 + BKT <= K;  // uniform
 #pragma unroll
     for (int j = 0; j < NINST; ++j) {
       uint32_t o = off[j];
@@ -473,13 +481,13 @@ struct DmaStager {
 };
 
 // per-lane fragment offsets for the DMA tile images
-template <int R, bool KM, int NF>
+template <int R, bool KM, int NF, int BKT>
 struct DmaFrag {
   int off[KM ? NF : 1];
   __device__ __forceinline__ void init(int w0, int lane) {
     if (!KM) {
       const int r = w0 + (lane & 15);
-      off[0] = r * 128 + (((lane >> 4) ^ ((r >> 1) & 7)) << 4);
+      off[0] = r * (BKT * 2) + (((lane >> 4) ^ kc_swz<BKT>(r)) << 4);
     } else {
       const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
       const int kr = 8 * g + q;
@@ -492,7 +500,7 @@ struct DmaFrag {
   }
   __device__ __forceinline__ bf16x8 read(const char* lds, int i, int kk) const {
     if (!KM) {
-      return *reinterpret_cast<const bf16x8*>(lds + ((off[0] ^ (kk << 6)) + i * 2048));
+      return *reinterpret_cast<const bf16x8*>(lds + ((off[0] ^ (kk << 6)) + i * (16 * BKT * 2)));
     } else {
       typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
       const char* a = lds + off[KM ? i : 0] + kk * 32 * (2 * R);
@@ -505,12 +513,12 @@ struct DmaFrag {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int BKT>
 __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 16, NI = TN / 16;
-  constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+  constexpr int ABYTES = BM * BKT * 2, BBYTES = BN * BKT * 2, STAGE = ABYTES + BBYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -524,9 +532,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) 
   const bf16* Ab = p.A + z1 * p.sa1 + z2 * p.sa2;
   const bf16* Bb = p.B + z1 * p.sb1 + z2 * p.sb2;
   const int bm0 = tm * BM, bn0 = tn * BN;
-  const int nkt = (p.K + BK - 1) / BK;
-  const int kt0 = split * p.kt_per_split;
-  const int kt1 = min(nkt, kt0 + p.kt_per_split);
+  const int nkt = (p.K + BKT - 1) / BKT;
+  const int kps = p.kt_per_split * (BK / BKT);  // host sizes splits in 64-deep steps
+  const int kt0 = split * kps;
+  const int kt1 = min(nkt, kt0 + kps);
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -536,12 +545,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) 
   BiasRegs<NI> bias_regs;
   load_bias<NI>(p, bn0, wn0, lane, z2, bias_regs);
 
-  DmaStager<BM, A_KM> sa;
-  DmaStager<BN, B_KM> sb;
+  DmaStager<BM, A_KM, BKT> sa;
+  DmaStager<BN, B_KM, BKT> sb;
   sa.init(Ab, p.lda, bm0, p.M, p.K, kt0, p.ext_a);
   sb.init(Bb, p.ldb, bn0, p.N, p.K, kt0, p.ext_b);
-  DmaFrag<BM, A_KM, MI> fra;
-  DmaFrag<BN, B_KM, NI> frb;
+  DmaFrag<BM, A_KM, MI, BKT> fra;
+  DmaFrag<BN, B_KM, NI, BKT> frb;
   fra.init(wm0, lane);
   frb.init(wn0, lane);
 
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) 
     const char* la = smem + cur * STAGE;
     const char* lb = la + ABYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BKT / 32; ++kk) {
       bf16x8 fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = fra.read(la, i, kk);
@@ -768,6 +777,137 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma3_kernel(const GemmParam
   gemm_epilogue<MI, NI>(p, acc, bias_regs, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
 }
 
+// =================================================================================================
+// Persistent three-stage LDS-DMA GEMM.  One workgroup (8 waves) per CU walks tiles t = blockIdx.x, + gridDim.x, ...;
+// the LDS ring (3 stages) is fed by ONE continuous stream of (tile, k-step) elements, two elements ahead of the
+// MFMAs, so the DMA of the next tile's first k-steps is already in flight while the current tile finishes and stores
+// its result: the per-tile prologue latency (~2 us of a ~8 us tile at K = 768) is paid once per workgroup instead of
+// once per tile, and tail quantisation shrinks (tiles are dealt round-robin to 256 resident workgroups).
+// vmcnt bookkeeping: every stream element is exactly NPT DMA instructions of this wave (out-of-range "dummy"
+// elements past the end of the stream write zeros); `s_waitcnt vmcnt(NPT)` before the barrier therefore retires the
+// element about to be multiplied whatever younger stores the previous tile's epilogue added.
+struct TileCursor {
+  const bf16* Ab;
+  const bf16* Bb;
+  int bm0, bn0, kt0, kt1, z, z1, z2, split;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ TileCursor decode_tile(const GemmParams& p, int t) {
+  TileCursor c;
+  const int per_z = p.tiles_m * p.tiles_n;
+  const int zs = t / per_z, rem = t % per_z;
+  const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
+  c.split = zs % p.split_k;
+  c.z = zs / p.split_k;
+  c.z1 = c.z / p.nb2;
+  c.z2 = c.z % p.nb2;
+  c.Ab = p.A + c.z1 * p.sa1 + c.z2 * p.sa2;
+  c.Bb = p.B + c.z1 * p.sb1 + c.z2 * p.sb2;
+  c.bm0 = tm * BM;
+  c.bn0 = tn * BN;
+  const int nkt = (p.K + BK - 1) / BK;
+  c.kt0 = c.split * p.kt_per_split;
+  c.kt1 = min(nkt, c.kt0 + p.kt_per_split);
+  return c;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_pers_kernel(const GemmParams p, int total_tiles) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
+  using SA = DmaStagerW<BM, A_KM, NW>;
+  using SB = DmaStagerW<BN, B_KM, NW>;
+  constexpr int NPT = SA::NINST + SB::NINST;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
+  DmaFragW<BM, A_KM, MI> fra;
+  DmaFragW<BN, B_KM, NI> frb;
+  fra.init(wm0, lane);
+  frb.init(wn0, lane);
+
+  // ---- issue cursor: walks the (tile, k-step) stream two elements ahead
+  SA sa;
+  SB sb;
+  int t_i = blockIdx.x, kt_i = 0, kt1_i = 0;
+  auto open_issue_tile = [&]() {
+    while (t_i < total_tiles) {
+      const TileCursor c = decode_tile<BM, BN>(p, t_i);
+      if (c.kt0 < c.kt1) {
+        sa.init(c.Ab, p.lda, c.bm0, p.M, c.kt0, p.ext_a);
+        sb.init(c.Bb, p.ldb, c.bn0, p.N, c.kt0, p.ext_b);
+        kt_i = c.kt0;
+        kt1_i = c.kt1;
+        return;
+      }
+      t_i += gridDim.x;  // a split with no k-steps contributes an all-zero slab (handled by the compute cursor)
+    }
+  };
+  // rsrc of the stagers must be valid even when this workgroup has no element at all (dummies use it)
+  {
+    const TileCursor c0 = decode_tile<BM, BN>(p, min((int)blockIdx.x, total_tiles - 1));
+    sa.init(c0.Ab, p.lda, c0.bm0, p.M, c0.kt0, p.ext_a);
+    sb.init(c0.Bb, p.ldb, c0.bn0, p.N, c0.kt0, p.ext_b);
+  }
+  open_issue_tile();
+  auto issue_next = [&](int stage) {
+    if (t_i < total_tiles) {
+      sa.issue(smem + stage * STAGE, kt_i, p.K);
+      sb.issue(smem + stage * STAGE + ABYTES, kt_i, p.K);
+      if (++kt_i == kt1_i) {
+        t_i += gridDim.x;
+        open_issue_tile();
+      }
+    } else {
+      sa.issue_dummy(smem + stage * STAGE);
+      sb.issue_dummy(smem + stage * STAGE + ABYTES);
+    }
+  };
+  issue_next(0);
+  issue_next(1);
+
+  int stage = 0;
+  for (int t_c = blockIdx.x; t_c < total_tiles; t_c += gridDim.x) {
+    const TileCursor c = decode_tile<BM, BN>(p, t_c);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    BiasRegs<NI> bias_regs;
+    load_bias<NI>(p, c.bn0, wn0, lane, c.z2, bias_regs);
+    for (int kt = c.kt0; kt < c.kt1; ++kt) {
+      wait_vmcnt<NPT>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue_next(stage >= 1 ? stage - 1 : 2);  // (stage + 2) % 3: read in the previous iteration by every wave
+      const char* la = smem + stage * STAGE;
+      const char* lb = la + ABYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = fra.read(la, i, kk);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = frb.read(lb, j, kk);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    gemm_epilogue<MI, NI>(p, acc, bias_regs, c.bm0, c.bn0, wm0, wn0, lane, c.z, c.z1, c.z2, c.split);
+  }
+  wait_vmcnt<0>();
+}
+
 // deterministic split-K combine: C = alpha * sum_s slab[s] (+ bias) (+ C)
 __global__ void splitk_reduce_kernel(const GemmParams p) {
   const long per = (long)p.M * p.N;
@@ -815,8 +955,21 @@ const char* kLayoutNames[8] = {"128, 128, 2, 2, false, false", "128, 128, 2, 2, 
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
 int launch(const GemmParams& p, bool dma, hipStream_t st) {
+  static const bool bk32 = [] {
+    const char* v = getenv("SSAK_GEMM_BK32");
+    return v && v[0] == '1';
+  }();
+  if (dma && bk32) {
+    // 32-deep K steps: half the LDS per workgroup (32 KiB for 128x128) -> 3 workgroups per CU instead of 2, which
+    // hides more of the per-tile prologue / epilogue on the short-K (K = 768) products
+    constexpr size_t lds32 = 2 * (size_t)(BM + BN) * 64;
+    const long nb = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
+    gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM, 32><<<dim3((unsigned)nb), NTHREADS, lds32, st>>>(p);
+    SSAK_LAUNCH_CHECK();
+    return SSAK_OK;
+  }
   const size_t lds = dma ? 2 * (size_t)(BM + BN) * 128 : 2 * (size_t)(Tile<BM, A_KM>::BYTES + Tile<BN, B_KM>::BYTES);
-  auto kern = dma ? gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM> : gemm_kernel<BM, BN, WM, WN, A_KM, B_KM>;
+  auto kern = dma ? gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM, 64> : gemm_kernel<BM, BN, WM, WN, A_KM, B_KM>;
   if (lds > 64 * 1024) {
     static bool attr_done[2] = {false, false};  // per instantiation and kernel flavour
     if (!attr_done[dma]) {
@@ -867,6 +1020,42 @@ int launch_big(const GemmParams& p, hipStream_t st) {
     g_prof.push_back(rec);
   }
   return SSAK_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+int launch_pers(const GemmParams& p, int variant_base, hipStream_t st) {
+  constexpr size_t lds = 3 * (size_t)(BM + BN) * 128;
+  auto kern = gemm_pers_kernel<BM, BN, WM, WN, A_KM, B_KM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const long total = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
+  const int grid = (int)std::min<long>(total, 256);  // one resident workgroup per CU
+  ProfRec rec;
+  if (g_prof_on) {
+    rec.e0 = prof_event();
+    rec.e1 = prof_event();
+    rec.variant = variant_base + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
+    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
+    (void)hipEventRecord(rec.e0, st);
+  }
+  kern<<<dim3((unsigned)grid), 64 * WM * WN, lds, st>>>(p, (int)total);
+  SSAK_LAUNCH_CHECK();
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.e1, st);
+    g_prof.push_back(rec);
+  }
+  return SSAK_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int dispatch_pers(const GemmParams& p, int a_km, int b_km, int variant_base, hipStream_t st) {
+  if (!a_km && !b_km) return launch_pers<BM, BN, WM, WN, false, false>(p, variant_base, st);
+  if (!a_km && b_km) return launch_pers<BM, BN, WM, WN, false, true>(p, variant_base, st);
+  if (a_km && b_km) return launch_pers<BM, BN, WM, WN, true, true>(p, variant_base, st);
+  return launch_pers<BM, BN, WM, WN, true, false>(p, variant_base, st);
 }
 
 int dispatch_big(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
@@ -960,8 +1149,20 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     const char* nb = getenv("SSAK_GEMM_NO_BIG");
     return nb && nb[0] == '1';
   }();
+  static const int env_pers = [] {
+    const char* v = getenv("SSAK_GEMM_PERS");
+    return v ? atoi(v) : 0;
+  }();
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
-  if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
+  if (d->N > 64 && dma && env_pers == 1 && d->M >= 256) {
+    p.tiles_m = ssak_cdiv(d->M, 256);
+    p.tiles_n = ssak_cdiv(d->N, 128);
+    rc = dispatch_pers<256, 128, 4, 2>(p, d->a_kmajor, d->b_kmajor, 20, st);
+  } else if (d->N > 64 && dma && env_pers == 2) {
+    p.tiles_m = ssak_cdiv(d->M, 128);
+    p.tiles_n = ssak_cdiv(d->N, 128);
+    rc = dispatch_pers<128, 128, 2, 4>(p, d->a_kmajor, d->b_kmajor, 24, st);
+  } else if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
     p.tiles_m = ssak_cdiv(d->M, 256);
     p.tiles_n = ssak_cdiv(d->N, 128);
     rc = dispatch_big(p, d->a_kmajor, d->b_kmajor, st);
@@ -991,12 +1192,14 @@ extern "C" int ssak_prof_enable(int on) {
 }
 
 extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
-  SSAK_REQUIRE(out && cap >= 20, "prof_collect: need room for 20 entries");
-  for (int i = 0; i < 20; ++i) {
+  SSAK_REQUIRE(out && cap >= 28, "prof_collect: need room for 28 entries");
+  for (int i = 0; i < 28; ++i) {
     if (i < 16)
       snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
-    else
+    else if (i < 20)
       snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
+    else
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_pers_kernel<%s, %s, %s>", i < 24 ? "256, 128, 4, 2" : "128, 128, 2, 4", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
     out[i].launches = 0;
     out[i].total_ms = 0.0;
     out[i].total_flops = 0.0;
@@ -1012,5 +1215,5 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
     g_event_pool.push_back(r.e1);
   }
   g_prof.clear();
-  return 20;
+  return 28;
 }
