@@ -11,7 +11,7 @@ OBJS := $(patsubst $(CSRC)/%,$(OBJ)/%.o,$(SRCS))
 
 all: $(LIB)
 
-$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h include/ssak_hip.h
+$(OBJ)/%.hip.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_common.h $(CSRC)/kernels.h include/ssak_hip.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -19,33 +19,11 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_common.h"
+#include "kernels.h"
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int NTHREADS = 256;
-
-struct GemmParams {
-  const bf16* A;
-  const bf16* B;
-  void* C;
-  const float* bias;
-  const bf16* aux_in;
-  bf16* aux_out;
-  float* slab;
-  int M, N, K;
-  long lda, ldb, ldc;
-  int nb2;
-  long sa1, sa2, sb1, sb2, sc1, sc2;
-  float alpha;
-  int epilogue, out_f32, accumulate, split_k;
-  int tiles_m, tiles_n, nz, kt_per_split;
-  uint32_t drop_thresh, drop_stream;
-  float drop_scale;
-  uint64_t drop_seed;
-  long bias_s2;
-  uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
-};
 
 // ---- LDS tile geometry -------------------------------------------------------------------------
 // K-contiguous tile: R rows x 128 B, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7)
@@ -181,146 +159,6 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int lane_off, int i
   }
 }
 
-__device__ __forceinline__ int xcd_remap(int id, int n) {
-  // contiguous run of logical ids per XCD (hardware deals consecutive workgroup ids round-robin over 8 XCDs);
-  // bijective for any n.  Speed only.
-  const int q = n >> 3, r = n & 7;
-  const int x = id & 7, i = id >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
-// bias for this lane's NI column groups, loaded BEFORE the K loop (vector loads; the round trip then overlaps the
-// main loop instead of being exposed at the tail of every workgroup: measured 19 us of 133 on the FFN shape)
-template <int NI>
-struct BiasRegs {
-  float v[NI][4];
-};
-template <int NI>
-__device__ __forceinline__ void load_bias(const GemmParams& p, int bn0, int wn0, int lane, int z2, BiasRegs<NI>& br) {
-  const int ln = (lane >> 4) * 4;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = bn0 + wn0 + 16 * j + ln;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) br.v[j][r] = 0.f;
-    if (p.bias && p.split_k == 1 && n < p.N) {
-      const float* bp = p.bias + z2 * p.bias_s2 + n;
-      if (n + 3 < p.N && ((z2 * p.bias_s2) & 3) == 0) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(bp);
-        br.v[j][0] = t[0];
-        br.v[j][1] = t[1];
-        br.v[j][2] = t[2];
-        br.v[j][3] = t[3];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) br.v[j][r] = bp[r];
-      }
-    }
-  }
-}
-
-template <int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], const BiasRegs<NI>& br, int bm0,
-                                              int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split) {
-  // ---- epilogue: lane holds m = .. + (lane & 15), n = .. + 4 * (lane >> 4) + r, r = 0..3
-  const int lm = lane & 15, ln = (lane >> 4) * 4;
-  if (p.split_k > 1) {
-    float* S = p.slab + ((long)split * p.nz + z) * (long)p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = bm0 + wm0 + 16 * i + lm;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = bn0 + wn0 + 16 * j + ln;
-        float* dst = S + (long)m * p.N + n;
-        if (n + 3 < p.N && (p.N & 3) == 0) {
-          *reinterpret_cast<f32x4*>(dst) = acc[i][j];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) dst[r] = acc[i][j][r];
-        }
-      }
-    }
-    return;
-  }
-  const long coff = z1 * p.sc1 + z2 * p.sc2;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = bn0 + wn0 + 16 * j + ln;
-    if (n >= p.N) continue;
-    const bool full = n + 3 < p.N;
-    const float* bv = br.v[j];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = bm0 + wm0 + 16 * i + lm;
-      if (m >= p.M) continue;
-      const long o = coff + (long)m * p.ldc + n;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + bv[r];
-      if (p.epilogue == SSAK_EPI_GELU) {
-        if (p.aux_out) {
-          if (full) {
-            bf16x4 t = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(p.aux_out + o) = t;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) p.aux_out[o + r] = (bf16)v[r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-      } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
-        if (full) {
-          const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux_in + o);  // one 8-byte load instead of four 2-byte ones
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)a4[r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) v[r] *= gelu_grad_f((float)p.aux_in[o + r]);
-        }
-      }
-      if (p.drop_thresh) {
-        // o is a multiple of 4 (n = ... + 4*(lane>>4), ldc % 4 == 0): two hashes give the four 16-bit uniforms
-        const uint32_t w0 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o);
-        const uint32_t w1 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o + 2);
-        v[0] = ((w0 & 0xffffu) >= p.drop_thresh) ? v[0] * p.drop_scale : 0.f;
-        v[1] = ((w0 >> 16) >= p.drop_thresh) ? v[1] * p.drop_scale : 0.f;
-        v[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[2] * p.drop_scale : 0.f;
-        v[3] = ((w1 >> 16) >= p.drop_thresh) ? v[3] * p.drop_scale : 0.f;
-      }
-      if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.C) + o;
-        if (p.accumulate) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) dst[r] += v[r];
-        } else if (full) {
-          *reinterpret_cast<f32x4*>(dst) = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) dst[r] = v[r];
-        }
-      } else {
-        bf16* dst = reinterpret_cast<bf16*>(p.C) + o;
-        if (full) {
-          bf16x4 t = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *reinterpret_cast<bf16x4*>(dst) = t;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) dst[r] = (bf16)v[r];
-        }
-      }
-    }
-  }
-}
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
@@ -398,8 +236,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     }
     __syncthreads();
   }
-
-  gemm_epilogue<MI, NI>(p, acc, bias_regs, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
+  // every wave is past its last fragment read (the barrier above): LDS becomes the epilogue's transposition buffer
+  gemm_epilogue<MI, NI>(p, acc, bias_regs, smem + wave * (1024 * MI * NI), bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
 }
 
 // =================================================================================================
@@ -415,14 +253,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 //   K-major tile     : [64 k-rows][2R B], chunk ch of k-row kr at slot ch ^ f(kr); f spreads the 8 k-rows one
 //                      transpose-read touches over the whole 256-B bank row (conflict-free ds_read_b64_tr_b16)
 // Two stages, ONE barrier per K step: wait own DMA (vmcnt 0) -> barrier -> issue next tile's DMA -> MFMA.
-typedef __attribute__((address_space(3))) void lds_void;
-
-template <int R>
-__device__ __forceinline__ int km_swz(int kr) {
-  // XOR applied to the 16-B chunk index of k-row kr
-  if (R == 128) return (((kr >> 3) & 1) << 3) | ((kr & 3) << 1);
-  return ((((kr >> 3) & 1) << 1) | ((kr >> 1) & 1)) << 1;  // R == 64: two k-rows share a 256-B bank row
-}
 
 // K-contiguous tile swizzle (XOR on the 16-byte chunk index of row r): 128-byte rows (BKT 64) / 64-byte rows (BKT 32)
 template <int BKT>
@@ -583,7 +413,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) 
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   }
-  gemm_epilogue<MI, NI>(p, acc, bias_regs, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
+  __syncthreads();  // all fragment reads done (no DMA is outstanding): LDS becomes the epilogue's transposition buffer
+  gemm_epilogue<MI, NI>(p, acc, bias_regs, smem + wave * (1024 * MI * NI), bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
 }
 
 // =================================================================================================
@@ -679,11 +510,6 @@ struct DmaFragW {
   }
 };
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  // s_waitcnt vmcnt(N) only (lgkmcnt / expcnt untouched); gfx9 encoding: vm[3:0] | exp 7<<4 | lgkm 15<<8 | vm[5:4]<<14
-  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-}
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dma3_kernel(const GemmParams p) {
@@ -773,139 +599,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma3_kernel(const GemmParam
     }
     stage = stage == 2 ? 0 : stage + 1;
   }
-  wait_vmcnt<0>();  // drain the trailing dummy DMA before LDS is released
-  gemm_epilogue<MI, NI>(p, acc, bias_regs, bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
-}
-
-// =================================================================================================
-// Persistent three-stage LDS-DMA GEMM.  One workgroup (8 waves) per CU walks tiles t = blockIdx.x, + gridDim.x, ...;
-// the LDS ring (3 stages) is fed by ONE continuous stream of (tile, k-step) elements, two elements ahead of the
-// MFMAs, so the DMA of the next tile's first k-steps is already in flight while the current tile finishes and stores
-// its result: the per-tile prologue latency (~2 us of a ~8 us tile at K = 768) is paid once per workgroup instead of
-// once per tile, and tail quantisation shrinks (tiles are dealt round-robin to 256 resident workgroups).
-// vmcnt bookkeeping: every stream element is exactly NPT DMA instructions of this wave (out-of-range "dummy"
-// elements past the end of the stream write zeros); `s_waitcnt vmcnt(NPT)` before the barrier therefore retires the
-// element about to be multiplied whatever younger stores the previous tile's epilogue added.
-struct TileCursor {
-  const bf16* Ab;
-  const bf16* Bb;
-  int bm0, bn0, kt0, kt1, z, z1, z2, split;
-};
-
-template <int BM, int BN>
-__device__ __forceinline__ TileCursor decode_tile(const GemmParams& p, int t) {
-  TileCursor c;
-  const int per_z = p.tiles_m * p.tiles_n;
-  const int zs = t / per_z, rem = t % per_z;
-  const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
-  c.split = zs % p.split_k;
-  c.z = zs / p.split_k;
-  c.z1 = c.z / p.nb2;
-  c.z2 = c.z % p.nb2;
-  c.Ab = p.A + c.z1 * p.sa1 + c.z2 * p.sa2;
-  c.Bb = p.B + c.z1 * p.sb1 + c.z2 * p.sb2;
-  c.bm0 = tm * BM;
-  c.bn0 = tn * BN;
-  const int nkt = (p.K + BK - 1) / BK;
-  c.kt0 = c.split * p.kt_per_split;
-  c.kt1 = min(nkt, c.kt0 + p.kt_per_split);
-  return c;
-}
-
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_pers_kernel(const GemmParams p, int total_tiles) {
-  constexpr int NW = WM * WN;
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int MI = TM / 16, NI = TN / 16;
-  constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE = ABYTES + BBYTES;
-  using SA = DmaStagerW<BM, A_KM, NW>;
-  using SB = DmaStagerW<BN, B_KM, NW>;
-  constexpr int NPT = SA::NINST + SB::NINST;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
-  DmaFragW<BM, A_KM, MI> fra;
-  DmaFragW<BN, B_KM, NI> frb;
-  fra.init(wm0, lane);
-  frb.init(wn0, lane);
-
-  // ---- issue cursor: walks the (tile, k-step) stream two elements ahead
-  SA sa;
-  SB sb;
-  int t_i = blockIdx.x, kt_i = 0, kt1_i = 0;
-  auto open_issue_tile = [&]() {
-    while (t_i < total_tiles) {
-      const TileCursor c = decode_tile<BM, BN>(p, t_i);
-      if (c.kt0 < c.kt1) {
-        sa.init(c.Ab, p.lda, c.bm0, p.M, c.kt0, p.ext_a);
-        sb.init(c.Bb, p.ldb, c.bn0, p.N, c.kt0, p.ext_b);
-        kt_i = c.kt0;
-        kt1_i = c.kt1;
-        return;
-      }
-      t_i += gridDim.x;  // a split with no k-steps contributes an all-zero slab (handled by the compute cursor)
-    }
-  };
-  // rsrc of the stagers must be valid even when this workgroup has no element at all (dummies use it)
-  {
-    const TileCursor c0 = decode_tile<BM, BN>(p, min((int)blockIdx.x, total_tiles - 1));
-    sa.init(c0.Ab, p.lda, c0.bm0, p.M, c0.kt0, p.ext_a);
-    sb.init(c0.Bb, p.ldb, c0.bn0, p.N, c0.kt0, p.ext_b);
-  }
-  open_issue_tile();
-  auto issue_next = [&](int stage) {
-    if (t_i < total_tiles) {
-      sa.issue(smem + stage * STAGE, kt_i, p.K);
-      sb.issue(smem + stage * STAGE + ABYTES, kt_i, p.K);
-      if (++kt_i == kt1_i) {
-        t_i += gridDim.x;
-        open_issue_tile();
-      }
-    } else {
-      sa.issue_dummy(smem + stage * STAGE);
-      sb.issue_dummy(smem + stage * STAGE + ABYTES);
-    }
-  };
-  issue_next(0);
-  issue_next(1);
-
-  int stage = 0;
-  for (int t_c = blockIdx.x; t_c < total_tiles; t_c += gridDim.x) {
-    const TileCursor c = decode_tile<BM, BN>(p, t_c);
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    BiasRegs<NI> bias_regs;
-    load_bias<NI>(p, c.bn0, wn0, lane, c.z2, bias_regs);
-    for (int kt = c.kt0; kt < c.kt1; ++kt) {
-      wait_vmcnt<NPT>();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      issue_next(stage >= 1 ? stage - 1 : 2);  // (stage + 2) % 3: read in the previous iteration by every wave
-      const char* la = smem + stage * STAGE;
-      const char* lb = la + ABYTES;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 fa[MI], fb[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = fra.read(la, i, kk);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) fb[j] = frb.read(lb, j, kk);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      }
-      stage = stage == 2 ? 0 : stage + 1;
-    }
-    gemm_epilogue<MI, NI>(p, acc, bias_regs, c.bm0, c.bn0, wm0, wn0, lane, c.z, c.z1, c.z2, c.split);
-  }
-  wait_vmcnt<0>();
+  wait_vmcnt<0>();  // drain the trailing dummy DMA ...
+  __syncthreads();  // ... in every wave, and all fragment reads are done: LDS becomes the epilogue's transposition buffer
+  gemm_epilogue<MI, NI>(p, acc, bias_regs, smem + wave * (1024 * MI * NI), bm0, bn0, wm0, wn0, lane, z, z1, z2, split);
 }
 
 // deterministic split-K combine: C = alpha * sum_s slab[s] (+ bias) (+ C)
@@ -955,19 +651,6 @@ const char* kLayoutNames[8] = {"128, 128, 2, 2, false, false", "128, 128, 2, 2, 
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
 int launch(const GemmParams& p, bool dma, hipStream_t st) {
-  static const bool bk32 = [] {
-    const char* v = getenv("SSAK_GEMM_BK32");
-    return v && v[0] == '1';
-  }();
-  if (dma && bk32) {
-    // 32-deep K steps: half the LDS per workgroup (32 KiB for 128x128) -> 3 workgroups per CU instead of 2, which
-    // hides more of the per-tile prologue / epilogue on the short-K (K = 768) products
-    constexpr size_t lds32 = 2 * (size_t)(BM + BN) * 64;
-    const long nb = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
-    gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM, 32><<<dim3((unsigned)nb), NTHREADS, lds32, st>>>(p);
-    SSAK_LAUNCH_CHECK();
-    return SSAK_OK;
-  }
   const size_t lds = dma ? 2 * (size_t)(BM + BN) * 128 : 2 * (size_t)(Tile<BM, A_KM>::BYTES + Tile<BN, B_KM>::BYTES);
   auto kern = dma ? gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM, 64> : gemm_kernel<BM, BN, WM, WN, A_KM, B_KM>;
   if (lds > 64 * 1024) {
@@ -1020,42 +703,6 @@ int launch_big(const GemmParams& p, hipStream_t st) {
     g_prof.push_back(rec);
   }
   return SSAK_OK;
-}
-
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
-int launch_pers(const GemmParams& p, int variant_base, hipStream_t st) {
-  constexpr size_t lds = 3 * (size_t)(BM + BN) * 128;
-  auto kern = gemm_pers_kernel<BM, BN, WM, WN, A_KM, B_KM>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
-  const long total = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
-  const int grid = (int)std::min<long>(total, 256);  // one resident workgroup per CU
-  ProfRec rec;
-  if (g_prof_on) {
-    rec.e0 = prof_event();
-    rec.e1 = prof_event();
-    rec.variant = variant_base + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
-    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
-    (void)hipEventRecord(rec.e0, st);
-  }
-  kern<<<dim3((unsigned)grid), 64 * WM * WN, lds, st>>>(p, (int)total);
-  SSAK_LAUNCH_CHECK();
-  if (g_prof_on) {
-    (void)hipEventRecord(rec.e1, st);
-    g_prof.push_back(rec);
-  }
-  return SSAK_OK;
-}
-
-template <int BM, int BN, int WM, int WN>
-int dispatch_pers(const GemmParams& p, int a_km, int b_km, int variant_base, hipStream_t st) {
-  if (!a_km && !b_km) return launch_pers<BM, BN, WM, WN, false, false>(p, variant_base, st);
-  if (!a_km && b_km) return launch_pers<BM, BN, WM, WN, false, true>(p, variant_base, st);
-  if (a_km && b_km) return launch_pers<BM, BN, WM, WN, true, true>(p, variant_base, st);
-  return launch_pers<BM, BN, WM, WN, true, false>(p, variant_base, st);
 }
 
 int dispatch_big(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
@@ -1149,19 +796,32 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     const char* nb = getenv("SSAK_GEMM_NO_BIG");
     return nb && nb[0] == '1';
   }();
-  static const int env_pers = [] {
-    const char* v = getenv("SSAK_GEMM_PERS");
-    return v ? atoi(v) : 0;
+  static const int env_p8 = [] {
+    const char* v = getenv("SSAK_GEMM_P8");  // development switch: 0 = never, 1 = whenever it applies, default = heuristic
+    return v ? atoi(v) : -1;
   }();
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
-  if (d->N > 64 && dma && env_pers == 1 && d->M >= 256) {
+  // 256x256 phase-interleaved kernel: one workgroup per CU, so it wants whole rounds of 256 tiles
+  const long p8_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 256) * p.nz * split;
+  const double p8_fill = (double)p8_tiles / (double)(ssak_cdiv(p8_tiles, 256) * 256);
+  const bool p8_ok = dma && d->M >= 256 && d->N >= 256;
+  const bool p8_auto = split == 1 && d->M >= 512 && (p8_fill >= 0.72 || p8_tiles >= 1536);
+  if (p8_ok && (env_p8 == 1 || (env_p8 < 0 && p8_auto))) {
     p.tiles_m = ssak_cdiv(d->M, 256);
-    p.tiles_n = ssak_cdiv(d->N, 128);
-    rc = dispatch_pers<256, 128, 4, 2>(p, d->a_kmajor, d->b_kmajor, 20, st);
-  } else if (d->N > 64 && dma && env_pers == 2) {
-    p.tiles_m = ssak_cdiv(d->M, 128);
-    p.tiles_n = ssak_cdiv(d->N, 128);
-    rc = dispatch_pers<128, 128, 2, 4>(p, d->a_kmajor, d->b_kmajor, 24, st);
+    p.tiles_n = ssak_cdiv(d->N, 256);
+    ProfRec rec;
+    if (g_prof_on) {
+      rec.e0 = prof_event();
+      rec.e1 = prof_event();
+      rec.variant = 20 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
+      rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
+      (void)hipEventRecord(rec.e0, st);
+    }
+    rc = ssak_gemm_p8_launch(&p, d->a_kmajor, d->b_kmajor, st);
+    if (g_prof_on) {
+      (void)hipEventRecord(rec.e1, st);
+      g_prof.push_back(rec);
+    }
   } else if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
     p.tiles_m = ssak_cdiv(d->M, 256);
     p.tiles_n = ssak_cdiv(d->N, 128);
@@ -1199,7 +859,7 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
     else if (i < 20)
       snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
     else
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_pers_kernel<%s, %s, %s>", i < 24 ? "256, 128, 4, 2" : "128, 128, 2, 4", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
+      snprintf(out[i].name, sizeof(out[i].name), "%s<%s, %s>", i < 24 ? "gemm_p8_kernel" : "unused", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
     out[i].launches = 0;
     out[i].total_ms = 0.0;
     out[i].total_flops = 0.0;

@@ -1,0 +1,212 @@
+// Shared device-side pieces of the bf16 MFMA GEMM kernels (gemm.hip, gemm_p8.hip): launch parameters, XCD-aware
+// workgroup order, bias prefetch, the fused epilogue, LDS-DMA helpers.  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+
+struct GemmParams {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  const float* bias;
+  const bf16* aux_in;
+  bf16* aux_out;
+  float* slab;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int nb2;
+  long sa1, sa2, sb1, sb2, sc1, sc2;
+  float alpha;
+  int epilogue, out_f32, accumulate, split_k;
+  int tiles_m, tiles_n, nz, kt_per_split;
+  uint32_t drop_thresh, drop_stream;
+  float drop_scale;
+  uint64_t drop_seed;
+  long bias_s2;
+  uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
+};
+
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  // contiguous run of logical ids per XCD (hardware deals consecutive workgroup ids round-robin over 8 XCDs);
+  // bijective for any n.  Speed only.
+  const int q = n >> 3, r = n & 7;
+  const int x = id & 7, i = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// bias for this lane's NI column groups, loaded BEFORE the K loop (vector loads; the round trip then overlaps the
+// main loop instead of being exposed at the tail of every workgroup: measured 19 us of 133 on the FFN shape)
+template <int NI>
+struct BiasRegs {
+  float v[NI][4];
+};
+template <int NI>
+__device__ __forceinline__ void load_bias(const GemmParams& p, int bn0, int wn0, int lane, int z2, BiasRegs<NI>& br) {
+  const int ln = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = bn0 + wn0 + 16 * j + ln;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) br.v[j][r] = 0.f;
+    if (p.bias && p.split_k == 1 && n < p.N) {
+      const float* bp = p.bias + z2 * p.bias_s2 + n;
+      if (n + 3 < p.N && ((z2 * p.bias_s2) & 3) == 0) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(bp);
+        br.v[j][0] = t[0];
+        br.v[j][1] = t[1];
+        br.v[j][2] = t[2];
+        br.v[j][3] = t[3];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) br.v[j][r] = bp[r];
+      }
+    }
+  }
+}
+
+// Fused epilogue.  The MFMA leaves lane l with 4 consecutive columns of 16 DIFFERENT rows (row = .. + (l & 15)), so a
+// direct store touches 16 rows x 32 B per wave-instruction: a quarter of each 128-B line.  Measured on the 256x256
+// kernel (tools/probes/p8_probe.hip): 17-19 us to issue the stores of one tile, as long as a whole K = 768 main loop.
+// So the accumulators take one round trip through the wave's private LDS region (fp32, alpha and bias applied on the
+// way in, 16-B chunk c of row r at slot c ^ (r mod chunks-per-row): conflict-free both ways) and come back with 16
+// (8 for 32-column wave tiles) consecutive lanes covering ONE whole row segment; activation, GELU', dropout, the side
+// output and every load / store then work on full cache lines.  `lds_wave` = 1024 * MI * NI bytes private to the wave;
+// the caller guarantees nobody still reads that memory (workgroup barrier after the K loop, LDS-DMA drained).
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], const BiasRegs<NI>& br, char* lds_wave,
+                                              int bm0, int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split) {
+  constexpr int CPR = 4 * NI;      // 16-byte chunks (4 fp32) per row of the wave tile
+  constexpr int PITCH = 64 * NI;   // bytes per row
+  constexpr int RPI = 64 / CPR;    // rows covered by one wave-instruction in the row domain
+  constexpr int STEPS = 16 * MI / RPI;
+  {
+    const int lm = lane & 15, lq = lane >> 4;
+    const bool raw = p.split_k > 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = 16 * i + lm;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int chunk = 4 * j + lq;
+        f32x4 v = acc[i][j];
+        if (!raw) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + br.v[j][r];
+        }
+        *reinterpret_cast<f32x4*>(lds_wave + row * PITCH + ((chunk ^ (row & (CPR - 1))) << 4)) = v;
+      }
+    }
+  }
+  const int rr = lane / CPR, cl = lane % CPR;
+  const long coff = z1 * p.sc1 + z2 * p.sc2;
+  float* const S = p.split_k > 1 ? p.slab + ((long)split * p.nz + z) * (long)p.M * p.N : nullptr;
+  // a rolled loop on purpose: unrolled, the mode switches below were replicated STEPS times and the epilogue spent its
+  // time fetching cold instructions (measured: 18-20 us per 256x256 tile, either store pattern)
+#pragma unroll 1
+  for (int s = 0; s < STEPS; ++s) {
+    const int row = s * RPI + rr;
+    const int chunk = cl ^ (row & (CPR - 1));
+    const f32x4 t = *reinterpret_cast<const f32x4*>(lds_wave + row * PITCH + (cl << 4));
+    const int m = bm0 + wm0 + row;
+    const int n = bn0 + wn0 + 4 * chunk;
+    if (m >= p.M || n >= p.N) continue;
+    const bool full = n + 3 < p.N;
+    if (S) {  // split-K partial sums: raw accumulators into this split's slab
+      float* dst = S + (long)m * p.N + n;
+      if (full && (p.N & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = t;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) dst[r] = t[r];
+      }
+      continue;
+    }
+    const long o = coff + (long)m * p.ldc + n;
+    float v[4] = {t[0], t[1], t[2], t[3]};
+    if (p.epilogue == SSAK_EPI_GELU) {
+      if (p.aux_out) {
+        if (full) {
+          bf16x4 q = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<bf16x4*>(p.aux_out + o) = q;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) p.aux_out[o + r] = (bf16)v[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+    } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
+      if (full) {
+        const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux_in + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)a4[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) v[r] *= gelu_grad_f((float)p.aux_in[o + r]);
+      }
+    }
+    if (p.drop_thresh) {
+      // o is a multiple of 4 (n = ... + 4*chunk, ldc % 4 == 0): two hashes give the four 16-bit uniforms
+      const uint32_t w0 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o);
+      const uint32_t w1 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o + 2);
+      v[0] = ((w0 & 0xffffu) >= p.drop_thresh) ? v[0] * p.drop_scale : 0.f;
+      v[1] = ((w0 >> 16) >= p.drop_thresh) ? v[1] * p.drop_scale : 0.f;
+      v[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[2] * p.drop_scale : 0.f;
+      v[3] = ((w1 >> 16) >= p.drop_thresh) ? v[3] * p.drop_scale : 0.f;
+    }
+    if (p.out_f32) {
+      float* dst = reinterpret_cast<float*>(p.C) + o;
+      if (p.accumulate) {
+        if (full) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = (f32x4){c[0] + v[0], c[1] + v[1], c[2] + v[2], c[3] + v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) dst[r] += v[r];
+        }
+      } else if (full) {
+        *reinterpret_cast<f32x4*>(dst) = (f32x4){v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) dst[r] = v[r];
+      }
+    } else {
+      bf16* dst = reinterpret_cast<bf16*>(p.C) + o;
+      if (full) {
+        bf16x4 q = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(dst) = q;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) dst[r] = (bf16)v[r];
+      }
+    }
+  }
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int R>
+__device__ __forceinline__ int km_swz(int kr) {
+  // XOR applied to the 16-B chunk index of k-row kr
+  if (R == 128) return (((kr >> 3) & 1) << 3) | ((kr & 3) << 1);
+  return ((((kr >> 3) & 1) << 1) | ((kr >> 1) & 1)) << 1;  // R == 64: two k-rows share a 256-B bank row
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  // s_waitcnt vmcnt(N) only (lgkmcnt / expcnt untouched); gfx9 encoding: vm[3:0] | exp 7<<4 | lgkm 15<<8 | vm[5:4]<<14
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+}  // namespace
