@@ -801,13 +801,32 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     return v ? atoi(v) : -1;
   }();
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
-  // 256x256 phase-interleaved kernel: one workgroup per CU, so it wants whole rounds of 256 tiles
-  const long p8_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 256) * p.nz * split;
-  const double p8_fill = (double)p8_tiles / (double)(ssak_cdiv(p8_tiles, 256) * 256);
-  const bool p8_ok = dma && d->M >= 256 && d->N >= 256;
-  const bool p8_auto = split == 1 && d->M >= 512 && (p8_fill >= 0.72 || p8_tiles >= 1536);
+  // Phase-interleaved kernel (gemm_p8.hip): one 8-wave workgroup per CU, tile (256|192|128) x 256.  It runs whole
+  // rounds of 256 tiles, so the tile height is picked to fill the last round, and the kernel is used when a simple
+  // cost model (microseconds; constants fitted to tools/bench_gemm.py on the train-step shapes) says it wins over
+  // the 128x128 kernel (two 4-wave workgroups per CU).
+  static const int env_p8_bm = [] {
+    const char* v = getenv("SSAK_GEMM_P8_BM");
+    return v ? atoi(v) : 0;
+  }();
+  int p8_bm = 0;
+  double p8_cost = 1e30;
+  const int p8_nkt = p.kt_per_split < nkt ? p.kt_per_split : nkt;
+  for (int bm = 256; bm >= 128; bm -= 64) {
+    if (env_p8_bm && bm != env_p8_bm) continue;
+    const long tiles = (long)ssak_cdiv(d->M, bm) * ssak_cdiv(d->N, 256) * p.nz * split;
+    const double cost = (double)ssak_cdiv(tiles, 256) * (2.0 + 4.7 * bm / 256.0 + p8_nkt * (0.25 + 1.30 * bm / 256.0));
+    if (cost < p8_cost) {
+      p8_cost = cost;
+      p8_bm = bm;
+    }
+  }
+  const long def_tiles = (long)ssak_cdiv(d->M, 128) * ssak_cdiv(d->N, 128) * p.nz * split;
+  const double def_cost = (double)ssak_cdiv(def_tiles, 512) * (2.5 + p8_nkt * 1.0);
+  const bool p8_ok = dma && d->M >= 256 && d->N >= 256 && p8_bm > 0;
+  const bool p8_auto = p8_cost < 0.97 * def_cost;
   if (p8_ok && (env_p8 == 1 || (env_p8 < 0 && p8_auto))) {
-    p.tiles_m = ssak_cdiv(d->M, 256);
+    p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
     ProfRec rec;
     if (g_prof_on) {
@@ -817,7 +836,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
       rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
       (void)hipEventRecord(rec.e0, st);
     }
-    rc = ssak_gemm_p8_launch(&p, d->a_kmajor, d->b_kmajor, st);
+    rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
     if (g_prof_on) {
       (void)hipEventRecord(rec.e1, st);
       g_prof.push_back(rec);

@@ -38,8 +38,11 @@ constexpr int P8_BUF = 4 * P8_PIECE;     // AT, AB, BL, BR
 constexpr int P8_LDS = 2 * P8_BUF;       // 128 KiB
 
 // Staging state of one operand (two pieces: half 0 = AT / BL, half 1 = AB / BR).  SEG = rows of a piece taken from one
-// wave row / column (64 for A, 32 for B), SPAN = that wave row's / column's extent in the tile (128 for A, 64 for B).
-template <bool KM, int SEG, int SPAN>
+// wave row / column (16 * MH for A, 32 for B), SPAN = that wave row's / column's extent in the tile (2 * SEG), NSEG = wave
+// rows / columns (2 for A, 4 for B).
+// NV = wave-instructions (1 KiB each) a piece really has; every wave always issues two per piece (index j * 8 + wave),
+// those with index >= NV as zero-writing dummies into the slot's unused tail, so the vmcnt arithmetic never changes.
+template <bool KM, int SEG, int SPAN, int NV, int NSEG>
 struct P8Stager {
   static constexpr uint32_t OOB = 0x80000000u;
   __amdgpu_buffer_rsrc_t rsrc;
@@ -55,7 +58,8 @@ struct P8Stager {
     kstep = (uint32_t)((KM ? (long)BK * ld : (long)BK) * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int S = (wave * 2 + j) * 64 + lane;  // 16-B slot of the piece this lane fills
+      const int S = (j * 8 + wave) * 64 + lane;  // 16-B slot of the piece this lane fills
+      const bool used = j * 8 + wave < NV;
       if (!KM) {
         const int r = S >> 3, pc = S & 7;
         const int c = pc ^ ((r >> 1) & 7);
@@ -63,7 +67,7 @@ struct P8Stager {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int gr = row0 + (r / SEG) * SPAN + h * SEG + (r % SEG);
-          off[h][j] = gr < rows_total ? (uint32_t)(((long)gr * ld + c * 8) * 2 + (long)kt0 * kstep) : OOB;
+          off[h][j] = (used && gr < rows_total) ? (uint32_t)(((long)gr * ld + c * 8) * 2 + (long)kt0 * kstep) : OOB;
         }
       } else {
         const int kr = S >> 4, pc = S & 15;
@@ -73,7 +77,8 @@ struct P8Stager {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int gr = row0 + (pr / SEG) * SPAN + h * SEG + (pr % SEG);
-          off[h][j] = gr < rows_total ? (uint32_t)(((long)kr * ld + gr) * 2 + (long)kt0 * kstep) : OOB;
+          // K-major pieces keep 256-byte k-rows whatever SEG is: chunks beyond the piece's NSEG * SEG columns stay empty
+          off[h][j] = (pr < NSEG * SEG && gr < rows_total) ? (uint32_t)(((long)kr * ld + gr) * 2 + (long)kt0 * kstep) : OOB;
         }
       }
     }
@@ -86,7 +91,7 @@ struct P8Stager {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint32_t o = kofs[j] < klim ? off[H][j] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_piece + (wave * 2 + j) * 1024), 16, o, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_piece + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
       off[H][j] += kstep;  // an OOB offset stays >= 2^31 (total advance < 2 GB), i.e. out of range
     }
   }
@@ -142,21 +147,24 @@ struct P8Frag {
     __builtin_amdgcn_s_barrier();   \
     P8_FENCE();                     \
   } while (0)
-// 16 MFMAs of one output quadrant: rows I0..I0+3 (16-row groups) x column groups J0, J0+1, both 32-deep halves
+// the 4 * MH MFMAs of one output quadrant: 16-row groups I0..I0+MH-1 x column groups J0, J0+1, both 32-deep halves
 #define P8_MFMA(I0, J0, FB)                                                                                   \
   do {                                                                                                        \
     P8_BARRIER();                                                                                             \
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                            \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)            \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < MH; ++i)           \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] =                               \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(I0) + i][(J0) + j], 0, 0, 0);  \
     __builtin_amdgcn_s_setprio(0);                                                                            \
     P8_BARRIER();                                                                                             \
   } while (0)
 
-template <bool A_KM, bool B_KM>
+// MH = 16-row groups per quadrant: the tile is (64 * MH) x 256, i.e. 256 / 192 / 128 rows -- picked by the host so
+// that the tile count fills whole rounds of 256 workgroups (M = 15968: 192-row tiles give 84 x 3 = 252 tiles for N = 768).
+template <int MH, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p) {
+  constexpr int BM = 64 * MH, SEGA = 16 * MH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   P8_STAMP(0);
   const int lane = threadIdx.x & 63;
@@ -170,24 +178,24 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
   const int z1 = z / p.nb2, z2 = z % p.nb2;
   const bf16* Ab = p.A + z1 * p.sa1 + z2 * p.sa2;
   const bf16* Bb = p.B + z1 * p.sb1 + z2 * p.sb2;
-  const int bm0 = tm * 256, bn0 = tn * 256;
+  const int bm0 = tm * BM, bn0 = tn * 256;
   const int nkt = (p.K + BK - 1) / BK;
   const int kt0 = split * p.kt_per_split;
   const int kt1 = min(nkt, kt0 + p.kt_per_split);
 
-  f32x4 acc[8][4];
+  f32x4 acc[2 * MH][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * MH; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  P8Stager<A_KM, 64, 128> sa;
-  P8Stager<B_KM, 32, 64> sb;
+  P8Stager<A_KM, SEGA, 2 * SEGA, A_KM ? 16 : 4 * MH, 2> sa;
+  P8Stager<B_KM, 32, 64, 16, 4> sb;
   sa.init(Ab, p.lda, bm0, p.M, kt0, p.ext_a);
   sb.init(Bb, p.ldb, bn0, p.N, kt0, p.ext_b);
-  P8Frag<A_KM, 4> fra;
+  P8Frag<A_KM, MH> fra;
   P8Frag<B_KM, 2> frb;
-  fra.init(wr * 64, lane);
+  fra.init(wr * SEGA, lane);
   frb.init(wc * 32, lane);
 
   // piece slots of buffer b: AT = 0, AB = 1, BL = 2, BR = 3
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
   if (wr == 1) P8_BARRIER();  // wave row 1 runs one barrier behind wave row 0
   P8_STAMP(1);
 
-  bf16x8 fa[4][2], fbl[2][2], fbr[2][2];
+  bf16x8 fa[MH][2], fbl[2][2], fbr[2][2];
   for (int kt = kt0; kt < kt1; ++kt) {
     char* const cur = ((kt - kt0) & 1) ? buf1 : buf0;
     char* const nxt = ((kt - kt0) & 1) ? buf0 : buf1;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
       for (int kk = 0; kk < 2; ++kk) fbl[j][kk] = frb.read(cur + 2 * P8_PIECE, j, kk);
     P8_FENCE();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MH; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 0 * P8_PIECE, i, kk);
     P8_FENCE();
@@ -234,16 +242,16 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
     P8_MFMA(0, 2, fbr);
     // ---- P3
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MH; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 1 * P8_PIECE, i, kk);
     P8_FENCE();
     sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K);  // BL(t+2)
-    P8_MFMA(4, 2, fbr);
+    P8_MFMA(MH, 2, fbr);
     // ---- P4
     sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K);  // AT(t+2)
     wait_vmcnt<8>();                                             // BL(t+1), AT(t+1)
-    P8_MFMA(4, 0, fbl);
+    P8_MFMA(MH, 0, fbl);
   }
   if (wr == 0) P8_BARRIER();
   wait_vmcnt<0>();  // drain the trailing dummies before LDS is released
@@ -253,8 +261,8 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
   load_bias<4>(p, bn0, wc * 64, lane, z2, bias_regs);
   __syncthreads();  // DMA drained in every wave, all fragment reads done: LDS becomes the transposition buffer
   char* const lds_wave = smem + wave * 16384;
-  gemm_epilogue<4, 4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), bias_regs, lds_wave, bm0, bn0, wr * 128, wc * 64, lane, z, z1, z2, split);
-  gemm_epilogue<4, 4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), bias_regs, lds_wave, bm0, bn0, wr * 128 + 64, wc * 64, lane, z, z1, z2, split);
+  gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[0]), bias_regs, lds_wave, bm0, bn0, wr * 2 * SEGA, wc * 64, lane, z, z1, z2, split);
+  gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[MH]), bias_regs, lds_wave, bm0, bn0, wr * 2 * SEGA + SEGA, wc * 64, lane, z, z1, z2, split);
 #ifdef P8_STAMPS
   P8_STAMP(3);
   wait_vmcnt<0>();
@@ -269,9 +277,9 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
 #endif
 }
 
-template <bool A_KM, bool B_KM>
+template <int MH, bool A_KM, bool B_KM>
 int launch_p8(const GemmParams& p, hipStream_t st) {
-  auto kern = gemm_p8_kernel<A_KM, B_KM>;
+  auto kern = gemm_p8_kernel<MH, A_KM, B_KM>;
   static bool attr_done = false;
   if (!attr_done) {
     SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
@@ -283,12 +291,19 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
   return SSAK_OK;
 }
 
+template <int MH>
+int dispatch_p8(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
+  if (!a_km && !b_km) return launch_p8<MH, false, false>(p, st);
+  if (!a_km && b_km) return launch_p8<MH, false, true>(p, st);
+  if (a_km && b_km) return launch_p8<MH, true, true>(p, st);
+  return launch_p8<MH, true, false>(p, st);
+}
+
 }  // namespace
 
-int ssak_gemm_p8_launch(const void* params, int a_km, int b_km, hipStream_t st) {
+int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
-  if (!a_km && !b_km) return launch_p8<false, false>(p, st);
-  if (!a_km && b_km) return launch_p8<false, true>(p, st);
-  if (a_km && b_km) return launch_p8<true, true>(p, st);
-  return launch_p8<true, false>(p, st);
+  if (bm == 256) return dispatch_p8<4>(p, a_km, b_km, st);
+  if (bm == 192) return dispatch_p8<3>(p, a_km, b_km, st);
+  return dispatch_p8<2>(p, a_km, b_km, st);
 }

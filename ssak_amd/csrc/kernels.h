@@ -69,5 +69,6 @@ int k_sumsq(const float* g, long n, float* out /*[1], zeroed by caller*/, hipStr
 int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, const float* gnorm_sq, float max_norm,
             float grad_scale, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t st);
 
-// gemm_p8.hip: 256x256-tile phase-interleaved GEMM; `params` is gemm_common.h's GemmParams (tiles_m/tiles_n for 256x256)
-int ssak_gemm_p8_launch(const void* params, int a_km, int b_km, hipStream_t st);
+// gemm_p8.hip: (256|192|128)x256-tile phase-interleaved GEMM; `params` is gemm_common.h's GemmParams with
+// tiles_m / tiles_n counted for bm x 256 tiles
+int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st);

@@ -20,18 +20,24 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (rand() & 0xff);
   hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+#ifndef P8_MH
+#define P8_MH 4
+#endif
   GemmParams p{};
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
   p.nb2 = 1; p.alpha = 1.f; p.split_k = 1; p.nz = 1;
-  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  p.tiles_m = (M + 64 * P8_MH - 1) / (64 * P8_MH); p.tiles_n = (N + 255) / 256;
   p.kt_per_split = (K + 63) / 64;
   p.ext_a = (uint32_t)((size_t)M * K * 2); p.ext_b = (uint32_t)((size_t)N * K * 2);
   const int nblk = p.tiles_m * p.tiles_n;
   unsigned long long* st;
   hipMalloc(&st, (size_t)nblk * 64);
   p.slab = (float*)st;
-  auto kern = gemm_p8_kernel<false, false>;
+  #ifndef P8_MH
+#define P8_MH 4
+#endif
+  auto kern = gemm_p8_kernel<P8_MH, false, false>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
