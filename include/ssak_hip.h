@@ -84,7 +84,8 @@ int ssak_ctc_greedy_decode(const float* logits, const int32_t* in_lens, int B, i
  * strides s?1 / s?2 per operand.  Epilogue: bias (fp32 [N] or NULL), then `epilogue` selects
  * NONE / GELU (optionally saving the pre-activation to `aux_out`) / MUL_GELU_GRAD (C *= gelu'(aux_in)).
  * out_f32 selects fp32 vs bf16 C.  split_k > 1 needs workspace >= split_k*batch*M*N*4 bytes and is summed
- * deterministically by a second kernel. */
+ * deterministically by a second kernel; split_k = 0 lets the library size the split (<= 32, and only as far as
+ * `workspace_bytes` allows; plain epilogue only, otherwise 1) -- the weight-gradient form, long K and few tiles. */
 #define SSAK_EPI_NONE 0
 #define SSAK_EPI_GELU 1
 #define SSAK_EPI_MUL_GELU_GRAD 2

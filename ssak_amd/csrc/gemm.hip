@@ -720,6 +720,61 @@ int dispatch_layout(const GemmParams& p, int a_km, int b_km, bool dma, hipStream
   return launch<BM, BN, WM, WN, true, false>(p, dma, st);
 }
 
+
+// ---- kernel / tile / split-K selection ---------------------------------------------------------------------------
+// A small cost model in microseconds (constants fitted to tools/bench_gemm.py and tools/probes/p8_probe.hip on the
+// Wav2Vec2-base train-step shapes, MI355X): a workgroup costs a fixed prologue + epilogue plus a per-K-tile time, the
+// launch runs ceil(workgroups / resident workgroups) rounds, a split-K launch adds its slab reduction.
+//   phase-interleaved kernel (gemm_p8.hip): one 8-wave workgroup per CU, tile (256|192|128) x 256 -- the tile height is
+//     what fills the last round (M = 15968: 192-row tiles give 84 x 3 = 252 tiles for N = 768);
+//   128x128 kernel: two 4-wave workgroups per CU.
+struct GemmPlan {
+  bool p8;
+  int bm;     // p8 tile height
+  int split;
+  double cost;
+};
+int g_env_p8 = -2, g_env_p8_bm = 0;
+GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
+  if (g_env_p8 == -2) {
+    const char* v = getenv("SSAK_GEMM_P8");  // development switches: 0 = never, 1 = whenever it applies
+    g_env_p8 = v ? atoi(v) : -1;
+    v = getenv("SSAK_GEMM_P8_BM");
+    g_env_p8_bm = v ? atoi(v) : 0;
+  }
+  const int nkt = ssak_cdiv(d->K, BK);
+  const long nz = (long)d->nb1 * d->nb2;
+  const double out_mb = (double)nz * d->M * d->N * 4e-6;  // one fp32 slab, MB
+  const bool wide = d->out_f32 != 0;
+  int s_lo = d->split_k > 1 ? d->split_k : 1, s_hi = s_lo;
+  if (d->split_k == 0) {  // auto: deterministic split-K sized by the model (plain epilogue only)
+    s_lo = 1;
+    s_hi = (d->epilogue == SSAK_EPI_NONE && !(d->drop_p > 0.f)) ? std::max(1, std::min(32, nkt / 4)) : 1;
+  }
+  const bool p8_ok = dma && d->M >= 256 && d->N >= 256 && g_env_p8 != 0;
+  GemmPlan best_def{false, 0, s_lo, 1e30}, best_p8{true, 256, s_lo, 1e30};
+  for (int s = s_lo; s <= s_hi; ++s) {
+    if (d->split_k == 0 && s > 1 && (size_t)s * nz * (size_t)d->M * d->N * sizeof(float) > workspace_bytes) break;
+    const int kt = ssak_cdiv(nkt, s);
+    const bool slab = s > 1;
+    const double reduce = slab ? 2.0 + (s + 1) * out_mb / 3.5 : 0.0;
+    {
+      const long blocks = (long)ssak_cdiv(d->M, 128) * ssak_cdiv(d->N, d->N > 64 ? 128 : 64) * nz * s;
+      const double c = (double)ssak_cdiv(blocks, 512) * (2.5 + ((slab || wide) ? 2.0 : 0.0) + kt * 1.0) + reduce;
+      if (c < best_def.cost) best_def = GemmPlan{false, 0, s, c};
+    }
+    for (int bm = 256; p8_ok && bm >= 128; bm -= 64) {
+      if (g_env_p8_bm && bm != g_env_p8_bm) continue;
+      const long blocks = (long)ssak_cdiv(d->M, bm) * ssak_cdiv(d->N, 256) * nz * s;
+      const double epi = ((slab || wide) ? 9.4 : 4.7) * bm / 256.0;
+      const double c = (double)ssak_cdiv(blocks, 256) * (2.0 + epi + kt * (0.60 + 0.98 * bm / 256.0)) + reduce;
+      if (c < best_p8.cost) best_p8 = GemmPlan{true, bm, s, c};
+    }
+  }
+  if (p8_ok && best_p8.cost < 1e30 && (g_env_p8 == 1 || best_p8.cost < 0.97 * best_def.cost)) return best_p8;
+  return best_def;
+}
+
 }  // namespace
 
 extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
@@ -735,8 +790,14 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   SSAK_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2, "gemm: bad epilogue %d", d->epilogue);
   SSAK_REQUIRE(d->epilogue != SSAK_EPI_MUL_GELU_GRAD || aux_in, "gemm: MUL_GELU_GRAD needs aux_in");
   SSAK_REQUIRE(!d->accumulate || d->out_f32, "gemm: accumulate needs fp32 output");
-  const int split = d->split_k > 1 ? d->split_k : 1;
-  SSAK_REQUIRE(split == 1 || d->epilogue == SSAK_EPI_NONE, "gemm: split_k supports the plain epilogue only");
+  SSAK_REQUIRE(d->split_k >= 0, "gemm: split_k must be >= 0 (0 = choose)");
+  SSAK_REQUIRE(d->split_k <= 1 || d->epilogue == SSAK_EPI_NONE, "gemm: split_k supports the plain epilogue only");
+  // the LDS-DMA kernels cannot mask partial 16-byte chunks: they need whole chunks or zero padding in memory
+  const bool partial_a = d->a_kmajor ? (d->M & 7) : (d->K & 7);
+  const bool partial_b = d->b_kmajor ? (d->N & 7) : (d->K & 7);
+  const bool dma = d->pads_are_zero || !(partial_a || partial_b);
+  const GemmPlan plan = plan_gemm(d, dma, workspace ? workspace_bytes : 0);
+  const int split = plan.split;
   GemmParams p;
   p.A = (const bf16*)A;
   p.B = (const bf16*)B;
@@ -786,46 +847,15 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     p.ext_a = (uint32_t)(((long)ext_a + 7) / 8 * 16);
     p.ext_b = (uint32_t)(((long)ext_b + 7) / 8 * 16);
   }
-  // the LDS-DMA kernel cannot mask partial 16-byte chunks: needs whole chunks or zero padding in memory
-  const bool partial_a = d->a_kmajor ? (d->M & 7) : (d->K & 7);
-  const bool partial_b = d->b_kmajor ? (d->N & 7) : (d->K & 7);
-  const bool dma = d->pads_are_zero || !(partial_a || partial_b);
   hipStream_t st = (hipStream_t)stream;
   int rc;
   static const bool env_no_big = [] {
     const char* nb = getenv("SSAK_GEMM_NO_BIG");
     return nb && nb[0] == '1';
   }();
-  static const int env_p8 = [] {
-    const char* v = getenv("SSAK_GEMM_P8");  // development switch: 0 = never, 1 = whenever it applies, default = heuristic
-    return v ? atoi(v) : -1;
-  }();
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
-  // Phase-interleaved kernel (gemm_p8.hip): one 8-wave workgroup per CU, tile (256|192|128) x 256.  It runs whole
-  // rounds of 256 tiles, so the tile height is picked to fill the last round, and the kernel is used when a simple
-  // cost model (microseconds; constants fitted to tools/bench_gemm.py on the train-step shapes) says it wins over
-  // the 128x128 kernel (two 4-wave workgroups per CU).
-  static const int env_p8_bm = [] {
-    const char* v = getenv("SSAK_GEMM_P8_BM");
-    return v ? atoi(v) : 0;
-  }();
-  int p8_bm = 0;
-  double p8_cost = 1e30;
-  const int p8_nkt = p.kt_per_split < nkt ? p.kt_per_split : nkt;
-  for (int bm = 256; bm >= 128; bm -= 64) {
-    if (env_p8_bm && bm != env_p8_bm) continue;
-    const long tiles = (long)ssak_cdiv(d->M, bm) * ssak_cdiv(d->N, 256) * p.nz * split;
-    const double cost = (double)ssak_cdiv(tiles, 256) * (2.0 + 4.7 * bm / 256.0 + p8_nkt * (0.25 + 1.30 * bm / 256.0));
-    if (cost < p8_cost) {
-      p8_cost = cost;
-      p8_bm = bm;
-    }
-  }
-  const long def_tiles = (long)ssak_cdiv(d->M, 128) * ssak_cdiv(d->N, 128) * p.nz * split;
-  const double def_cost = (double)ssak_cdiv(def_tiles, 512) * (2.5 + p8_nkt * 1.0);
-  const bool p8_ok = dma && d->M >= 256 && d->N >= 256 && p8_bm > 0;
-  const bool p8_auto = p8_cost < 0.97 * def_cost;
-  if (p8_ok && (env_p8 == 1 || (env_p8 < 0 && p8_auto))) {
+  const int p8_bm = plan.bm;
+  if (plan.p8) {
     p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
     ProfRec rec;

@@ -148,7 +148,29 @@ struct P8Frag {
     P8_FENCE();                     \
   } while (0)
 // the 4 * MH MFMAs of one output quadrant: 16-row groups I0..I0+MH-1 x column groups J0, J0+1, both 32-deep halves
-#define P8_MFMA(I0, J0, FB)                                                                                   \
+#ifdef P8_DMA_IN_MFMA
+// variant: the phase's LDS-DMA is issued by the wave row that is multiplying, between the two 32-deep halves
+#define P8_MFMA(I0, J0, FB, DMA)                                                                              \
+  do {                                                                                                        \
+    P8_BARRIER();                                                                                             \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] =                               \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][0], fa[i][0], acc[(I0) + i][(J0) + j], 0, 0, 0);    \
+    P8_FENCE();                                                                                               \
+    DMA;                                                                                                      \
+    P8_FENCE();                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] =                               \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][1], fa[i][1], acc[(I0) + i][(J0) + j], 0, 0, 0);    \
+    __builtin_amdgcn_s_setprio(0);                                                                            \
+    P8_BARRIER();                                                                                             \
+  } while (0)
+#define P8_PRE(DMA)
+#define P8_WAIT() wait_vmcnt<6>()
+#else
+#define P8_MFMA(I0, J0, FB, DMA)                                                                              \
   do {                                                                                                        \
     P8_BARRIER();                                                                                             \
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */                                                      \
@@ -159,6 +181,9 @@ struct P8Frag {
     __builtin_amdgcn_s_setprio(0);                                                                            \
     P8_BARRIER();                                                                                             \
   } while (0)
+#define P8_PRE(DMA) DMA
+#define P8_WAIT() wait_vmcnt<8>()
+#endif
 
 // MH = 16-row groups per quadrant: the tile is (64 * MH) x 256, i.e. 256 / 192 / 128 rows -- picked by the host so
 // that the tile count fills whole rounds of 256 workgroups (M = 15968: 192-row tiles give 84 x 3 = 252 tiles for N = 768).
@@ -228,30 +253,30 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 0 * P8_PIECE, i, kk);
     P8_FENCE();
-    sb.template issue<1>(nxt + 3 * P8_PIECE, kt + 1, kt1, p.K);  // BR(t+1)
-    wait_vmcnt<8>();                                             // BR(t)
-    P8_MFMA(0, 0, fbl);
+    P8_PRE(sb.template issue<1>(nxt + 3 * P8_PIECE, kt + 1, kt1, p.K));  // BR(t+1)
+    P8_WAIT();                                                            // BR(t)
+    P8_MFMA(0, 0, fbl, sb.template issue<1>(nxt + 3 * P8_PIECE, kt + 1, kt1, p.K));
     // ---- P2
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) fbr[j][kk] = frb.read(cur + 3 * P8_PIECE, j, kk);
     P8_FENCE();
-    sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K);  // AB(t+1)
-    wait_vmcnt<8>();                                             // AB(t)
-    P8_MFMA(0, 2, fbr);
+    P8_PRE(sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K));  // AB(t+1)
+    P8_WAIT();                                                            // AB(t)
+    P8_MFMA(0, 2, fbr, sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K));
     // ---- P3
 #pragma unroll
     for (int i = 0; i < MH; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 1 * P8_PIECE, i, kk);
     P8_FENCE();
-    sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K);  // BL(t+2)
-    P8_MFMA(MH, 2, fbr);
+    P8_PRE(sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K));  // BL(t+2)
+    P8_MFMA(MH, 2, fbr, sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K));
     // ---- P4
-    sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K);  // AT(t+2)
-    wait_vmcnt<8>();                                             // BL(t+1), AT(t+1)
-    P8_MFMA(MH, 0, fbl);
+    P8_PRE(sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K));  // AT(t+2)
+    P8_WAIT();                                                            // BL(t+1), AT(t+1)
+    P8_MFMA(MH, 0, fbl, sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K));
   }
   if (wr == 0) P8_BARRIER();
   wait_vmcnt<0>();  // drain the trailing dummies before LDS is released

@@ -459,14 +459,9 @@ struct Gemm {
   int run(hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
     return ssak_gemm_bf16(&d, A, B, C, bias, aux_in, aux_out, ws, ws_bytes, (void*)st);
   }
-  // weight-gradient form: long K, few output tiles -> deterministic split-K sized to fill the chip
+  // weight-gradient form: long K, few output tiles -> deterministic split-K, sized by the library's cost model
   int run_wgrad(hipStream_t st, void* slab, size_t slab_bytes) {
-    const long tiles = (long)ssak_cdiv(d.M, 128) * ssak_cdiv(d.N, d.N > 64 ? 128 : 64) * d.nb1 * d.nb2;
-    const int nkt = ssak_cdiv(d.K, 64);
-    int split = (int)std::min<long>(32, std::max<long>(1, (768 + tiles - 1) / tiles));
-    split = std::max(1, std::min(split, nkt / 4));
-    while (split > 1 && (size_t)split * d.nb1 * d.nb2 * (size_t)d.M * d.N * sizeof(float) > slab_bytes) --split;
-    d.split_k = split;
+    d.split_k = 0;
     return run(st, slab, slab_bytes);
   }
 };

@@ -198,7 +198,8 @@ def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
                  sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k, float(drop_p),
                  drop_stream, drop_seed, 0, int(pads_are_zero))
-    ws = _ws(split_k * nb1 * nb2 * M * N * 4, A.device) if split_k > 1 else None
+    n_slabs = split_k if split_k > 0 else max(1, min(32, ((K + 63) // 64) // 4))  # 0 = library-sized split
+    ws = _ws(n_slabs * nb1 * nb2 * M * N * 4, A.device) if n_slabs > 1 else None
     check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
                              0 if ws is None else ws.numel(), stream()))
     return C_out

@@ -29,9 +29,11 @@ bench("ffn1", M, 3072, 768)
 bench("ffn2", M, 768, 3072)
 bench("dx ffn2 (NN)", M, 3072, 768, b_km=True)
 bench("dx ffn1 (NN)", M, 768, 3072, b_km=True)
-for sk in (1, 2, 4, 8):
+for sk in (0, 1, 2, 4, 8):
     bench("dW ffn (TN)", 3072, 768, M, a_km=True, b_km=True, split_k=sk, out=torch.float32)
-for sk in (1, 4, 8, 16):
+bench("dW ffn2 (TN)", 768, 3072, M, a_km=True, b_km=True, split_k=0, out=torch.float32)
+bench("dW qkv (TN)", 2304, 768, M, a_km=True, b_km=True, split_k=0, out=torch.float32)
+for sk in (0, 4, 8, 16):
     bench("dW proj (TN)", 768, 768, M, a_km=True, b_km=True, split_k=sk, out=torch.float32)
 bench("conv1 per-utt", 15999, 512, 1536, nb=B)
 bench("conv3 per-utt", 3999, 512, 1536, nb=B)
