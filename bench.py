@@ -94,11 +94,18 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched under torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # rehearsal switches for a one-GPU box (never set by the driver): all ranks on one card, gloo instead of RCCL
+    if os.environ.get("SSAK_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("SSAK_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from ssak_amd import hip
     from ssak_amd.config import Wav2Vec2Config

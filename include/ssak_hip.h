@@ -121,7 +121,7 @@ typedef struct {
   double total_flops;
 } ssak_prof_entry;
 int ssak_prof_enable(int on);
-int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 28; returns the number of entries (28) */
+int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 32; returns the number of entries (32) */
 
 /* ---- a7 (part): fused self-attention, head_dim 64 --------------------------------------------
  * Replaces Wav2Vec2Attention's softmax(QK^T d^-0.5 + key mask) -> dropout -> .V and its autograd

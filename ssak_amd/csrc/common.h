@@ -87,20 +87,37 @@ __device__ __forceinline__ float erf_fast(float x) {
   const float r = 1.f - p * t * __expf(-ax * ax);
   return copysignf(r, x);
 }
-// exact-form (erf) GELU, the activation of both the conv feature encoder and the FFN
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  // d/dx [x Phi(x)] = Phi(x) + x phi(x); erf(x/sqrt2) and phi(x) share e = exp(-x^2/2)
-  const float e = __expf(-0.5f * x * x);
-  const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float erfv = copysignf(1.f - p * t * e, x);
-  return 0.5f * (1.f + erfv) + x * 0.39894228040143268f * e;
+// GELU (erf form, the activation of the conv feature encoder and of the FFN): x * Phi(x) with the normal CDF written as
+// a logistic function of an odd polynomial, Phi(x) = 1 / (1 + exp2(q(x))), q(x) = -log2(e) * x (c0 + c1 x^2 + c2 x^4 +
+// c3 x^6), x clamped to [-6, 6].  Coefficients fitted to logit(Phi) for max |Phi error| = 1.6e-5 (fp32 evaluation
+// included; bf16 resolution is 3.9e-3), i.e. the same function as the reference's exact GELU at every precision this
+// engine stores.  7 VALU + exp + rcp per element instead of 15 + 2 for the Abramowitz-Stegun erf: the GELU / GELU'
+// GEMM epilogues were VALU-bound (tools/probes/p8_probe.hip: 18 us of epilogue after a 19 us K = 768 main loop).  The
+// two-element forms keep everything but the transcendentals in packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define SSAK_PHI_C0 (-2.302147388458252f)
+#define SSAK_PHI_C1 (-0.10512793809175491f)
+#define SSAK_PHI_C2 (0.00039503577863797545f)
+#define SSAK_PHI_C3 (5.9617443184833974e-05f)
+__device__ __forceinline__ f32x2 phi2(f32x2 x) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -6.f, 6.f), __builtin_amdgcn_fmed3f(x[1], -6.f, 6.f)};
+  const f32x2 s = xc * xc;
+  f32x2 q = __builtin_elementwise_fma(s, (f32x2){SSAK_PHI_C3, SSAK_PHI_C3}, (f32x2){SSAK_PHI_C2, SSAK_PHI_C2});
+  q = __builtin_elementwise_fma(q, s, (f32x2){SSAK_PHI_C1, SSAK_PHI_C1});
+  q = __builtin_elementwise_fma(q, s, (f32x2){SSAK_PHI_C0, SSAK_PHI_C0});
+  q = q * xc;
+  const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])} + (f32x2){1.f, 1.f};
+  return (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) { return x * phi2(x); }
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+  // d/dx [x Phi(x)] = Phi(x) + x phi(x), phi(x) = exp(-x^2 / 2) / sqrt(2 pi)
+  const f32x2 t = x * x * (f32x2){-0.72134752044448170f, -0.72134752044448170f};
+  const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  return __builtin_elementwise_fma(x * (f32x2){0.39894228040143268f, 0.39894228040143268f}, e, phi2(x));
+}
+__device__ __forceinline__ float gelu_f(float x) { return gelu2((f32x2){x, x})[0]; }
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad2((f32x2){x, x})[0]; }
 // counter-based RNG for dropout masks: the forward and backward kernels recompute the same bits from
 // (seed, stream, element index); no mask tensor is stored.  "lowbias32" mixer: 2 integer multiplies (v_mul_lo_u32 is
 // a slow VALU op; the GEMM epilogues and the attention kernels were VALU-bound on a 3-multiply hash).

@@ -862,7 +862,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     if (g_prof_on) {
       rec.e0 = prof_event();
       rec.e1 = prof_event();
-      rec.variant = 20 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
+      rec.variant = 20 + (p8_bm / 64 - 2) * 4 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
       rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
       (void)hipEventRecord(rec.e0, st);
     }
@@ -901,14 +901,14 @@ extern "C" int ssak_prof_enable(int on) {
 }
 
 extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
-  SSAK_REQUIRE(out && cap >= 28, "prof_collect: need room for 28 entries");
-  for (int i = 0; i < 28; ++i) {
+  SSAK_REQUIRE(out && cap >= 32, "prof_collect: need room for 32 entries");
+  for (int i = 0; i < 32; ++i) {
     if (i < 16)
       snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
     else if (i < 20)
       snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
     else
-      snprintf(out[i].name, sizeof(out[i].name), "%s<%s, %s>", i < 24 ? "gemm_p8_kernel" : "unused", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<%d, %s, %s>", (i - 20) / 4 + 2, (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
     out[i].launches = 0;
     out[i].total_ms = 0.0;
     out[i].total_flops = 0.0;
@@ -924,5 +924,5 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
     g_event_pool.push_back(r.e1);
   }
   g_prof.clear();
-  return 28;
+  return 32;
 }

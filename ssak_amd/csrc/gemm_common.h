@@ -133,11 +133,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           *reinterpret_cast<bf16x8*>(p.aux_out + o) = q;
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+        for (int r = 0; r < 8; r += 2) {
+          const f32x2 y = gelu2((f32x2){v[r], v[r + 1]});
+          v[r] = y[0];
+          v[r + 1] = y[1];
+        }
       } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
         const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(p.aux_in + o);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f((float)a8[r]);
+        for (int r = 0; r < 8; r += 2) {
+          const f32x2 y = gelu_grad2((f32x2){(float)a8[r], (float)a8[r + 1]});
+          v[r] *= y[0];
+          v[r + 1] *= y[1];
+        }
       }
       if (p.drop_thresh) {
 #pragma unroll
@@ -255,6 +263,136 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int r = 0; r < 4; ++r)
           if (n + r < p.N) dst[r] = (bf16)v[r];
       }
+    }
+  }
+}
+
+// ---- LDS-free epilogue for interior 64-column wave tiles -----------------------------------------------------------
+// Everything elementwise (alpha, bias, GELU, GELU', dropout) is done in the accumulator layout.  fp32 outputs (slabs,
+// weight gradients) are stored from there directly: the 4 lanes of a row hold 64 contiguous bytes.  bf16 outputs would be
+// 8 B per lane and a quarter line per row, so the packed pairs go through a 4x4 transposition between the wave's four
+// 16-lane rows and the four column groups (v_permlane32_swap + v_permlane16_swap, 8 per 16 rows): lane (lm, lq) ends
+// up with the 16 consecutive columns 16*lq.. of row lm = two 16-byte stores, the four lanes of a row cover one 128-B
+// line.  No LDS traffic, no barrier, ~40 VALU + 2 stores per 16 rows on the plain path (the LDS round trip it replaces
+// measured 4.6 us per 256x256 tile whatever the number of workgroups, tools/probes/p8_probe.hip).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ void xpose4(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3) {
+  u32x2 t = __builtin_amdgcn_permlane32_swap(r0, r2, false, false);
+  r0 = t[0];
+  r2 = t[1];
+  t = __builtin_amdgcn_permlane32_swap(r1, r3, false, false);
+  r1 = t[0];
+  r3 = t[1];
+  t = __builtin_amdgcn_permlane16_swap(r0, r1, false, false);
+  r0 = t[0];
+  r1 = t[1];
+  t = __builtin_amdgcn_permlane16_swap(r2, r3, false, false);
+  r2 = t[0];
+  r3 = t[1];
+}
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+// store 16 rows x 64 columns of bf16 held as v[j][r] (accumulator layout) at dst + row lm, columns 16*lq..
+__device__ __forceinline__ void store_bf16_rows(bf16* dst_lane /* + row lm, + 16*lq */, const float (&v)[4][4]) {
+  uint32_t lo[4], hi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16x2 a = {(bf16)v[j][0], (bf16)v[j][1]};
+    const bf16x2 b = {(bf16)v[j][2], (bf16)v[j][3]};
+    lo[j] = __builtin_bit_cast(uint32_t, a);
+    hi[j] = __builtin_bit_cast(uint32_t, b);
+  }
+  xpose4(lo[0], lo[1], lo[2], lo[3]);
+  xpose4(hi[0], hi[1], hi[2], hi[3]);
+  *reinterpret_cast<u32x4*>(dst_lane) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+  *reinterpret_cast<u32x4*>(dst_lane + 8) = (u32x4){lo[2], hi[2], lo[3], hi[3]};
+}
+// true when the wave tile [wm0, wm0 + rows) x [wn0, wn0 + 64) of this workgroup can take gemm_epilogue_direct
+__device__ __forceinline__ bool epilogue_direct_ok(const GemmParams& p, int bm0, int bn0, int wm0, int wn0, int rows, long coff) {
+  return bm0 + wm0 + rows <= p.M && bn0 + wn0 + 64 <= p.N && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (coff & 7) == 0 &&
+         (((uintptr_t)p.aux_in | (uintptr_t)p.aux_out | (uintptr_t)p.C) & 15) == 0;
+}
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 (&acc)[MI][4], const BiasRegs<4>& br, int bm0,
+                                                     int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split) {
+  const int lm = lane & 15, lq = lane >> 4;
+  if (p.split_k > 1) {  // raw partial sums into this split's slab
+    float* S = p.slab + ((long)split * p.nz + z) * (long)p.M * p.N + (long)(bm0 + wm0 + lm) * p.N + bn0 + wn0 + 4 * lq;
+    const long step = 16L * p.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i, S += step)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(S + 16 * j) = acc[i][j];
+    return;
+  }
+  long orow = z1 * p.sc1 + z2 * p.sc2 + (long)(bm0 + wm0 + lm) * p.ldc + bn0 + wn0;  // row lm of the 16-row group, column 0
+  const long step = 16L * p.ldc;
+  const bool plain = p.epilogue == SSAK_EPI_NONE && !p.drop_thresh;
+  if (plain && !p.out_f32) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i, orow += step) {
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] * p.alpha + br.v[j][r];
+      store_bf16_rows(reinterpret_cast<bf16*>(p.C) + orow + 16 * lq, v);
+      __builtin_amdgcn_sched_barrier(0);  // keep the 16-row groups apart: hoisted addresses cost registers
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i, orow += step) {
+    __builtin_amdgcn_sched_barrier(0);
+    const long oa = orow + 4 * lq;  // this lane's chunk of column group j: oa + 16 * j
+    float v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] * p.alpha + br.v[j][r];
+    if (p.epilogue == SSAK_EPI_GELU) {
+      if (p.aux_out) store_bf16_rows(p.aux_out + orow + 16 * lq, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 y = gelu2((f32x2){v[j][r], v[j][r + 1]});
+          v[j][r] = y[0];
+          v[j][r + 1] = y[1];
+        }
+    } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
+      bf16x4 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const bf16x4*>(p.aux_in + oa + 16 * j);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 y = gelu_grad2((f32x2){(float)a[j][r], (float)a[j][r + 1]});
+          v[j][r] *= y[0];
+          v[j][r + 1] *= y[1];
+        }
+    }
+    if (p.drop_thresh) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w0 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)(oa + 16 * j));
+        const uint32_t w1 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)(oa + 16 * j) + 2);
+        v[j][0] = ((w0 & 0xffffu) >= p.drop_thresh) ? v[j][0] * p.drop_scale : 0.f;
+        v[j][1] = ((w0 >> 16) >= p.drop_thresh) ? v[j][1] * p.drop_scale : 0.f;
+        v[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[j][2] * p.drop_scale : 0.f;
+        v[j][3] = ((w1 >> 16) >= p.drop_thresh) ? v[j][3] * p.drop_scale : 0.f;
+      }
+    }
+    if (p.out_f32) {
+      float* dst = reinterpret_cast<float*>(p.C) + oa;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 t = {v[j][0], v[j][1], v[j][2], v[j][3]};
+        if (p.accumulate) t += *reinterpret_cast<const f32x4*>(dst + 16 * j);
+        *reinterpret_cast<f32x4*>(dst + 16 * j) = t;
+      }
+    } else {
+      store_bf16_rows(reinterpret_cast<bf16*>(p.C) + orow + 16 * lq, v);
     }
   }
 }

@@ -26,6 +26,8 @@
 // LDS images per piece (as the 128x128 kernel): K-contiguous [128 rows][128 B], 16-B chunk c of row r at slot
 // c ^ ((r >> 1) & 7) (ds_read_b128, conflict-free); K-major [64 k-rows][256 B], chunk ch of k-row kr at slot
 // ch ^ km_swz(kr) (ds_read_b64_tr_b16).  The DMA writes linearly, so the swizzles are applied to the source address.
+#include <algorithm>
+
 #include "common.h"
 #include "gemm_common.h"
 #include "kernels.h"
@@ -35,7 +37,8 @@ namespace {
 constexpr int P8_THREADS = 512;
 constexpr int P8_PIECE = 16384;          // bytes per piece
 constexpr int P8_BUF = 4 * P8_PIECE;     // AT, AB, BL, BR
-constexpr int P8_LDS = 2 * P8_BUF;       // 128 KiB
+constexpr int P8_PIPE = 2 * P8_BUF;      // 128 KiB of operand pieces
+constexpr int P8_LDS = P8_PIPE + 8 * 1024;  // + 1 KiB per wave: the tile's bias slice, staged by DMA with the operands
 
 // Staging state of one operand (two pieces: half 0 = AT / BL, half 1 = AB / BR).  SEG = rows of a piece taken from one
 // wave row / column (16 * MH for A, 32 for B), SPAN = that wave row's / column's extent in the tile (2 * SEG), NSEG = wave
@@ -119,10 +122,15 @@ struct P8Frag {
     if (!KM) {
       return *reinterpret_cast<const bf16x8*>(piece + ((off[0] ^ (kk << 6)) + i * 2048));
     } else {
-      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-      const char* a = piece + off[KM ? i : 0] + kk * 32 * 256;
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * 256));
+      // inline asm on purpose: for the ds_read_tr builtin the compiler cannot tell the read apart from the LDS-DMA writes
+      // in flight and puts `s_waitcnt vmcnt(0)` in front of every fragment read, which drains the whole pipeline four
+      // times per K tile.  Ordering is by the counted waits + barriers of the phase structure; results are consumed
+      // after the explicit lgkmcnt(0) of P8_MFMA.
+      typedef __attribute__((address_space(3))) char lds_char;
+      const uint32_t a = (uint32_t)(uintptr_t)(lds_char*)(piece + off[KM ? i : 0] + kk * 32 * 256);
+      s16x4 lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a) : "memory");
       typedef __attribute__((ext_vector_type(8))) short s16x8;
       s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       return __builtin_bit_cast(bf16x8, v);
@@ -134,7 +142,7 @@ struct P8Frag {
 #ifdef P8_STAMPS
 #define P8_STAMP(i)                                                                                   \
   do {                                                                                                \
-    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.slab)[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.slab)[(blockIdx.x * 4 + p8_round) * 8 + (i)] = wall_clock64(); \
   } while (0)
 #else
 #define P8_STAMP(i)
@@ -148,29 +156,7 @@ struct P8Frag {
     P8_FENCE();                     \
   } while (0)
 // the 4 * MH MFMAs of one output quadrant: 16-row groups I0..I0+MH-1 x column groups J0, J0+1, both 32-deep halves
-#ifdef P8_DMA_IN_MFMA
-// variant: the phase's LDS-DMA is issued by the wave row that is multiplying, between the two 32-deep halves
-#define P8_MFMA(I0, J0, FB, DMA)                                                                              \
-  do {                                                                                                        \
-    P8_BARRIER();                                                                                             \
-    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                            \
-    _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] =                               \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][0], fa[i][0], acc[(I0) + i][(J0) + j], 0, 0, 0);    \
-    P8_FENCE();                                                                                               \
-    DMA;                                                                                                      \
-    P8_FENCE();                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] =                               \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][1], fa[i][1], acc[(I0) + i][(J0) + j], 0, 0, 0);    \
-    __builtin_amdgcn_s_setprio(0);                                                                            \
-    P8_BARRIER();                                                                                             \
-  } while (0)
-#define P8_PRE(DMA)
-#define P8_WAIT() wait_vmcnt<6>()
-#else
-#define P8_MFMA(I0, J0, FB, DMA)                                                                              \
+#define P8_MFMA(I0, J0, FB)                                                                                   \
   do {                                                                                                        \
     P8_BARRIER();                                                                                             \
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */                                                      \
@@ -181,125 +167,197 @@ struct P8Frag {
     __builtin_amdgcn_s_setprio(0);                                                                            \
     P8_BARRIER();                                                                                             \
   } while (0)
-#define P8_PRE(DMA) DMA
-#define P8_WAIT() wait_vmcnt<8>()
-#endif
 
 // MH = 16-row groups per quadrant: the tile is (64 * MH) x 256, i.e. 256 / 192 / 128 rows -- picked by the host so
 // that the tile count fills whole rounds of 256 workgroups (M = 15968: 192-row tiles give 84 x 3 = 252 tiles for N = 768).
+// Tile coordinates of one unit of work (uniform across the workgroup).
+struct P8Tile {
+  int bm0, bn0, z, z1, z2, split, kt0, kt1;
+};
+
 template <int MH, bool A_KM, bool B_KM>
 __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p) {
   constexpr int BM = 64 * MH, SEGA = 16 * MH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  P8_STAMP(0);
+#ifdef P8_STAMPS
+  int p8_round = 0;  // stamps: [workgroup][tile round < 4][8]
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int per_z = p.tiles_m * p.tiles_n;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int zs = id / per_z, rem = id % per_z;
-  const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
-  const int split = zs % p.split_k, z = zs / p.split_k;
-  const int z1 = z / p.nb2, z2 = z % p.nb2;
-  const bf16* Ab = p.A + z1 * p.sa1 + z2 * p.sa2;
-  const bf16* Bb = p.B + z1 * p.sb1 + z2 * p.sb2;
-  const int bm0 = tm * BM, bn0 = tn * 256;
+  const int ntiles = per_z * p.nz * p.split_k;
   const int nkt = (p.K + BK - 1) / BK;
-  const int kt0 = split * p.kt_per_split;
-  const int kt1 = min(nkt, kt0 + p.kt_per_split);
-
-  f32x4 acc[2 * MH][4];
-#pragma unroll
-  for (int i = 0; i < 2 * MH; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto decode = [&](int t) {
+    P8Tile c;
+    const int id = xcd_remap(t, ntiles);
+    const int zs = id / per_z, rem = id % per_z;
+    const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
+    c.split = zs % p.split_k;
+    c.z = zs / p.split_k;
+    c.z1 = c.z / p.nb2;
+    c.z2 = c.z % p.nb2;
+    c.bm0 = tm * BM;
+    c.bn0 = tn * 256;
+    c.kt0 = c.split * p.kt_per_split;
+    c.kt1 = min(nkt, c.kt0 + p.kt_per_split);
+    return c;
+  };
 
   P8Stager<A_KM, SEGA, 2 * SEGA, A_KM ? 16 : 4 * MH, 2> sa;
   P8Stager<B_KM, 32, 64, 16, 4> sb;
-  sa.init(Ab, p.lda, bm0, p.M, kt0, p.ext_a);
-  sb.init(Bb, p.ldb, bn0, p.N, kt0, p.ext_b);
   P8Frag<A_KM, MH> fra;
   P8Frag<B_KM, 2> frb;
   fra.init(wr * SEGA, lane);
   frb.init(wc * 32, lane);
-
   // piece slots of buffer b: AT = 0, AB = 1, BL = 2, BR = 3
   char* const buf0 = smem;
   char* const buf1 = smem + P8_BUF;
-  // prologue: BL(0) AT(0) BR(0) AB(0) BL(1) AT(1)
-  sb.template issue<0>(buf0 + 2 * P8_PIECE, kt0, kt1, p.K);
-  sa.template issue<0>(buf0 + 0 * P8_PIECE, kt0, kt1, p.K);
-  sb.template issue<1>(buf0 + 3 * P8_PIECE, kt0, kt1, p.K);
-  sa.template issue<1>(buf0 + 1 * P8_PIECE, kt0, kt1, p.K);
-  sb.template issue<0>(buf1 + 2 * P8_PIECE, kt0 + 1, kt1, p.K);
-  sa.template issue<0>(buf1 + 0 * P8_PIECE, kt0 + 1, kt1, p.K);
-  wait_vmcnt<8>();  // BL(0), AT(0) landed (this wave's share)
-  P8_BARRIER();     // ... everyone's
-  if (wr == 1) P8_BARRIER();  // wave row 1 runs one barrier behind wave row 0
-  P8_STAMP(1);
+  // stage the first two K tiles of tile c (all eight piece slots): BL(0) AT(0) BR(0) AB(0) BL(1) AT(1) BR(1) AB(1)
+  // bias of the wave's 64 columns: one more LDS-DMA at the head of the priming sequence (lanes 0-15, 16 B each; the rest
+  // out of range = zeros).  A register load here would sit in the compiler's scoreboard across the persistent loop and
+  // make it drain vmcnt -- stores included -- in the middle of the next tile's first K step.
+  const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.bias, 0, p.bias ? (int)((((long)p.nb2 - 1) * p.bias_s2 + p.N) * 4) : 0, 0x00020000);
+  char* const bias_lds = smem + P8_PIPE + wave * 1024;
+  auto prime = [&](const P8Tile& c) {
+    {
+      const long col = c.z2 * p.bias_s2 + c.bn0 + wc * 64 + 4 * lane;
+      const uint32_t o = lane < 16 ? (uint32_t)(col * 4) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lds_void*)bias_lds, 16, o, 0, 0, 0);
+    }
+    sa.init(p.A + c.z1 * p.sa1 + c.z2 * p.sa2, p.lda, c.bm0, p.M, c.kt0, p.ext_a);
+    sb.init(p.B + c.z1 * p.sb1 + c.z2 * p.sb2, p.ldb, c.bn0, p.N, c.kt0, p.ext_b);
+    sb.template issue<0>(buf0 + 2 * P8_PIECE, c.kt0, c.kt1, p.K);
+    sa.template issue<0>(buf0 + 0 * P8_PIECE, c.kt0, c.kt1, p.K);
+    sb.template issue<1>(buf0 + 3 * P8_PIECE, c.kt0, c.kt1, p.K);
+    sa.template issue<1>(buf0 + 1 * P8_PIECE, c.kt0, c.kt1, p.K);
+    sb.template issue<0>(buf1 + 2 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
+    sa.template issue<0>(buf1 + 0 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
+    sb.template issue<1>(buf1 + 3 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
+    sa.template issue<1>(buf1 + 1 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
+  };
+  // vector-memory instructions the LDS-free epilogue issues per wave (stores only; vmcnt counts them like the DMA)
+  const int epi_vm = (p.split_k > 1 || p.out_f32 || (p.epilogue == SSAK_EPI_GELU && p.aux_out)) ? 8 * MH : 4 * MH;
+  const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD;  // epilogues that only store
 
-  bf16x8 fa[MH][2], fbl[2][2], fbr[2][2];
-  for (int kt = kt0; kt < kt1; ++kt) {
-    char* const cur = ((kt - kt0) & 1) ? buf1 : buf0;
-    char* const nxt = ((kt - kt0) & 1) ? buf0 : buf1;
-    // ---- P1
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fbl[j][kk] = frb.read(cur + 2 * P8_PIECE, j, kk);
-    P8_FENCE();
-#pragma unroll
-    for (int i = 0; i < MH; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 0 * P8_PIECE, i, kk);
-    P8_FENCE();
-    P8_PRE(sb.template issue<1>(nxt + 3 * P8_PIECE, kt + 1, kt1, p.K));  // BR(t+1)
-    P8_WAIT();                                                            // BR(t)
-    P8_MFMA(0, 0, fbl, sb.template issue<1>(nxt + 3 * P8_PIECE, kt + 1, kt1, p.K));
-    // ---- P2
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fbr[j][kk] = frb.read(cur + 3 * P8_PIECE, j, kk);
-    P8_FENCE();
-    P8_PRE(sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K));  // AB(t+1)
-    P8_WAIT();                                                            // AB(t)
-    P8_MFMA(0, 2, fbr, sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K));
-    // ---- P3
-#pragma unroll
-    for (int i = 0; i < MH; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 1 * P8_PIECE, i, kk);
-    P8_FENCE();
-    P8_PRE(sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K));  // BL(t+2)
-    P8_MFMA(MH, 2, fbr, sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K));
-    // ---- P4
-    P8_PRE(sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K));  // AT(t+2)
-    P8_WAIT();                                                            // BL(t+1), AT(t+1)
-    P8_MFMA(MH, 0, fbl, sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K));
-  }
-  if (wr == 0) P8_BARRIER();
-  wait_vmcnt<0>();  // drain the trailing dummies before LDS is released
-  P8_STAMP(2);
+  // Persistent over tiles (the host launches one workgroup per CU).  The next tile's first two K tiles are put in
+  // flight BEFORE the current tile's epilogue, and the epilogue's stores are left to drain under the next main loop:
+  // vmcnt retires in issue order, so `vmcnt(stores of the epilogue)` at the top of the next tile means "the sixteen
+  // priming DMAs have landed", and the first wait that must cover DMAs younger than the stores comes two K tiles later
+  // (phase 4 of K tile 1).  Measured on K = 768 tiles (tools/probes/p8_probe.hip): every CU reaches its epilogue at the
+  // same moment, the 32 MB burst of a round takes 2.7 us (bf16) to 8 us (GELU + saved pre-activation) to drain at HBM
+  // speed, and the pipeline fill of a fresh workgroup costs another 2 us -- all of it used to be exposed.
+  bool primed = false;
+  P8Tile cur_t = decode(blockIdx.x);
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const P8Tile c = cur_t;
+    P8_STAMP(0);
+    const bool was_primed = primed;
+    if (!primed) {
+      prime(c);
+      wait_vmcnt<12>();  // BL(0), AT(0) landed (this wave's share)
+    } else if (epi_vm == 8 * MH) {
+      wait_vmcnt<8 * MH>();  // everything older than the previous epilogue's stores: the eight primed pieces
+    } else {
+      wait_vmcnt<4 * MH>();
+    }
+    P8_BARRIER();     // ... everyone's
+    if (wr == 1) P8_BARRIER();  // wave row 1 runs one barrier behind wave row 0
+    P8_STAMP(1);
 
-  BiasRegs<4> bias_regs;
-  load_bias<4>(p, bn0, wc * 64, lane, z2, bias_regs);
-  __syncthreads();  // DMA drained in every wave, all fragment reads done: LDS becomes the transposition buffer
-  char* const lds_wave = smem + wave * 16384;
-  gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[0]), bias_regs, lds_wave, bm0, bn0, wr * 2 * SEGA, wc * 64, lane, z, z1, z2, split);
-  gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[MH]), bias_regs, lds_wave, bm0, bn0, wr * 2 * SEGA + SEGA, wc * 64, lane, z, z1, z2, split);
+    f32x4 acc[2 * MH][4];
+#pragma unroll
+    for (int i = 0; i < 2 * MH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int kt0 = c.kt0, kt1 = c.kt1;
+    bf16x8 fa[MH][2], fbl[2][2], fbr[2][2];
+    for (int kt = kt0; kt < kt1; ++kt) {
+      char* const cur = ((kt - kt0) & 1) ? buf1 : buf0;
+      char* const nxt = ((kt - kt0) & 1) ? buf0 : buf1;
+      const bool first = kt == kt0;                  // BR(1), AB(1) were staged by prime()
+      const bool settled = was_primed && kt - kt0 < 2;  // every piece this K tile waits for landed before the loop
+      // ---- P1
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fbl[j][kk] = frb.read(cur + 2 * P8_PIECE, j, kk);
+      P8_FENCE();
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 0 * P8_PIECE, i, kk);
+      P8_FENCE();
+      if (!first) sb.template issue<1>(nxt + 3 * P8_PIECE, kt + 1, kt1, p.K);  // BR(t+1)
+      if (!settled) wait_vmcnt<8>();                                           // BR(t)
+      P8_MFMA(0, 0, fbl);
+      // ---- P2
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fbr[j][kk] = frb.read(cur + 3 * P8_PIECE, j, kk);
+      P8_FENCE();
+      if (!first) sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K);  // AB(t+1)
+      if (!settled) wait_vmcnt<8>();                                           // AB(t)
+      P8_MFMA(0, 2, fbr);
+      // ---- P3
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 1 * P8_PIECE, i, kk);
+      P8_FENCE();
+      sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K);  // BL(t+2)
+      P8_MFMA(MH, 2, fbr);
+      // ---- P4
+      sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K);  // AT(t+2)
+      if (!(was_primed && first)) wait_vmcnt<8>();                 // BL(t+1), AT(t+1)
+      P8_MFMA(MH, 0, fbl);
+    }
+    if (wr == 0) P8_BARRIER();
+    wait_vmcnt<0>();  // drain the trailing dummies before LDS is released
+    P8_STAMP(2);
+
+    __syncthreads();  // DMA drained in every wave, all fragment reads done: LDS is free
+    BiasRegs<4> bias_regs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + (16 * j + 4 * (lane >> 4)) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias_regs.v[j][r] = b4[r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the slice is in registers before the next tile's DMA overwrites it
+    P8_FENCE();
+    // interior tile: every wave takes the LDS-free epilogue, so the next tile can start filling LDS right now
+    const bool interior = c.bm0 + BM <= p.M && c.bn0 + 256 <= p.N &&
+                          epilogue_direct_ok(p, c.bm0, c.bn0, 0, 0, BM, c.z1 * p.sc1 + c.z2 * p.sc2);
+    primed = false;
+    if (t + (int)gridDim.x < ntiles) {
+      cur_t = decode(t + gridDim.x);
+      if (interior && epi_early) {
+        prime(cur_t);
+        primed = true;
+      }
+    }
+    if (interior) {
+      gemm_epilogue_direct<2 * MH>(p, acc, bias_regs, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
+    } else {
+      char* const lds_wave = smem + wave * 16384;
+      gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[0]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
+      gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[MH]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA + SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
+      __syncthreads();  // the transposition buffers are read out before the next tile's pieces overwrite them
+    }
+    P8_STAMP(3);
 #ifdef P8_STAMPS
-  P8_STAMP(3);
-  wait_vmcnt<0>();
-  P8_STAMP(4);
-  if (threadIdx.x == 0) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
-    unsigned hw2;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw2));
-    reinterpret_cast<unsigned long long*>(p.slab)[blockIdx.x * 8 + 5] = ((unsigned long long)hw << 32) | hw2;
-  }
+    __syncthreads();
+    P8_STAMP(4);  // every wave has issued its epilogue
+    wait_vmcnt<0>();
+    __syncthreads();
+    P8_STAMP(5);  // ... and its stores have drained
+    p8_round = min(p8_round + 1, 3);
 #endif
+  }
 }
 
 template <int MH, bool A_KM, bool B_KM>
@@ -310,8 +368,14 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
     SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
     attr_done = true;
   }
-  const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
-  kern<<<dim3((unsigned)nblk), P8_THREADS, P8_LDS, st>>>(p);
+  const long ntiles = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    SSAK_HIP(hipGetDevice(&dev));
+    SSAK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(p);  // one persistent workgroup per CU
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

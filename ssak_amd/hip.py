@@ -211,8 +211,8 @@ def prof_enable(on: bool):
 
 def prof_collect():
     """[(kernel name, launches, total ms, total algorithmic flops)] since the last collect."""
-    arr = (ProfEntry * 28)()
-    n = lib.ssak_prof_collect(arr, 28)
+    arr = (ProfEntry * 32)()
+    n = lib.ssak_prof_collect(arr, 32)
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops) for i in range(n)]

@@ -21,7 +21,7 @@ def bench(name, M, N, K, a_km=False, b_km=False, nb=1, split_k=1, out=torch.bflo
     ms = e0.elapsed_time(e1) / iters
     print(f"{name:28s} M={M:6d} N={N:5d} K={K:6d} nb={nb:3d} sk={split_k} {ms*1e3:9.1f} us  {2*M*N*K*nb/ms/1e9:8.1f} TF/s", flush=True)
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 M = B * 499
 bench("qkv", M, 2304, 768)
 bench("out_proj", M, 768, 768)
