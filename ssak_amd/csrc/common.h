@@ -43,15 +43,31 @@ void ssak_set_error(const char* fmt, ...);
 static inline int ssak_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__
+// Wave-wide reductions by DPP (quad swaps, row half mirror / mirror, row_bcast15 / 31, then v_readlane of lane 63): six
+// VALU-rate steps; the __shfl_xor butterfly they replace went through ds_bpermute (LDS crossbar latency on every step),
+// which made the one-wave-per-row normalisation kernels latency-bound.  The result is uniform (an SGPR broadcast).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<0xB1, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xf>(0.f, v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xf>(0.f, v);  // row_half_mirror
+  v += dpp_f<0x140, 0xf>(0.f, v);  // row_mirror: every lane holds its 16-lane row total
+  v += dpp_f<0x142, 0xa>(0.f, v);  // row_bcast15 into rows 1 and 3
+  v += dpp_f<0x143, 0xc>(0.f, v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // block reductions for blockDim.x <= 1024 (<= 16 waves); `red` is >= 16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -171,10 +171,38 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
       gm[i][k] = (ch < nch) ? p.gamma[ch * 8 + k] : 0.f;
     }
   }
-  for (int row = wid; row < p.M; row += gridDim.x * (ROW_THREADS / 64)) {
-    const float mean = p.mean[row], rstd = p.rstd[row];
+  // raw operands of the row a wave works on are fetched one row ahead: a wave owns ~8 rows and every row is a dependent
+  // chain load -> two wave reductions -> store, so without the prefetch the kernel ran at HBM latency, not bandwidth
+  const int rstep = gridDim.x * (ROW_THREADS / 64);
+  uint4 ra[NCH], rb[NCH], rx[NCH];
+  float mean_n = 0.f, rstd_n = 0.f;
+  auto fetch = [&](int row) {
+    mean_n = p.mean[row];
+    rstd_n = p.rstd[row];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        const size_t o = (size_t)row * p.C + ch * 8;
+        ra[i] = *reinterpret_cast<const uint4*>(p.g1 + o);
+        if (p.g2) rb[i] = *reinterpret_cast<const uint4*>(p.g2 + o);
+        rx[i] = *reinterpret_cast<const uint4*>(p.r + o);
+      }
+    }
+  };
+  if (wid < p.M) fetch(wid);
+  for (int row = wid; row < p.M; row += rstep) {
+    const float mean = mean_n, rstd = rstd_n;
     float dyv[NCH][8], xh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
+    uint4 ca[NCH], cb[NCH], cx[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      ca[i] = ra[i];
+      cb[i] = rb[i];
+      cx[i] = rx[i];
+    }
+    if (row + rstep < p.M) fetch(row + rstep);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
@@ -186,14 +214,14 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
       if (ch < nch) {
         const size_t o = (size_t)row * p.C + ch * 8;
         float a[8], x[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.g1 + o), a);
+        unpack8(ca[i], a);
         if (p.g2) {
           float b2[8];
-          unpack8(*reinterpret_cast<const uint4*>(p.g2 + o), b2);
+          unpack8(cb[i], b2);
 #pragma unroll
           for (int k = 0; k < 8; ++k) a[k] += b2[k];
         }
-        unpack8(*reinterpret_cast<const uint4*>(p.r + o), x);
+        unpack8(cx[i], x);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           if (p.post_thresh) a[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? a[k] * p.post_scale : 0.f;
