@@ -75,6 +75,21 @@ int ssak_ctc_loss_fwd_bwd(const float* logits, const int32_t* in_lens, const int
 int ssak_ctc_greedy_decode(const float* logits, const int32_t* in_lens, int B, int F, int V, int blank, int32_t* ids,
                            int32_t* out_lens, void* stream);
 
+/* ---- f1: CTC forced alignment (Viterbi trellis + backtrack) ----------------------------------
+ * Replaces get_trellis + backtrack of ssak/utils/align_transcriptions.py:27-70,79-123 (USE_MAX, USE_CHAR_REPEATED),
+ * reached from compute_alignment (:294-402) under tools/align_audio_transcript.py:121,335.
+ * emission [F, V] fp32 log-probabilities (compute_log_probas, ssak/infer/general.py:99-101); tokens [L] int32 in [0, V);
+ * col0 [F+1] = trellis column 0 supplied by the caller (the first_as_garbage variant, :38) or NULL for the running sum of
+ * the blank log-probability (:40).  Outputs: trellis [F+1, L+1] fp32, bit-identical to the reference's; the path as
+ * arrays indexed by time frame -- path_token[t] = token index, path_logp[t] = log of Point.score -- valid for
+ * t in [path_info[1], path_info[1] + path_info[0]); path_info[0] = -1 when the walk ends without reaching token 0
+ * (the reference raises RuntimeError("Failed to align ...")), -2 when a token id lies outside [0, V).
+ * workspace >= ssak_ctc_align_workspace_bytes (one byte per trellis cell + one per frame).  One utterance per call, L <= 16384. */
+size_t ssak_ctc_align_workspace_bytes(int F, int L);
+int ssak_ctc_forced_align(const float* emission, const int32_t* tokens, int F, int V, int L, int blank, const float* col0,
+                          float* trellis, int32_t* path_token, float* path_logp, int32_t* path_info /*[2]*/, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* ---- dense contraction (MFMA bf16, fp32 accumulate) -----------------------------------------
  * The one GEMM behind every Linear / Conv1d / attention product of a3-a10.  C = alpha * op(A) * op(B)
  * (+ epilogue).  Operand layouts: *_kmajor = 0 -> stored [rows, K] with K contiguous (A: [M,K], B: [N,K],

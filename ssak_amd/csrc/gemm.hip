@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstdio>
 #include "common.h"
 #include "gemm_common.h"
 #include "kernels.h"
@@ -798,6 +799,11 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   const bool dma = d->pads_are_zero || !(partial_a || partial_b);
   const GemmPlan plan = plan_gemm(d, dma, workspace ? workspace_bytes : 0);
   const int split = plan.split;
+  static const bool env_trace = getenv("SSAK_GEMM_TRACE") != nullptr;  // development: one line per launch
+  if (env_trace)
+    fprintf(stderr, "gemm M=%d N=%d K=%d akm=%d bkm=%d nb=%dx%d epi=%d f32=%d acc=%d drop=%g dma=%d -> %s bm=%d split=%d cost=%.1f\n", d->M,
+            d->N, d->K, d->a_kmajor, d->b_kmajor, d->nb1, d->nb2, d->epilogue, d->out_f32, d->accumulate, d->drop_p, (int)dma,
+            plan.p8 ? "p8" : "tile128", plan.bm, plan.split, plan.cost);
   GemmParams p;
   p.A = (const bf16*)A;
   p.B = (const bf16*)B;

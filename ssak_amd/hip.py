@@ -60,6 +60,8 @@ def _load():
         "ssak_ctc_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "ssak_ctc_loss_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]),
         "ssak_ctc_greedy_decode": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "ssak_ctc_align_workspace_bytes": (sz, [i32, i32]),
+        "ssak_ctc_forced_align": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_prof_enable": (i32, [i32]),
         "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),

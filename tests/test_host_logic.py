@@ -133,3 +133,26 @@ def test_synthetic_batch_is_ctc_feasible():
     assert w.shape == (4, 16000) and w.dtype == np.float32 and np.abs(w).max() <= 1.0
     n = (lab >= 0).sum(-1)
     assert n.min() >= 60 and n.max() <= 120 and lab.max() < len(VOCAB) and (2 * n + 1 <= 499).all()
+
+
+def test_align_host_mirror_matches_oracle(gold):
+    """The pure-Python tail of the alignment path (merge_repeats / merge_words / vocabulary helpers) against the oracle's
+    restatement of ssak/utils/align_transcriptions.py:140-172 on the golden path."""
+    from oracle import align_ref
+    from ssak_amd import align
+    from ssak_amd.data import CharTokenizer
+    z = gold("align.npz")
+    tok = z["base_tokens"].tolist()
+    path_o = [align_ref.Point(int(a), int(b), float(c)) for a, b, c in zip(z["base_path_token"], z["base_path_time"], z["base_path_score"])]
+    path_m = [align.Point(p.token_index, p.time_index, p.score) for p in path_o]
+    transcript = "".join("ab cd"[t % 5] for t in tok)
+    so, sm = align_ref.merge_repeats(transcript, path_o), align.merge_repeats(transcript, path_m)
+    assert [(s.label, s.start, s.end, s.score) for s in so] == [(s.label, s.start, s.end, s.score) for s in sm]
+    wo, wm = align_ref.merge_words(so), align.merge_words(sm)
+    assert [(s.label, s.start, s.end, s.score) for s in wo] == [(s.label, s.start, s.end, s.score) for s in wm]
+    t = CharTokenizer(["<pad>", "<s>", "</s>", "<unk>", "|", "a", "b", "É"])
+    labels, blank = align.get_model_vocab((None, t))
+    assert labels[4] == " " and blank == 0
+    d = {c: i for i, c in enumerate(labels)}
+    assert align.loose_get_char_index(d, "A", 4) == 5 and align.loose_get_char_index(d, "é", 4) == 7
+    assert align.loose_get_char_index(d, "z", 4) == 4 and align.loose_get_char_index(d, "z", None) is None

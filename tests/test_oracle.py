@@ -139,3 +139,54 @@ def test_w2v2_base_vs_hf(gold):
     for n, nr, hd in zip(z["grad_names"], z["grad_norms"], z["grad_heads"]):
         g = grads[str(n)].numpy()
         assert abs(np.sqrt((g.astype(np.float64) ** 2).sum()) - nr) <= 2e-3 * nr + 1e-7, n
+
+
+# ------------------------------------------------------------------ forced alignment
+ALIGN_CASES = ["tiny", "base", "blank5", "garbage", "flat", "tight", "infeasible"]
+
+
+@pytest.mark.parametrize("name", ALIGN_CASES)
+def test_align_oracle_vs_torch_golden(gold, name):
+    """Bit-exact against the trellis / path the reference's torch ops give (oracle/gen_golden_align.py)."""
+    from oracle import align_ref
+    z = gold("align.npz")
+    em, tok, blank = z[f"{name}_emission"], z[f"{name}_tokens"].tolist(), int(z[f"{name}_blank"])
+    tr = align_ref.get_trellis(em, tok, blank, bool(z[f"{name}_garbage"]))
+    assert np.array_equal(tr, z[f"{name}_trellis"])
+    if not int(z[f"{name}_ok"]):
+        with pytest.raises(RuntimeError):
+            align_ref.backtrack(tr, em, tok, blank)
+        return
+    path = align_ref.backtrack(tr, em, tok, blank)
+    assert [p.token_index for p in path] == z[f"{name}_path_token"].tolist()
+    assert [p.time_index for p in path] == z[f"{name}_path_time"].tolist()
+    assert np.allclose([p.score for p in path], z[f"{name}_path_score"], rtol=1e-6, atol=0)
+
+
+def test_align_trellis_is_best_path_by_enumeration():
+    """trellis[F, L] equals the best score over ALL admissible frame labellings (tiny cases, exhaustive)."""
+    from oracle import align_ref
+    rng = np.random.default_rng(0)
+    for F, V, L in [(6, 4, 2), (7, 5, 3), (8, 4, 4), (9, 3, 1)]:
+        em = np.log(rng.dirichlet(np.ones(V), size=F)).astype(np.float32)
+        tok = rng.integers(1, V, L).tolist()
+        tr = align_ref.get_trellis(em, tok, 0)
+        assert abs(float(tr[F, L]) - align_ref.best_score_by_enumeration(em, tok, 0)) < 1e-4
+
+
+def test_align_path_properties_and_segments(gold):
+    from oracle import align_ref
+    z = gold("align.npz")
+    em, tok = z["base_emission"], z["base_tokens"].tolist()
+    path = align_ref.backtrack(align_ref.get_trellis(em, tok, 0), em, tok, 0)
+    ti = [p.token_index for p in path]
+    tt = [p.time_index for p in path]
+    assert ti[0] == 0 and ti[-1] == len(tok) - 1 and all(b - a in (0, 1) for a, b in zip(ti, ti[1:]))
+    assert all(b - a == 1 for a, b in zip(tt, tt[1:]))  # one point per frame, contiguous
+    assert all(0.0 <= p.score <= 1.0 for p in path)
+    transcript = "".join("ab cd"[t % 5] for t in tok)
+    segs = align_ref.merge_repeats(transcript, path)
+    assert len(segs) == len(tok) and segs[0].start == tt[0] and segs[-1].end == tt[-1] + 1
+    assert all(a.end == b.start for a, b in zip(segs, segs[1:]))
+    words = align_ref.merge_words(segs)
+    assert "".join(w.label for w in words) == transcript.replace(" ", "")
