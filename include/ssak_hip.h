@@ -75,6 +75,17 @@ int ssak_ctc_loss_fwd_bwd(const float* logits, const int32_t* in_lens, const int
 int ssak_ctc_greedy_decode(const float* logits, const int32_t* in_lens, int B, int F, int V, int blank, int32_t* ids,
                            int32_t* out_lens, void* stream);
 
+/* ---- f3: word error counts for the evaluation step ---------------------------------------------
+ * Replaces compute_metrics of ssak/train/transformers/wav2vec_train.py:110-125 after the argmax (ssak_ctc_greedy_decode):
+ * batch_decode of predictions and (ungrouped) labels, remove_special_words(glue_apostrophe=False), the "wer" metric.
+ * hyp_ids [B, F] / hyp_lens [B] as ssak_ctc_greedy_decode writes them; labels [B, Lmax] int32, negative = padding;
+ * token_class [V] uint8: 0 letter, 1 word separator ("|"), 2 removed from the text (pad and the other "<...>" tokens),
+ * 3 letter that also ends its word (the apostrophe).  edits [B] = substitutions + deletions + insertions between the
+ * word sequences, ref_words [B] = reference words; WER = sum(edits) / sum(ref_words). */
+size_t ssak_ctc_wer_workspace_bytes(int B, int F, int Lmax);
+int ssak_ctc_wer(const int32_t* hyp_ids, const int32_t* hyp_lens, const int32_t* labels, const uint8_t* token_class, int B, int F,
+                 int Lmax, int V, int32_t* edits, int32_t* ref_words, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- f1: CTC forced alignment (Viterbi trellis + backtrack) ----------------------------------
  * Replaces get_trellis + backtrack of ssak/utils/align_transcriptions.py:27-70,79-123 (USE_MAX, USE_CHAR_REPEATED),
  * reached from compute_alignment (:294-402) under tools/align_audio_transcript.py:121,335.

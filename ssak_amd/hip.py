@@ -60,6 +60,8 @@ def _load():
         "ssak_ctc_workspace_bytes": (sz, [i32, i32, i32, i32]),
         "ssak_ctc_loss_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]),
         "ssak_ctc_greedy_decode": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "ssak_ctc_wer_workspace_bytes": (sz, [i32, i32, i32]),
+        "ssak_ctc_wer": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "ssak_ctc_align_workspace_bytes": (sz, [i32, i32]),
         "ssak_ctc_forced_align": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
@@ -191,6 +193,20 @@ def ctc_greedy_decode(logits: torch.Tensor, in_lens: torch.Tensor | None = None,
     n = torch.empty(B, dtype=torch.int32, device=logits.device)
     check(lib.ssak_ctc_greedy_decode(ptr(logits), ptr(in_lens), B, F, V, blank, ptr(ids), ptr(n), stream()))
     return ids, n
+
+
+def ctc_wer(hyp_ids: torch.Tensor, hyp_lens: torch.Tensor, labels: torch.Tensor, token_class: torch.Tensor):
+    """(edits [B], ref_words [B]) int32 on the device; see ``ssak_ctc_wer`` in include/ssak_hip.h."""
+    B, F = hyp_ids.shape
+    labels = labels.to(device=hyp_ids.device, dtype=torch.int32).contiguous()
+    token_class = token_class.to(device=hyp_ids.device, dtype=torch.uint8).contiguous()
+    Lmax, V = labels.shape[1], token_class.numel()
+    edits = torch.empty(B, dtype=torch.int32, device=hyp_ids.device)
+    nref = torch.empty(B, dtype=torch.int32, device=hyp_ids.device)
+    ws = _ws(lib.ssak_ctc_wer_workspace_bytes(B, F, Lmax), hyp_ids.device)
+    check(lib.ssak_ctc_wer(ptr(hyp_ids), ptr(hyp_lens), ptr(labels), ptr(token_class), B, F, Lmax, V, ptr(edits), ptr(nref),
+                           ptr(ws), ws.numel(), stream()))
+    return edits, nref
 
 
 def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,

@@ -99,27 +99,28 @@ def prepare(utts, tok):
 
 
 def evaluate(model, tok, waves, labels, batch_size):
+    """eval_loss and eval_wer over the validation set.  Logits never leave the device: greedy decode and the word-level
+    edit counts are kernels (ssak_amd.metrics), the loss is summed on the device, and there is ONE host read at the end
+    (the reference's compute_metrics argmaxes the full logits on the host at every eval step, wav2vec_train.py:110-125)."""
+    from .metrics import WerAccumulator
     model.eval()
-    tot, n, refs, hyps = 0.0, 0, [], []
+    acc = WerAccumulator(tok.vocab, tok.pad_token_id, model.device, tok.delim)
+    tot = torch.zeros(1, dtype=torch.float32, device=model.device)
+    n = 0
     for i in range(0, len(waves), batch_size):
         x, lens = pad_waves(waves[i:i + batch_size])
-        lab = pad_labels(labels[i:i + batch_size])
+        lab = torch.from_numpy(pad_labels(labels[i:i + batch_size])).to(model.device)
         xd, ld = torch.from_numpy(x).to(model.device), torch.from_numpy(lens).to(model.device)
         use_mask = model.config.feat_extract_norm == "layer"
+        fl = torch.tensor([model.num_frames(int(l)) for l in lens], dtype=torch.int32, device=model.device)
         with torch.cuda.device(model.device):
             xn = hip.wave_normalize(xd, ld)
-        out = model(xn, lengths=ld if use_mask else None, labels=torch.from_numpy(lab))
-        tot += float(out.loss.item()) * len(x)
+            out = model(xn, lengths=ld if use_mask else None, labels=lab)
+            tot += out.loss * len(x)
+            acc.add(out.logits, lab, fl)
         n += len(x)
-        fl = torch.tensor([model.num_frames(int(l)) for l in lens], dtype=torch.int32)
-        with torch.cuda.device(model.device):
-            dec, cnt = hip.ctc_greedy_decode(out.logits, fl, tok.pad_token_id)
-        dec, cnt = dec.cpu().numpy(), cnt.cpu().numpy()
-        for b in range(len(x)):
-            hyps.append(remove_special_words(tok.decode(dec[b, :cnt[b]], group_tokens=False), glue_apostrophe=False))
-            refs.append(remove_special_words(tok.decode(lab[b], group_tokens=False), glue_apostrophe=False))
     model.train()
-    return {"eval_loss": tot / max(n, 1), "eval_wer": word_error_rate(refs, hyps)}
+    return {"eval_loss": float(tot.item()) / max(n, 1), "eval_wer": acc.compute()["wer"]}
 
 
 def main(argv=None):

@@ -334,3 +334,43 @@ def test_fused_attention_dropout_consistency(hip):
     pred = (dqkv[:, :2 * H] * (qkv3[:, :2 * H].float() - qkv[:, :2 * H].float())).sum().item()
     got = (o3.float() * dctx.float()).sum().item() - base
     assert pred > 0 and abs(got - pred) < 0.25 * pred, (got, pred)
+
+
+# ------------------------------------------------------------------ evaluation metric on the device (f3)
+def test_device_wer_vs_oracle(hip):
+    """Random "recognitions" of random transcripts (apostrophes, <unk>, repeats, blanks, empty hypotheses) through greedy
+    decode + ssak_ctc_wer, against the CPU restatement of compute_metrics: integer results, bit-exact."""
+    from oracle import wer_ref
+    from ssak_amd import metrics
+    from ssak_amd.synth import VOCAB
+    rng = np.random.default_rng(3)
+    B, F, V, L = 48, 300, len(VOCAB), 90
+    letters = [i for i, t in enumerate(VOCAB) if len(t) == 1 and t != "|"]
+    labels = np.full((B, L), -100, np.int64)
+    pred = np.zeros((B, F), np.int64)
+    for b in range(B):
+        n = int(rng.integers(0, L))
+        ref = [int(rng.choice(letters)) if rng.random() > 0.18 else VOCAB.index("|") for _ in range(n)]
+        if n > 4 and b % 5 == 0:
+            ref[2] = VOCAB.index("<unk>")
+        labels[b, :n] = ref
+        # a noisy frame-level rendering of the reference: repeats, blanks between, some substitutions / drops
+        frames = []
+        for t in ref:
+            if rng.random() < 0.08:
+                continue
+            if rng.random() < 0.08:
+                t = int(rng.choice(letters))
+            frames += [t] * int(rng.integers(1, 3)) + [0] * int(rng.integers(0, 2))
+        frames = frames[:F]
+        if b == 7:
+            frames = []
+        pred[b, :len(frames)] = frames
+    logits = np.full((B, F, V), -5.0, np.float32)
+    np.put_along_axis(logits, pred[..., None], 5.0, axis=2)
+    acc = metrics.WerAccumulator(VOCAB, 0)
+    edits, nref = acc.add(_dev(logits), _dev(labels))
+    e_ref, n_ref, wer_ref_v = wer_ref.compute_metrics(pred, labels, VOCAB, 0)
+    assert edits.cpu().numpy().tolist() == e_ref.tolist()
+    assert nref.cpu().numpy().tolist() == n_ref.tolist()
+    assert abs(acc.compute()["wer"] - wer_ref_v) < 1e-12

@@ -190,3 +190,24 @@ def test_align_path_properties_and_segments(gold):
     assert all(a.end == b.start for a, b in zip(segs, segs[1:]))
     words = align_ref.merge_words(segs)
     assert "".join(w.label for w in words) == transcript.replace(" ", "")
+
+
+# ------------------------------------------------------------------ evaluation metric
+def test_wer_oracle_known_answers():
+    from oracle import wer_ref
+    from ssak_amd.synth import VOCAB
+    enc = lambda s: [VOCAB.index("|" if c == " " else c) for c in s]
+    assert wer_ref.word_edits("the cat sat".split(), "the cat sat".split()) == 0
+    assert wer_ref.word_edits("the cat sat".split(), "the hat sat down".split()) == 2   # 1 substitution + 1 insertion
+    assert wer_ref.word_edits("a b c d".split(), "b c".split()) == 2                     # 2 deletions
+    assert wer_ref.word_edits([], "x y".split()) == 2
+    assert wer_ref.format_words_for_wer("l'ami <unk> d'ici") == "l' ami d' ici"
+    # argmax rows with repeats and blanks (a blank keeps the double l apart); labels ungrouped with -100 padding:
+    # hypothesis "hello word" against "hello world" -> 1 edit / 2 words
+    pred = [0] + enc("hheel") + [0] + enc("lo") + [0] + enc("  wworr") + [0] + enc("d") + [0, 0]
+    lab = enc("hello world") + [-100] * 5
+    e, n, wer = wer_ref.compute_metrics([pred], [lab], VOCAB, 0)
+    assert e.tolist() == [1] and n.tolist() == [2] and wer == 0.5
+    lab2 = enc("hello word") + [-100] * 6
+    e, n, wer = wer_ref.compute_metrics([pred, pred], [lab, lab2], VOCAB, 0)
+    assert e.tolist() == [1, 0] and n.tolist() == [2, 2] and wer == 0.25
