@@ -137,6 +137,13 @@ typedef struct {
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Grouped form: n <= 8 plain products (no bias / activation / dropout / batches / split-K) that share K, the operand layouts,
+ * alpha and the output type run as ONE launch whose tiles are dealt over the whole chip -- the weight gradients
+ * dW = dY^T X of one or two encoder layers (loss.backward() of wav2vec_train.py:415), which one at a time are too few tiles
+ * to fill the GPU without split-K slabs.  descs / A / B / C are host arrays of length n. */
+int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs /*host*/, int n, const void* const* A, const void* const* B, void* const* C,
+                           void* stream);
+
 /* Per-launch GEMM timing for the roofline report (measurement aid, not on the reference's path): while
  * enabled, every GEMM launch is bracketed by HIP events on its own stream; ssak_prof_collect waits for them and
  * returns, per kernel instantiation (named as rocprofv3 prints it), launches / summed ms / algorithmic FLOPs. */
@@ -147,7 +154,7 @@ typedef struct {
   double total_flops;
 } ssak_prof_entry;
 int ssak_prof_enable(int on);
-int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 32; returns the number of entries (32) */
+int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 33; returns the number of entries (33) */
 
 /* ---- a7 (part): fused self-attention, head_dim 64 --------------------------------------------
  * Replaces Wav2Vec2Attention's softmax(QK^T d^-0.5 + key mask) -> dropout -> .V and its autograd

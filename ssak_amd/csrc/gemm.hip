@@ -900,6 +900,76 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   return SSAK_OK;
 }
 
+// Grouped launch: n <= 8 products of the same K, operand layouts, alpha and output type in ONE persistent launch of the
+// phase-interleaved kernel (no bias / activation / dropout / split-K / batches).  This is the weight-gradient form of the
+// train step: the four dW = dY^T X products of an encoder layer have 108 256x256 tiles between them and K = 16 k rows;
+// launched one by one each needs a 7-way split-K with fp32 slabs and a reduction pass to fill the chip, two layers launched
+// together are 216 tiles -- one round of workgroups, every accumulator written once, straight into the gradient buffer.
+extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const void* const* A, const void* const* B, void* const* C,
+                                      void* stream) {
+  SSAK_REQUIRE(descs && A && B && C && n >= 1 && n <= 8, "gemm_grouped: need 1..8 problems");
+  const ssak_gemm_desc& d0 = descs[0];
+  int Ms[8], Ns[8];
+  long lda[8], ldb[8], ldc[8];
+  uint32_t ea[8], eb[8];
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const ssak_gemm_desc& d = descs[i];
+    SSAK_REQUIRE(A[i] && B[i] && C[i], "gemm_grouped: null operand");
+    SSAK_REQUIRE(d.M > 0 && d.N > 0 && d.K == d0.K && d.K > 0, "gemm_grouped: all problems must share K");
+    SSAK_REQUIRE(d.a_kmajor == d0.a_kmajor && d.b_kmajor == d0.b_kmajor && d.out_f32 == d0.out_f32 && d.alpha == d0.alpha &&
+                     d.accumulate == d0.accumulate, "gemm_grouped: layouts, alpha and output type must match");
+    SSAK_REQUIRE(d.nb1 == 1 && d.nb2 == 1 && d.epilogue == SSAK_EPI_NONE && !(d.drop_p > 0.f) && d.split_k <= 1,
+                 "gemm_grouped: plain single products only");
+    SSAK_REQUIRE((d.lda & 7) == 0 && (d.ldb & 7) == 0 && (d.ldc & 3) == 0, "gemm_grouped: lda/ldb must be multiples of 8, ldc of 4");
+    SSAK_REQUIRE(((uintptr_t)A[i] & 15) == 0 && ((uintptr_t)B[i] & 15) == 0 && ((uintptr_t)C[i] & 15) == 0,
+                 "gemm_grouped: operands must be 16-byte aligned");
+    SSAK_REQUIRE(!d.accumulate || d.out_f32, "gemm_grouped: accumulate needs fp32 output");
+    const bool partial_a = d.a_kmajor ? (d.M & 7) : (d.K & 7);
+    const bool partial_b = d.b_kmajor ? (d.N & 7) : (d.K & 7);
+    SSAK_REQUIRE(d.pads_are_zero || !(partial_a || partial_b), "gemm_grouped: operands need whole 16-byte chunks (or zero padding)");
+    const double xa = d.a_kmajor ? ((double)(d.K - 1) * d.lda + d.M) : ((double)(d.M - 1) * d.lda + d.K);
+    const double xb = d.b_kmajor ? ((double)(d.K - 1) * d.ldb + d.N) : ((double)(d.N - 1) * d.ldb + d.K);
+    SSAK_REQUIRE(xa * 2 < 2.0e9 && xb * 2 < 2.0e9, "gemm_grouped: an operand must span < 2 GB");
+    ea[i] = (uint32_t)(((long)xa + 7) / 8 * 16);
+    eb[i] = (uint32_t)(((long)xb + 7) / 8 * 16);
+    Ms[i] = d.M;
+    Ns[i] = d.N;
+    lda[i] = d.lda;
+    ldb[i] = d.ldb;
+    ldc[i] = d.ldc;
+    flops += 2.0 * d.M * d.N * (double)d.K;
+  }
+  GemmParams p{};
+  p.K = d0.K;
+  p.M = d0.M;
+  p.N = d0.N;
+  p.nb2 = 1;
+  p.nz = 1;
+  p.alpha = d0.alpha;
+  p.epilogue = SSAK_EPI_NONE;
+  p.out_f32 = d0.out_f32;
+  p.accumulate = d0.accumulate;
+  p.split_k = 1;
+  p.drop_scale = 1.f;
+  p.kt_per_split = ssak_cdiv(d0.K, BK);
+  hipStream_t st = (hipStream_t)stream;
+  ProfRec rec;
+  if (g_prof_on) {
+    rec.e0 = prof_event();
+    rec.e1 = prof_event();
+    rec.variant = 32;
+    rec.flops = flops;
+    (void)hipEventRecord(rec.e0, st);
+  }
+  const int rc = ssak_gemm_p8_launch_grouped(&p, n, A, B, C, Ms, Ns, lda, ldb, ldc, ea, eb, d0.a_kmajor, d0.b_kmajor, st);
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.e1, st);
+    g_prof.push_back(rec);
+  }
+  return rc;
+}
+
 extern "C" int ssak_prof_enable(int on) {
   g_prof_on = on != 0;
 
@@ -907,14 +977,16 @@ extern "C" int ssak_prof_enable(int on) {
 }
 
 extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
-  SSAK_REQUIRE(out && cap >= 32, "prof_collect: need room for 32 entries");
-  for (int i = 0; i < 32; ++i) {
+  SSAK_REQUIRE(out && cap >= 33, "prof_collect: need room for 33 entries");
+  for (int i = 0; i < 33; ++i) {
     if (i < 16)
       snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
     else if (i < 20)
       snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
+    else if (i < 32)
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<%d, %s, %s, false>", (i - 20) / 4 + 2, (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
     else
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<%d, %s, %s>", (i - 20) / 4 + 2, (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<4, true, true, true>");  // grouped weight gradients
     out[i].launches = 0;
     out[i].total_ms = 0.0;
     out[i].total_flops = 0.0;
@@ -930,5 +1002,5 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
     g_event_pool.push_back(r.e1);
   }
   g_prof.clear();
-  return 32;
+  return 33;
 }

@@ -172,11 +172,28 @@ struct P8Frag {
 // that the tile count fills whole rounds of 256 workgroups (M = 15968: 192-row tiles give 84 x 3 = 252 tiles for N = 768).
 // Tile coordinates of one unit of work (uniform across the workgroup).
 struct P8Tile {
-  int bm0, bn0, z, z1, z2, split, kt0, kt1;
+  int bm0, bn0, z, z1, z2, split, kt0, kt1, g;
 };
 
-template <int MH, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p) {
+// Grouped launch: up to 8 independent products of the same K, layouts and epilogue (the weight gradients of one or two
+// encoder layers) share ONE persistent launch, so that together they fill a round of workgroups without split-K slabs.
+// The table travels in the kernel arguments (scalar loads with a dynamic index).
+struct P8Problem {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  long lda, ldb, ldc;
+  int M, N;
+  uint32_t ext_a, ext_b;
+  int tile0, tiles_n;  // first tile id of this problem, its tile columns
+};
+struct P8Group {
+  int n, total_tiles;
+  P8Problem pr[8];
+};
+
+template <int MH, bool A_KM, bool B_KM, bool GROUPED = false>
+__global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p, const P8Group grp) {
   constexpr int BM = 64 * MH, SEGA = 16 * MH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P8_STAMPS
@@ -186,11 +203,24 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int per_z = p.tiles_m * p.tiles_n;
-  const int ntiles = per_z * p.nz * p.split_k;
+  const int ntiles = GROUPED ? grp.total_tiles : per_z * p.nz * p.split_k;
   const int nkt = (p.K + BK - 1) / BK;
   auto decode = [&](int t) {
     P8Tile c;
     const int id = xcd_remap(t, ntiles);
+    if (GROUPED) {
+      int gi = 0;
+      for (int k = 1; k < grp.n; ++k) gi = id >= grp.pr[k].tile0 ? k : gi;
+      const int rem = id - grp.pr[gi].tile0;
+      c.g = gi;
+      c.bm0 = rem / grp.pr[gi].tiles_n * BM;
+      c.bn0 = rem % grp.pr[gi].tiles_n * 256;
+      c.z = c.z1 = c.z2 = c.split = 0;
+      c.kt0 = 0;
+      c.kt1 = nkt;
+      return c;
+    }
+    c.g = 0;
     const int zs = id / per_z, rem = id % per_z;
     const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
     c.split = zs % p.split_k;
@@ -226,8 +256,14 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
       const uint32_t o = lane < 16 ? (uint32_t)(col * 4) : 0x80000000u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lds_void*)bias_lds, 16, o, 0, 0, 0);
     }
-    sa.init(p.A + c.z1 * p.sa1 + c.z2 * p.sa2, p.lda, c.bm0, p.M, c.kt0, p.ext_a);
-    sb.init(p.B + c.z1 * p.sb1 + c.z2 * p.sb2, p.ldb, c.bn0, p.N, c.kt0, p.ext_b);
+    if (GROUPED) {
+      const P8Problem& q = grp.pr[c.g];
+      sa.init(q.A, q.lda, c.bm0, q.M, c.kt0, q.ext_a);
+      sb.init(q.B, q.ldb, c.bn0, q.N, c.kt0, q.ext_b);
+    } else {
+      sa.init(p.A + c.z1 * p.sa1 + c.z2 * p.sa2, p.lda, c.bm0, p.M, c.kt0, p.ext_a);
+      sb.init(p.B + c.z1 * p.sb1 + c.z2 * p.sb2, p.ldb, c.bn0, p.N, c.kt0, p.ext_b);
+    }
     sb.template issue<0>(buf0 + 2 * P8_PIECE, c.kt0, c.kt1, p.K);
     sa.template issue<0>(buf0 + 0 * P8_PIECE, c.kt0, c.kt1, p.K);
     sb.template issue<1>(buf0 + 3 * P8_PIECE, c.kt0, c.kt1, p.K);
@@ -330,8 +366,15 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the slice is in registers before the next tile's DMA overwrites it
     P8_FENCE();
     // interior tile: every wave takes the LDS-free epilogue, so the next tile can start filling LDS right now
-    const bool interior = c.bm0 + BM <= p.M && c.bn0 + 256 <= p.N &&
-                          epilogue_direct_ok(p, c.bm0, c.bn0, 0, 0, BM, c.z1 * p.sc1 + c.z2 * p.sc2);
+    GemmParams pe = p;  // the epilogue's view: in a grouped launch the output belongs to this tile's problem
+    if (GROUPED) {
+      pe.C = grp.pr[c.g].C;
+      pe.ldc = grp.pr[c.g].ldc;
+      pe.M = grp.pr[c.g].M;
+      pe.N = grp.pr[c.g].N;
+    }
+    const bool interior = c.bm0 + BM <= pe.M && c.bn0 + 256 <= pe.N &&
+                          epilogue_direct_ok(pe, c.bm0, c.bn0, 0, 0, BM, c.z1 * p.sc1 + c.z2 * p.sc2);
     primed = false;
     if (t + (int)gridDim.x < ntiles) {
       cur_t = decode(t + gridDim.x);
@@ -341,11 +384,11 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
       }
     }
     if (interior) {
-      gemm_epilogue_direct<2 * MH>(p, acc, bias_regs, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
+      gemm_epilogue_direct<2 * MH>(pe, acc, bias_regs, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
     } else {
       char* const lds_wave = smem + wave * 16384;
-      gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[0]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
-      gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[MH]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA + SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
+      gemm_epilogue<MH, 4>(pe, reinterpret_cast<f32x4(&)[MH][4]>(acc[0]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
+      gemm_epilogue<MH, 4>(pe, reinterpret_cast<f32x4(&)[MH][4]>(acc[MH]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA + SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
       __syncthreads();  // the transposition buffers are read out before the next tile's pieces overwrite them
     }
     P8_STAMP(3);
@@ -360,22 +403,32 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p)
   }
 }
 
-template <int MH, bool A_KM, bool B_KM>
-int launch_p8(const GemmParams& p, hipStream_t st) {
-  auto kern = gemm_p8_kernel<MH, A_KM, B_KM>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
-    attr_done = true;
-  }
-  const long ntiles = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
+int p8_num_cu(int* out) {
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
     SSAK_HIP(hipGetDevice(&dev));
     SSAK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(p);  // one persistent workgroup per CU
+  *out = n_cu;
+  return SSAK_OK;
+}
+
+template <int MH, bool A_KM, bool B_KM>
+int launch_p8(const GemmParams& p, hipStream_t st) {
+  auto kern = gemm_p8_kernel<MH, A_KM, B_KM, false>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
+    attr_done = true;
+  }
+  const long ntiles = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
+  int n_cu = 0;
+  if (int rc = p8_num_cu(&n_cu)) return rc;
+  P8Group none;
+  none.n = 0;
+  none.total_tiles = 0;
+  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(p, none);  // one persistent workgroup per CU
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -388,6 +441,21 @@ int dispatch_p8(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
   return launch_p8<MH, true, false>(p, st);
 }
 
+template <bool A_KM, bool B_KM>
+int launch_p8_grouped(const GemmParams& p, const P8Group& grp, hipStream_t st) {
+  auto kern = gemm_p8_kernel<4, A_KM, B_KM, true>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
+    attr_done = true;
+  }
+  int n_cu = 0;
+  if (int rc = p8_num_cu(&n_cu)) return rc;
+  kern<<<dim3((unsigned)std::min(grp.total_tiles, n_cu)), P8_THREADS, P8_LDS, st>>>(p, grp);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
 }  // namespace
 
 int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st) {
@@ -395,4 +463,37 @@ int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStrea
   if (bm == 256) return dispatch_p8<4>(p, a_km, b_km, st);
   if (bm == 192) return dispatch_p8<3>(p, a_km, b_km, st);
   return dispatch_p8<2>(p, a_km, b_km, st);
+}
+
+// Grouped launch of n <= 8 problems sharing K, layouts, alpha and output type (256-row tiles).  `params` carries the shared
+// fields (K, alpha, out_f32, accumulate, ...); A/B/C, M/N, leading dimensions and extents come per problem.
+int ssak_gemm_p8_launch_grouped(const void* params, int n, const void* const* A, const void* const* B, void* const* C, const int* M,
+                                const int* N, const long* lda, const long* ldb, const long* ldc, const uint32_t* ext_a,
+                                const uint32_t* ext_b, int a_km, int b_km, hipStream_t st) {
+  const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
+  P8Group grp;
+  grp.n = n;
+  int t0 = 0;
+  for (int i = 0; i < n; ++i) {
+    P8Problem& q = grp.pr[i];
+    q.A = (const bf16*)A[i];
+    q.B = (const bf16*)B[i];
+    q.C = C[i];
+    q.lda = lda[i];
+    q.ldb = ldb[i];
+    q.ldc = ldc[i];
+    q.M = M[i];
+    q.N = N[i];
+    q.ext_a = ext_a[i];
+    q.ext_b = ext_b[i];
+    q.tile0 = t0;
+    q.tiles_n = ssak_cdiv(N[i], 256);
+    t0 += ssak_cdiv(M[i], 256) * q.tiles_n;
+  }
+  for (int i = n; i < 8; ++i) grp.pr[i] = grp.pr[0];
+  grp.total_tiles = t0;
+  if (!a_km && !b_km) return launch_p8_grouped<false, false>(p, grp, st);
+  if (!a_km && b_km) return launch_p8_grouped<false, true>(p, grp, st);
+  if (a_km && b_km) return launch_p8_grouped<true, true>(p, grp, st);
+  return launch_p8_grouped<true, false>(p, grp, st);
 }

@@ -60,6 +60,9 @@ struct Plan {
   std::vector<LayerBuf> lb;
   // backward temporaries
   size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH, lnpart;
+  // second set of the buffers the weight-gradient products read (dy of both LayerNorms, dI, dqkv): those products are
+  // queued and launched two layers at a time, so a layer's set must survive the next layer's backward
+  size_t dY1 = 0, dYb[2] = {0, 0}, dIb[2] = {0, 0}, dqkvb[2] = {0, 0}, dY1b[2] = {0, 0};
   // Whisper front end: RS2 rows per utterance after conv2, RS1 = 2*RS2 before it
   int Tin = 0, RS1 = 0, RS2 = 0;
   bool fused_attn = false;
@@ -369,10 +372,19 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.dA = cv.take((size_t)M * H * b2);
     p.dB = cv.take((size_t)M * H * b2);
     p.dY = cv.take((size_t)M * H * b2);
+    p.dY1 = cv.take((size_t)M * H * b2);
     p.dC = cv.take((size_t)M * H * b2);
     p.scratchH = cv.take((size_t)M * H * b2);
     p.dI = cv.take((size_t)M * I * b2);
     p.dqkv = cv.take((size_t)M * 3 * H * b2);
+    p.dYb[0] = p.dY;
+    p.dY1b[0] = p.dY1;
+    p.dIb[0] = p.dI;
+    p.dqkvb[0] = p.dqkv;
+    p.dYb[1] = cv.take((size_t)M * H * b2);
+    p.dY1b[1] = cv.take((size_t)M * H * b2);
+    p.dIb[1] = cv.take((size_t)M * I * b2);
+    p.dqkvb[1] = cv.take((size_t)M * 3 * H * b2);
     p.dSb = cv.take(p.fused_attn ? 256 : (size_t)B * nh * p.F * p.Fp * b2);
     p.delta = cv.take((size_t)B * nh * p.F * sizeof(float));
     p.pgdy = cv.take((size_t)G * p.pg_rows * (H / G) * b2);
@@ -463,6 +475,44 @@ struct Gemm {
   int run_wgrad(hipStream_t st, void* slab, size_t slab_bytes) {
     d.split_k = 0;
     return run(st, slab, slab_bytes);
+  }
+};
+
+// Weight-gradient products are not on the critical path of the backward: they are queued and launched together (one or
+// two layers = up to 8 products) as ONE grouped GEMM that fills a round of workgroups with 256x256 tiles, instead of
+// four launches per layer that each need split-K slabs and a reduction pass (ssak_gemm_bf16_grouped).
+struct WgradQueue {
+  ssak_gemm_desc d[8];
+  const void* A[8];
+  const void* B[8];
+  void* C[8];
+  int n = 0, layers = 0, tiles = 0;
+  long ann_off[2] = {0, 0};
+  static int tiles_of(const ssak_gemm_desc& g) { return ssak_cdiv(g.M, 256) * ssak_cdiv(g.N, 256); }
+  void push(const Gemm& g) {
+    d[n] = g.d;
+    A[n] = g.A;
+    B[n] = g.B;
+    C[n] = g.C;
+    tiles += tiles_of(g.d);
+    ++n;
+  }
+  // launch what is queued: grouped when it fills at least 5/8 of a round of 256 workgroups, else one by one (split-K)
+  int flush(hipStream_t st, void* slab, size_t slab_bytes) {
+    int rc = SSAK_OK;
+    if (n > 0) {
+      if (tiles >= 160) {
+        rc = ssak_gemm_bf16_grouped(d, n, A, B, C, (void*)st);
+      } else {
+        for (int i = 0; i < n && rc == SSAK_OK; ++i) {
+          d[i].split_k = 0;
+          rc = ssak_gemm_bf16(&d[i], A[i], B[i], C[i], nullptr, nullptr, nullptr, slab, slab_bytes, (void*)st);
+        }
+      }
+    }
+    n = 0;
+    tiles = 0;
+    return rc;
   }
 };
 
@@ -873,13 +923,22 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   // ---- encoder layers, last to first.  gA (+gB) = gradient w.r.t. x[l+1], the layer output (post-LN) or the
   // normalised input of the next layer (stable-LN); Gres = gradient of the residual stream (stable-LN only).
   const bool stable = whisper || c.do_stable_layer_norm != 0;
-  const bool hdrop = c.hidden_dropout > 0.f;
   const bf16* Gres = nullptr;
   auto free_buf = [&](const bf16* u1, const bf16* u2, const bf16* u3) {
     bf16* cand[3] = {BF(p.dC), BF(p.dA), BF(p.scratchH)};
     for (bf16* cnd : cand)
       if (cnd != u1 && cnd != u2 && cnd != u3) return cnd;
     return (bf16*)nullptr;
+  };
+  WgradQueue wq;
+  int kept = 0;  // layers that ran so far: selects the buffer set their weight-gradient operands live in
+  const int layer_tiles = ssak_cdiv(3 * H, 256) * ssak_cdiv(H, 256) + ssak_cdiv(H, 256) * ssak_cdiv(H, 256) +
+                          2 * ssak_cdiv(I, 256) * ssak_cdiv(H, 256);
+  auto flush_wgrads = [&]() -> int {
+    TRY(wq.flush(st, slab, p.slab_bytes));
+    for (int i = 0; i < wq.layers; ++i) announce(wq.ann_off[i], layer_span);
+    wq.layers = 0;
+    return SSAK_OK;
   };
   for (int l = c.num_layers - 1; l >= 0; --l) {
     const LayerP& L = e->lp[l];
@@ -901,45 +960,51 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
       continue;
     }
     bf16* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
-    bf16* dY = BF(p.dY);
+    const int set = kept & 1;
+    ++kept;
+    bf16* dY = BF(p.dYb[set]);     // dy of the feed-forward branch (dropout mask applied): dX and dW operand
+    bf16* dY1 = BF(p.dY1b[set]);   // dy of the attention branch
+    bf16* dI = BF(p.dIb[set]);
     if (!stable) {
       // final_layer_norm backward: r2 = x1 + drop(ffn)
-      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, hdrop ? dY : nullptr,
+      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, dY,
                           Gd + L.ln2w, Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
     } else {
       // (next LN) backward: x[l+1] = LN_next(r2), r2 = r1 + drop(ffn); the residual-stream gradient is added after it
-      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dR, hdrop ? dY : nullptr, Gd + nxt_w,
+      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dR, dY, Gd + nxt_w,
                           Gd + nxt_b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
     }
-    const bf16* dy2 = hdrop ? dY : dR;
-    TRY(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true).run_wgrad(st, slab, p.slab_bytes));
+    // (the dy output is written even without hidden dropout -- a plain copy then -- so that the queued weight-gradient
+    // products always read buffers of this layer's set, never the rotating residual-stream buffers)
+    const bf16* dy2 = dY;
+    wq.push(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));
     TRY(k_colsum(dy2, H, M, H, Gd + L.b2, st));
-    TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(BF(p.dI), I)
+    TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
             .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed).run(st));
-    TRY(Gemm(I, H, M).a(BF(p.dI), I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true).run_wgrad(st, slab, p.slab_bytes));
-    TRY(k_colsum(BF(p.dI), I, M, I, Gd + L.b1, st));
+    wq.push(Gemm(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
+    TRY(k_colsum(dI, I, M, I, Gd + L.b1, st));
     bf16* dX = BF(p.dB);
-    TRY(Gemm(M, H, I).a(BF(p.dI), I).b(W + L.w1, H, true).c(dX, H).run(st));
+    TRY(Gemm(M, H, I).a(dI, I).b(W + L.w1, H, true).c(dX, H).run(st));
     bf16* dR1;
     if (!stable) {
       // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
       dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
-      TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, hdrop ? dY : nullptr, Gd + L.ln1w,
+      TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, dY1, Gd + L.ln1w,
                           Gd + L.ln1b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
     } else {
       // final_layer_norm backward: x1 = LN(r1), r1 = r + drop(attn_out); residual gradient dR is added after it
       dR1 = free_buf(dR, dX, nullptr);
-      TRY(k_layernorm_bwd(dX, nullptr, BF(lb.r1), stl, stl + M, P + L.ln2w, dR, dR1, hdrop ? dY : nullptr, Gd + L.ln2w,
+      TRY(k_layernorm_bwd(dX, nullptr, BF(lb.r1), stl, stl + M, P + L.ln2w, dR, dR1, dY1, Gd + L.ln2w,
                           Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
     }
-    const bf16* dy1 = hdrop ? dY : dR1;
-    TRY(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true).run_wgrad(st, slab, p.slab_bytes));
+    const bf16* dy1 = dY1;
+    wq.push(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));
     TRY(k_colsum(dy1, H, M, H, Gd + L.bo, st));
     bf16* dctx = free_buf(dR1, dX, nullptr);
     TRY(Gemm(M, H, H).a(dy1, H).b(W + L.wo, H, true).c(dctx, H).run(st));
     // attention backward per (utterance, head)
     bf16* qkv = BF(lb.qkv);
-    bf16* dqkv = BF(p.dqkv);
+    bf16* dqkv = BF(p.dqkvb[set]);
     const long sq1 = (long)F * 3 * H, sp1 = (long)nh * F * Fp, sp2 = (long)F * Fp, sh1 = (long)F * H;
     if (p.fused_attn) {
       TRY(k_attention_bwd(qkv, BF(lb.ctx), FP(lb.lse), flens, dctx, FP(p.delta), dqkv, B, F, nh, H,
@@ -955,10 +1020,12 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
       TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
     }
-    TRY(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true).run_wgrad(st, slab, p.slab_bytes));
+    wq.push(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
     TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st));
     TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
-    announce(L.wqkv, layer_span);
+    wq.ann_off[wq.layers++] = L.wqkv;
+    // launch when a second layer is queued, or when another layer would spill into a second round of workgroups
+    if (wq.layers == 2 || wq.tiles + layer_tiles > 256) TRY(flush_wgrads());
     if (!stable) {
       // gradient w.r.t. this layer's input = dR1 (residual of r1) + dX
       gA = dR1;
@@ -969,6 +1036,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
       Gres = dR1;
     }
   }
+  TRY(flush_wgrads());
   // ---- encoder input
   bf16* dh1 = free_buf(gA, gB, Gres);
   if (!stable) {

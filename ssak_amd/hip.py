@@ -65,6 +65,7 @@ def _load():
         "ssak_ctc_align_workspace_bytes": (sz, [i32, i32]),
         "ssak_ctc_forced_align": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "ssak_prof_enable": (i32, [i32]),
         "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
@@ -223,14 +224,27 @@ def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=
     return C_out
 
 
+def gemm_grouped(problems, stream_=None):
+    """problems: list of (A, B, C_out, M, N, K, lda, ldb, ldc) sharing K / layouts (a_kmajor, b_kmajor passed per call via
+    keyword in each tuple's dict is not needed: the weight-gradient form is k-major on both operands)."""
+    n = len(problems)
+    descs = (GemmDesc * n)()
+    pa, pb, pc = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    for i, (A, B, Cout, M, N, K, lda, ldb, ldc, akm, bkm) in enumerate(problems):
+        descs[i] = GemmDesc(M, N, K, int(akm), int(bkm), lda, ldb, ldc, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0,
+                            int(Cout.dtype == torch.float32), 0, 1, 0.0, 0, 0, 0, 1)
+        pa[i], pb[i], pc[i] = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
+    check(lib.ssak_gemm_bf16_grouped(descs, n, pa, pb, pc, stream()))
+
+
 def prof_enable(on: bool):
     check(lib.ssak_prof_enable(int(on)))
 
 
 def prof_collect():
     """[(kernel name, launches, total ms, total algorithmic flops)] since the last collect."""
-    arr = (ProfEntry * 32)()
-    n = lib.ssak_prof_collect(arr, 32)
+    arr = (ProfEntry * 33)()
+    n = lib.ssak_prof_collect(arr, 33)
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops) for i in range(n)]

@@ -374,3 +374,39 @@ def test_device_wer_vs_oracle(hip):
     assert edits.cpu().numpy().tolist() == e_ref.tolist()
     assert nref.cpu().numpy().tolist() == n_ref.tolist()
     assert abs(acc.compute()["wer"] - wer_ref_v) < 1e-12
+
+
+@pytest.mark.parametrize("a_km,b_km", [(True, True), (False, False), (False, True)])
+def test_gemm_grouped_exact(hip, a_km, b_km):
+    """Several products of one K in a single grouped launch (the weight-gradient form), ragged shapes included:
+    integer operands, bit-exact against fp32 matmuls; nothing written outside each C."""
+    g = torch.Generator().manual_seed(11)
+    K = 1000
+    shapes = [(768, 768), (2304, 768), (300, 520), (256, 256), (768, 3072), (264, 40)]
+    probs, refs = [], []
+    for M, N in shapes:
+        Mp, Np, Kp = (M + 7) // 8 * 8, (N + 7) // 8 * 8, (K + 7) // 8 * 8
+        A = torch.randint(-3, 4, (Kp, Mp) if a_km else (Mp, Kp), generator=g).to(torch.bfloat16)
+        B = torch.randint(-3, 4, (Kp, Np) if b_km else (Np, Kp), generator=g).to(torch.bfloat16)
+        if a_km:
+            A[K:, :] = 0
+            A[:, M:] = 0
+        else:
+            A[M:, :] = 0
+            A[:, K:] = 0
+        if b_km:
+            B[K:, :] = 0
+            B[:, N:] = 0
+        else:
+            B[N:, :] = 0
+            B[:, K:] = 0
+        Av = A[:K, :M] if a_km else A[:M, :K]
+        Bv = B[:K, :N] if b_km else B[:N, :K]
+        refs.append(_gemm_ref(Av, Bv, a_km, b_km))
+        Cc = torch.full((M, Np), -7.0, dtype=torch.float32).cuda()
+        probs.append((A.cuda(), B.cuda(), Cc, M, N, K, A.shape[1], B.shape[1], Np, a_km, b_km))
+    for _ in range(3):
+        hip.gemm_grouped(probs)
+    for (A, B, Cc, M, N, *_), ref in zip(probs, refs):
+        assert torch.equal(Cc[:, :N].cpu(), ref), (M, N, (Cc[:, :N].cpu() - ref).abs().max())
+        assert (Cc[:, N:] == -7.0).all()
