@@ -318,7 +318,8 @@ __global__ void conv_w_rearrange_kernel(const float* __restrict__ w, bf16* __res
   }
 }
 
-// sum over rows of v[r][k]^2 (and optionally dw_fwd[o][k][c] * v[o][c][k]); K <= 1024 threads, rows strided by grid
+// sum over rows of v[r][k]^2 (and optionally dwf[group][k][c][n] * v[o][c][k], o = group * cg + n); K <= 1024 threads,
+// rows strided by grid
 __global__ void posconv_colnorm_kernel(const float* __restrict__ v, const float* __restrict__ dwf, int rows, int K,
                                        int cg, float* __restrict__ partial) {
   const int k = threadIdx.x;
@@ -328,7 +329,7 @@ __global__ void posconv_colnorm_kernel(const float* __restrict__ v, const float*
     const float a = v[(long)r * K + k];
     if (dwf) {
       const int o = r / cg, c = r % cg;
-      s = fmaf(a, dwf[((long)o * K + k) * cg + c], s);
+      s = fmaf(a, dwf[((((long)(o / cg)) * K + k) * cg + c) * cg + (o % cg)], s);  // dwf[group][tap][c][n]
     } else {
       s = fmaf(a, a, s);
     }
@@ -368,7 +369,7 @@ __global__ void posconv_wbwd_kernel(const float* __restrict__ dwf, const float* 
     const int c = (int)((e / K) % cg);
     const int o = (int)(e / ((long)K * cg));
     const float inv = rsqrtf(nsq[k]);
-    const float d = dwf[((long)o * K + k) * cg + c];
+    const float d = dwf[((((long)(o / cg)) * K + k) * cg + c) * cg + (o % cg)];  // dwf[group][tap][c][n]
     dv[e] += g[k] * inv * (d - v[e] * dot[k] * inv * inv);
     if (e < K) dg[e] += dot[e] * rsqrtf(nsq[e]);
   }

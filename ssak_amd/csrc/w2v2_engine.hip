@@ -1075,11 +1075,13 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(k_posconv_pack(dpre, BF(p.pgdy), B, F, H, G, K, st));
   {
     const int lead = K / 2, RS = F + K;
-    // dW[g][n][tap*cg + c] = sum over packed rows of dy[row][n] * x[row + tap][c]   (one long-K GEMM per group)
-    TRY(Gemm(cg, K * cg, B * RS)
-            .a(BF(p.pgdy) + (long)lead * cg, cg, true)
-            .b(BF(p.pgx), cg, true)
-            .c(FP(p.dwf), (long)K * cg, true)
+    // dW^T[g][tap*cg + c][n] = sum over packed rows of x[row + tap][c] * dy[row][n]: one long-K GEMM per group, with the
+    // 48 output channels of a group on the N side (128x64 tiles, 75 % useful) -- on the M side they sat in 128-row tiles
+    // (37 % useful) and this product was the slowest launch of the backward
+    TRY(Gemm(K * cg, cg, B * RS)
+            .a(BF(p.pgx), cg, true)
+            .b(BF(p.pgdy) + (long)lead * cg, cg, true)
+            .c(FP(p.dwf), cg, true)
             .batch(1, G, 0, p.pg_rows * cg, 0, p.pg_rows * cg, 0, (long)cg * K * cg)
             .run(st));
     TRY(k_posconv_weight_bwd(FP(p.dwf), P + e->p_pc_g, P + e->p_pc_v, e->pc_norms, Gd + e->p_pc_g, Gd + e->p_pc_v, H, G, K, st));
