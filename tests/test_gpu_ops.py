@@ -67,6 +67,25 @@ def test_ctc_edge_cases(hip):
     assert (grad[2, 17:] == 0).all()
 
 
+@pytest.mark.parametrize("Lmax,F", [(300, 700), (600, 1300)])
+def test_ctc_long_label_sequences(hip, Lmax, F):
+    """Label sequences beyond one wave's 4 and 8 states per lane: 16 states per lane (S <= 1024) and, past that, the
+    workgroup-barrier kernel; repeated labels, a ragged batch and an infeasible utterance (zeroed) against the fp64 oracle."""
+    from oracle import ctc_ref
+    rng = np.random.default_rng(Lmax)
+    B, V = 3, 20
+    logits = rng.standard_normal((B, F, V)).astype(np.float32)
+    labels = np.full((B, Lmax), -100)
+    for b, n in enumerate((Lmax, Lmax - 37, 40)):
+        labels[b, :n] = rng.integers(1, 4 if b == 1 else V, n)  # few classes -> many repeats (no skip transitions)
+    in_lens = np.array([F, F - 11, 50], np.int32)                # utterance 2: 40 labels with repeats in 50 frames may not fit
+    loss, nll, grad = hip.ctc_loss(_dev(logits), _dev(in_lens), _dev(labels), 0, "mean", True)
+    o_loss, o_grad, o_nll = ctc_ref.ctc_loss_and_grad(logits, labels, in_lens, 0, "mean", True)
+    assert abs(loss.item() - o_loss) <= 2e-4 * abs(o_loss)
+    assert np.abs(nll.cpu().numpy() - o_nll).max() <= 2e-4 * np.abs(o_nll).max()
+    assert np.abs(grad.cpu().numpy() - o_grad).max() <= 2e-3 * np.abs(o_grad).max()
+
+
 def test_ctc_full_size_properties(hip):
     """BASELINE shape (B=32, F=499, V=32, L in [60,120]): size-independent properties.
     Rows of d loss/d logits sum to zero (softmax minus a posterior), gradient is zero past in_len, and
