@@ -282,12 +282,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     rowbase[qs] = drop_rowbase(p, b, h, qrow[qs]);
     const int qc = min(qrow[qs], F - 1);
     lse[qs] = p.lse[((long)b * p.nh + h) * F + qc];
-    dl[qs] = p.delta[((long)b * p.nh + h) * F + qc];
+    // delta[q] = sum_d dO[q,d] * O[q,d], computed here from the dO fragments the kernel holds anyway (it used to be a
+    // separate pass over dO and O) and written out for the dK/dV kernel, which runs after this one
+    float part = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       qf[qs][kk] = load_row_frag(base + h * HD, ld, qrow[qs], F, kk, lane);
       dof[qs][kk] = load_row_frag(p.dctx + (long)b * F * H + h * HD, H, qrow[qs], F, kk, lane);
+      const bf16x8 of = load_row_frag(p.ctx + (long)b * F * H + h * HD, H, qrow[qs], F, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part = fmaf((float)dof[qs][kk][j], (float)of[j], part);
     }
+    part += shfl_xor_f(part, 16);
+    part += shfl_xor_f(part, 32);
+    dl[qs] = part;
+    if (g == 0 && qrow[qs] < F) p.delta[((long)b * p.nh + h) * F + qrow[qs]] = part;
   }
   f32x4 dq[2][4];
 #pragma unroll
@@ -557,8 +566,6 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
                     bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, hipStream_t st) {
   SSAK_REQUIRE(k_attention_supported(H, nh), "attention: fused kernels are built for head_dim 64 (got %d)", nh ? H / nh : 0);
   const AttnParams p = make_params(qkv, const_cast<bf16*>(ctx), const_cast<float*>(lse), klens, dctx, delta, dqkv, B, F, nh, H, drop);
-  attn_delta_kernel<<<ssak_cdiv((long)B * F, 4), 256, 0, st>>>(dctx, ctx, delta, B, F, nh, H);
-  SSAK_LAUNCH_CHECK();
   attn_bwd_dq_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
   SSAK_LAUNCH_CHECK();
   constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 2 * KT * 4;

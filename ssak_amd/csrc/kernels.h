@@ -14,8 +14,8 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
                     hipStream_t st, const DropSpec& mid = DropSpec(), bool post_gelu = false);
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
                     const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
-                    float* partial /*[LN_BWD_BLOCKS*2*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
-                    hipStream_t st, const DropSpec& mid = DropSpec());
+                    float* partial /*[LN_BWD_BLOCKS*3*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
+                    hipStream_t st, const DropSpec& mid = DropSpec(), float* dy_colsum = nullptr /*[C] += column sums of dy*/);
 constexpr int LN_BWD_BLOCKS = 512;
 int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
                   int rows_per_batch, const DropSpec& drop, hipStream_t st);

@@ -144,7 +144,8 @@ struct LnBwdParams {
   bf16* dy;           // [M,C] grad wrt y = dr * premask/(1-p)  (null when no pre-dropout: use dr)
   float* dgamma;      // [C] += (finalize kernel)
   float* dbeta;
-  float* partial;     // [gridDim.x][2][C] per-workgroup column partials
+  float* partial;     // [gridDim.x][3][C] per-workgroup column partials
+  float* dy_colsum;   // [C] += column sums of dy (the bias gradient of the Linear that produced the branch) or null
   int M, C;
   uint64_t seed;
   uint32_t pre_stream, pre_thresh, post_stream, post_thresh;
@@ -156,11 +157,11 @@ struct LnBwdParams {
 
 template <int NCH>
 __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p) {
-  __shared__ float red[2][ROW_THREADS / 64][NCH * 64 * 8 / 64][64];  // [dgamma|dbeta][wave][slot][lane]
+  __shared__ float red[3][ROW_THREADS / 64][NCH * 64 * 8 / 64][64];  // [dgamma|dbeta|dy sum][wave][slot][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.C >> 3;
   const int wid = blockIdx.x * (ROW_THREADS / 64) + wave;
-  float ag[NCH][8], ab[NCH][8], gm[NCH][8];
+  float ag[NCH][8], ab[NCH][8], gm[NCH][8], ay[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
     for (int k = 0; k < 8; ++k) {
       ag[i][k] = 0.f;
       ab[i][k] = 0.f;
+      ay[i][k] = 0.f;
       gm[i][k] = (ch < nch) ? p.gamma[ch * 8 + k] : 0.f;
     }
   }
@@ -257,8 +259,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
         *reinterpret_cast<uint4*>(p.dr + o) = pack8(d);
         if (p.dy) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
+          for (int k = 0; k < 8; ++k) {
             d[k] = (!p.pre_thresh || keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh)) ? d[k] * p.pre_scale : 0.f;
+            ay[i][k] += d[k];  // fp32 values, before the bf16 rounding of the store
+          }
           *reinterpret_cast<uint4*>(p.dy + o) = pack8(d);
         }
       }
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
     for (int k = 0; k < 8; ++k) {
       red[0][wave][i * 8 + k][lane] = ag[i][k];
       red[1][wave][i * 8 + k][lane] = ab[i][k];
+      red[2][wave][i * 8 + k][lane] = ay[i][k];
     }
   __syncthreads();
   for (int e = threadIdx.x; e < NCH * 8 * 64; e += ROW_THREADS) {
@@ -278,38 +283,42 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
     const int i = slot >> 3, k = slot & 7;
     const int col = (ln + 64 * i) * 8 + k;
     if (col < p.C) {
-      float sg = 0.f, sb = 0.f;
+      float sg = 0.f, sb = 0.f, sy = 0.f;
 #pragma unroll
       for (int w = 0; w < ROW_THREADS / 64; ++w) {
         sg += red[0][w][slot][ln];
         sb += red[1][w][slot][ln];
+        sy += red[2][w][slot][ln];
       }
-      p.partial[((size_t)blockIdx.x * 2) * p.C + col] = sg;
-      p.partial[((size_t)blockIdx.x * 2 + 1) * p.C + col] = sb;
+      p.partial[((size_t)blockIdx.x * 3) * p.C + col] = sg;
+      p.partial[((size_t)blockIdx.x * 3 + 1) * p.C + col] = sb;
+      p.partial[((size_t)blockIdx.x * 3 + 2) * p.C + col] = sy;
     }
   }
 }
 
 __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dy_colsum) {
   // workgroup = 64 columns x 16 row groups; fixed summation order (deterministic), then one += per column
   __shared__ float red[16][65];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + cx;  // index into [2][C]
+  const int e = blockIdx.x * 64 + cx;  // index into [3][C] (the third plane only when dy_colsum is given)
+  const int planes = dy_colsum ? 3 : 2;
   float s = 0.f;
-  if (e < 2 * C) {
+  if (e < planes * C) {
     const int which = e / C, col = e % C;
 #pragma unroll 8
-    for (int b = ry; b < nblk; b += 16) s += partial[((size_t)b * 2 + which) * C + col];
+    for (int b = ry; b < nblk; b += 16) s += partial[((size_t)b * 3 + which) * C + col];
   }
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && e < 2 * C) {
+  if (ry == 0 && e < planes * C) {
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t += red[r][cx];
     const int which = e / C, col = e % C;
-    float* dst = which ? dbeta : dgamma;
+    float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dy_colsum;
     dst[col] += t;
   }
 }
@@ -547,9 +556,10 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
                     const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
                     float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st,
-                    const DropSpec& mid) {
+                    const DropSpec& mid, float* dy_colsum) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm_bwd: C=%d must be a multiple of 8 and <= 1536", C);
-  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, M, C, pre.seed,
+  SSAK_REQUIRE(!dy_colsum || dy, "layernorm_bwd: the dy column sum needs the dy output");
+  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, M, C, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
                 pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f, 1,
                 mid.stream, thresh_of(mid.p), mid.p > 0.f ? 1.f / (1.f - mid.p) : 1.f};
@@ -564,7 +574,7 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   else
     ln_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
-  ln_bwd_finalize_kernel<<<ssak_cdiv(2 * C, 64), 1024, 0, st>>>(partial, grid, C, dgamma, dbeta);
+  ln_bwd_finalize_kernel<<<ssak_cdiv((dy_colsum ? 3 : 2) * C, 64), 1024, 0, st>>>(partial, grid, C, dgamma, dbeta, dy_colsum);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

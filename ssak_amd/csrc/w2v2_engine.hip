@@ -390,7 +390,7 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.pgdy = cv.take((size_t)G * p.pg_rows * (H / G) * b2);
     p.dwf = cv.take((size_t)H * K * (H / G) * sizeof(float));
     p.dln0 = cv.take((size_t)M * C * b2);
-    p.lnpart = cv.take((size_t)LN_BWD_BLOCKS * 2 * std::max(H, C) * sizeof(float));
+    p.lnpart = cv.take((size_t)LN_BWD_BLOCKS * 3 * std::max(H, C) * sizeof(float));
     // split-K slabs: the largest weight-gradient product is [I,H] (or [3H,H]); at most 32 slices
     const size_t big = (size_t)std::max(std::max(I * H, 3 * H * H), std::max(H * C, V * H));
     p.slab_bytes = big * 32 * sizeof(float);
@@ -968,17 +968,16 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     if (!stable) {
       // final_layer_norm backward: r2 = x1 + drop(ffn)
       TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, dY,
-                          Gd + L.ln2w, Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+                          Gd + L.ln2w, Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
     } else {
       // (next LN) backward: x[l+1] = LN_next(r2), r2 = r1 + drop(ffn); the residual-stream gradient is added after it
       TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dR, dY, Gd + nxt_w,
-                          Gd + nxt_b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st));
+                          Gd + nxt_b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
     }
     // (the dy output is written even without hidden dropout -- a plain copy then -- so that the queued weight-gradient
     // products always read buffers of this layer's set, never the rotating residual-stream buffers)
     const bf16* dy2 = dY;
-    wq.push(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));
-    TRY(k_colsum(dy2, H, M, H, Gd + L.b2, st));
+    wq.push(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
     TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
             .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed).run(st));
     wq.push(Gemm(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
@@ -990,16 +989,15 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
       // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
       dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
       TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, dY1, Gd + L.ln1w,
-                          Gd + L.ln1b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+                          Gd + L.ln1b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
     } else {
       // final_layer_norm backward: x1 = LN(r1), r1 = r + drop(attn_out); residual gradient dR is added after it
       dR1 = free_buf(dR, dX, nullptr);
       TRY(k_layernorm_bwd(dX, nullptr, BF(lb.r1), stl, stl + M, P + L.ln2w, dR, dR1, dY1, Gd + L.ln2w,
-                          Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st));
+                          Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
     }
     const bf16* dy1 = dY1;
-    wq.push(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));
-    TRY(k_colsum(dy1, H, M, H, Gd + L.bo, st));
+    wq.push(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));  // (bo's gradient: summed by the LN backward)
     bf16* dctx = free_buf(dR1, dX, nullptr);
     TRY(Gemm(M, H, H).a(dy1, H).b(W + L.wo, H, true).c(dctx, H).run(st));
     // attention backward per (utterance, head)
