@@ -67,6 +67,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
     for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
     if (ch < nch) {
       const size_t o = (size_t)row * p.C + ch * 8;
+      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       if (p.y) {
         unpack8(*reinterpret_cast<const uint4*>(p.y + o), v[i]);
         if (p.pre_thresh) {
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const size_t o = (size_t)row * p.C + ch * 8;
+      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       float g[8], b[8], w[8];
       *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(p.gamma + ch * 8);
       *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(p.gamma + ch * 8 + 4);
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
       const int ch = lane + 64 * i;
       if (ch < nch) {
         const size_t o = (size_t)row * p.C + ch * 8;
+        __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
         ra[i] = *reinterpret_cast<const uint4*>(p.g1 + o);
         if (p.g2) rb[i] = *reinterpret_cast<const uint4*>(p.g2 + o);
         rx[i] = *reinterpret_cast<const uint4*>(p.r + o);
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
       }
       if (ch < nch) {
         const size_t o = (size_t)row * p.C + ch * 8;
+        __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
         float a[8], x[8];
         unpack8(ca[i], a);
         if (p.g2) {
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
       const int ch = lane + 64 * i;
       if (ch < nch) {
         const size_t o = (size_t)row * p.C + ch * 8;
+        __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
         float d[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = rstd * (dyv[i][k] - s1 - xh[i][k] * s2);
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxP
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const size_t o = (size_t)row * p.ld + ch * 8;
+      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       float pr[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) pr[k] = v[i][k] * inv;
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
     }
     if (ch < nch) {
       const size_t o = (size_t)row * p.ld + ch * 8;
+      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       float g[8];
       unpack8(*reinterpret_cast<const uint4*>(p.P + o), pr[i]);
       unpack8(*reinterpret_cast<const uint4*>(p.dPd + o), g);
@@ -527,7 +534,9 @@ __global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restri
   }
 }
 
-uint32_t thresh_of(float p) { return p <= 0.f ? 0u : (uint32_t)fminf(4294967295.f, p * 4294967296.f); }
+// 16-bit dropout threshold and the scale of the probability it realises
+uint32_t thresh_of(float p) { return p <= 0.f ? 0u : (uint32_t)fminf(65535.f, roundf(p * 65536.f)); }
+float scale_of(float p) { return p <= 0.f ? 1.f : 1.f / (1.f - (float)thresh_of(p) / 65536.f); }
 
 }  // namespace
 
@@ -539,8 +548,8 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
   LnFwdParams p{y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
-                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f,
-                mid.stream, thresh_of(mid.p), mid.p > 0.f ? 1.f / (1.f - mid.p) : 1.f, post_gelu ? 1 : 0};
+                scale_of(pre.p), scale_of(post.p),
+                mid.stream, thresh_of(mid.p), scale_of(mid.p), post_gelu ? 1 : 0};
   const int grid = ssak_cdiv(M, ROW_THREADS / 64);
   const int nch = ssak_cdiv(C / 8, 64);
   if (nch == 1)
@@ -561,8 +570,8 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   SSAK_REQUIRE(!dy_colsum || dy, "layernorm_bwd: the dy column sum needs the dy output");
   LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, M, C, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
-                pre.p > 0.f ? 1.f / (1.f - pre.p) : 1.f, post.p > 0.f ? 1.f / (1.f - post.p) : 1.f, 1,
-                mid.stream, thresh_of(mid.p), mid.p > 0.f ? 1.f / (1.f - mid.p) : 1.f};
+                scale_of(pre.p), scale_of(post.p), 1,
+                mid.stream, thresh_of(mid.p), scale_of(mid.p)};
   // LN_BWD_BLOCKS workgroups of 4 waves stride over the rows and keep column partials in registers
   p.rows_per_wave = 0;
   const int grid = std::min(LN_BWD_BLOCKS, ssak_cdiv(M, ROW_THREADS / 64));
@@ -583,7 +592,7 @@ int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int ro
                   int rows_per_batch, const DropSpec& drop, hipStream_t st) {
   SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld & 7) == 0 && ld <= 1536, "softmax: cols=%d ld=%d unsupported (ld %% 8 == 0, <= 1536)", cols, ld);
   SoftmaxParams p{S, P, Pd, klens, rows, cols, ld, rows_per_batch, drop.seed, drop.stream, thresh_of(drop.p),
-                  drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f};
+                  scale_of(drop.p)};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
   const int nch = ssak_cdiv(ld / 8, 64);
   if (nch == 1)
@@ -600,7 +609,7 @@ int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, 
                   hipStream_t st) {
   SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld & 7) == 0 && ld <= 1536, "softmax_bwd: cols=%d ld=%d unsupported", cols, ld);
   SoftmaxBwdParams p{dPd, P, dS, rows, cols, ld, drop.seed, drop.stream, thresh_of(drop.p),
-                     drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f};
+                     scale_of(drop.p)};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
   const int nch = ssak_cdiv(ld / 8, 64);
   if (nch == 1)
