@@ -468,20 +468,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
           }
         }
 #pragma unroll
-        for (int qh = 0; qh < 2; ++qh)
+        for (int qh = 0; qh < 2; ++qh) {
+          // Dropout words of this lane's 4 queries x 2 keys.  A word covers a key PAIR and the pair sits in two adjacent
+          // lanes, so each lane hashes two of the four query rows and takes the other two from its partner by DPP
+          // (half the hashes of one-per-element; the hash was a quarter of this kernel's VALU work).
+          uint32_t W[2][4];
+          if (p.thresh16) {
+            const uint32_t half = (uint32_t)(p.Fp >> 1);
+            const uint32_t par = lane & 1;
+            // rowbase(q) = ((b * nh + h) * F + q) * half without the clamp of drop_rowbase: rows >= F are masked below
+            const uint32_t rb = ((uint32_t)(b * p.nh + h) * (uint32_t)F + (uint32_t)(qq0 + 16 * (2 * t2 + qh) + 4 * g) + par) * half;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const uint32_t kp = (uint32_t)(krow[ks] >> 1);
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const uint32_t mine = hash_u32(p.seed, p.stream, (uint64_t)(rb + (uint32_t)(2 * i) * half + kp));  // row par + 2i
+                const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);  // row 1 - par + 2i
+                W[ks][2 * i] = par ? other : mine;
+                W[ks][2 * i + 1] = par ? mine : other;
+              }
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int ql = 16 * (2 * t2 + qh) + 4 * g + r;  // query inside the tile
             const int q = qq0 + ql;
             const float ls = lse_s[ql], dl = dl_s[ql];
             const bool rowok = q < F && ls > -INFINITY;
-            const uint32_t rowbase = drop_rowbase(p, b, h, q);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
               const int key = krow[ks];
               float keep = 1.f;
               if (p.thresh16) {
-                const uint32_t w = drop_word(p, rowbase, key);
+                const uint32_t w = W[ks][r];
                 const uint32_t u = (key & 1) ? (w >> 16) : (w & 0xffffu);
                 keep = (u >= p.thresh16) ? p.drop_scale : 0.f;
               }
@@ -491,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
               dp[ks][qh][r] = pr * (dpv - dl) * p.scale;   // dS
             }
           }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           pdb[ks] = pack_p(s[ks][0], s[ks][1]);

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")
+_LIB_PATH = os.environ.get("SSAK_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")  # (the override is for A/B runs of two builds)
 
 
 class GemmDesc(C.Structure):
