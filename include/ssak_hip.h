@@ -75,6 +75,23 @@ int ssak_ctc_loss_fwd_bwd(const float* logits, const int32_t* in_lens, const int
 int ssak_ctc_greedy_decode(const float* logits, const int32_t* in_lens, int B, int F, int V, int blank, int32_t* ids,
                            int32_t* out_lens, void* stream);
 
+/* ---- f2: audio ingest (PCM decode, mono mix, sample-rate conversion) ---------------------------
+ * Replaces load_audio / conform_audio of ssak/utils/audio.py:24-154 for PCM input, reached from the Kaldi-folder loader
+ * (ssak/utils/dataset.py:27-424,630-645): the segment cut is a byte range chosen by the caller (offset = int(start*sr),
+ * audio.py:85-92), channels are averaged (librosa.to_mono, :118) and the rate change is torchaudio.transforms.Resample
+ * with its defaults (:134): Hann-windowed sinc interpolation, lowpass_filter_width 6, rolloff 0.99.
+ * ssak_pcm_to_mono_f32: raw = interleaved little-endian PCM bytes of all utterances (device), byte_offsets [B] int64 /
+ *   nframes [B] int32 (device), sample_width in bytes (1 unsigned, 2 / 4 signed) -> out [B, Tmax] fp32, zero padded.
+ * ssak_resample_plan / _table (host): reduced rates, filter half-width and taps; table [new_r][taps] fp32 computed in
+ *   double like torchaudio's kernel.  ssak_resample_sinc: in [B, Tin] (in_lens [B] or NULL) -> out [B, Tout] with
+ *   out_lens[b] = ceil(new_r * len / orig_r) valid samples (0 beyond); table on the device. */
+int ssak_pcm_to_mono_f32(const void* raw, const int64_t* byte_offsets, const int32_t* nframes, int B, int channels, int sample_width,
+                         int Tmax, float* out, void* stream);
+int ssak_resample_plan(int orig_sr, int new_sr, int* orig_r, int* new_r, int* width, int* taps);
+int ssak_resample_table(int orig_sr, int new_sr, float* table /*host*/);
+int ssak_resample_sinc(const float* in, const int32_t* in_lens, int B, int Tin, int orig_sr, int new_sr, const float* table /*device*/,
+                       float* out, int Tout, int32_t* out_lens, void* stream);
+
 /* ---- f3: word error counts for the evaluation step ---------------------------------------------
  * Replaces compute_metrics of ssak/train/transformers/wav2vec_train.py:110-125 after the argmax (ssak_ctc_greedy_decode):
  * batch_decode of predictions and (ungrouped) labels, remove_special_words(glue_apostrophe=False), the "wer" metric.

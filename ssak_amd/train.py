@@ -147,10 +147,20 @@ def main(argv=None):
                                  mask_time_prob=args.mask_time_prob, layerdrop=args.layer_dropout,
                                  ctc_loss_reduction="mean", ctc_zero_infinity=True, pad_token_id=tok_pad(args.base_model))
     model.train()
-    tw, tl = prepare(train_u, tok)
+    # --online (wav2vec_train.py:148: audio loaded on the fly instead of up front): file reads on a background thread, PCM
+    # decode / mono mix / resampling / normalisation on the device (ssak_amd.ingest)
+    if args.online:
+        from .ingest import BatchPrefetcher, DeviceIngest
+        ingest = DeviceIngest(16000, dev)
+        tw = None
+        tl = [tok.encode(remove_special_words(u.text)) for u in train_u]
+        train_len = [int(u.duration * 16000) for u in train_u]
+    else:
+        tw, tl = prepare(train_u, tok)
+        train_len = [len(w) for w in tw]
     vw, vl = prepare(valid_u, tok)
-    steps_per_epoch = max(1, len(tw) // args.batch_size)
-    total = round(args.num_epochs * len(tw) / args.batch_size)
+    steps_per_epoch = max(1, len(tl) // args.batch_size)
+    total = round(args.num_epochs * len(tl) / args.batch_size)
     opt = AdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay, warmup_steps=500, total_steps=max(total, 1))
     trainer = Trainer(model, opt)
     trainer.broadcast_parameters()
@@ -164,16 +174,19 @@ def main(argv=None):
     use_mask = model.config.feat_extract_norm == "layer"
     step, t0, run_loss = 0, time.time(), []
     while step < total:
-        for idx in length_grouped_batches([len(w) for w in tw], args.batch_size, rng):
-            if step >= total:
-                break
-            mine = shard_batch(idx, rank, world) if world > 1 else idx
-            if not mine:
-                continue
-            x, lens = pad_waves([tw[i] for i in mine])
+        plan = [shard_batch(idx, rank, world) if world > 1 else idx for idx in length_grouped_batches(train_len, args.batch_size, rng)]
+        plan = [m for m in plan if m][:total - step]
+        if args.online:
+            feed = BatchPrefetcher(ingest, [[(train_u[i].path, train_u[i].start or None, train_u[i].end or None) for i in m] for m in plan])
+        else:
+            feed = (pad_waves([tw[i] for i in m]) for m in plan)
+        for mine, (x, lens) in zip(plan, feed):
             lab = pad_labels([tl[i] for i in mine])
-            loss = trainer.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(lens).to(dev),
-                                      torch.from_numpy(lab).to(dev))
+            if args.online:  # already on the device and normalised
+                loss = trainer.train_step(x, lens, torch.from_numpy(lab).to(dev), raw=False)
+            else:
+                loss = trainer.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(lens).to(dev),
+                                          torch.from_numpy(lab).to(dev))
             run_loss.append(loss)
             step += 1
             if step % args.eval_steps == 0 or step == total:

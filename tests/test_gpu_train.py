@@ -124,6 +124,17 @@ def test_train_and_infer_cli_on_kaldi_folder(tmp_path):
     evals = [e["eval_loss"] for e in st["log_history"] if "eval_loss" in e]
     assert st["global_step"] == 40 and len(train_losses) == 2 and train_losses[1] < train_losses[0]
     assert evals[-1] < json.load(open(run / "init_eval.json"))["eval_loss"]
+    # --online: the same training with audio read on the fly and decoded / normalised on the device (ssak_amd.ingest)
+    # must follow the same loss trajectory (same seed, same batches; dropout is off in this config)
+    r = subprocess.run([sys.executable, "-m", "ssak_amd.train", str(kd), str(kd), "--base_model", str(tmp_path / "base"),
+                        "--batch_size", "4", "--num_epochs", "20", "--eval_steps", "20", "--learning_rate", "3e-3", "--online",
+                        "--min_duration", "0", "--output_dir", str(tmp_path / "out_online")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run2 = tmp_path / "out_online" / os.listdir(tmp_path / "out_online")[0]
+    st2 = json.load(open(run2 / "checkpoint-40" / "trainer_state.json"))
+    losses2 = [e["loss"] for e in st2["log_history"] if "loss" in e]
+    assert len(losses2) == 2 and losses2[1] < losses2[0]
     r = subprocess.run([sys.executable, "-m", "ssak_amd.infer", str(kd), "--model", str(run / "final"), "--use_ids",
                         "--batch_size", "3", "--output", str(tmp_path / "hyp.txt")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -211,3 +211,25 @@ def test_wer_oracle_known_answers():
     lab2 = enc("hello word") + [-100] * 6
     e, n, wer = wer_ref.compute_metrics([pred, pred], [lab, lab2], VOCAB, 0)
     assert e.tolist() == [1, 0] and n.tolist() == [2, 2] and wer == 0.25
+
+
+# ------------------------------------------------------------------ audio ingest
+@pytest.mark.parametrize("orig,new", [(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000)])
+def test_resample_oracle_properties(orig, new):
+    """torchaudio is absent (parity unpinned): the restated sinc resampler is held to its defining properties."""
+    from oracle import resample_ref
+    n = orig // 2  # half a second
+    t = np.arange(n) / orig
+    f0 = 440.0
+    x = (0.5 * np.sin(2 * np.pi * f0 * t + 0.3)).astype(np.float32)
+    y = resample_ref.resample(x, orig, new)
+    assert len(y) == int(np.ceil(new * n / orig))
+    ty = np.arange(len(y)) / new
+    want = 0.5 * np.sin(2 * np.pi * f0 * ty + 0.3)
+    core = slice(200, len(y) - 200)  # away from the zero-padded edges
+    assert np.abs(y[core] - want[core]).max() < 2e-3
+    dc = resample_ref.resample(np.ones(n, np.float32), orig, new)
+    assert np.abs(dc[core] - 1.0).max() < 2e-3  # unit DC gain (rolloff 0.99 leaves < 0.2 % ripple)
+    assert np.array_equal(resample_ref.resample(x, new, new), x)
+    k, width, o, nn = resample_ref.sinc_resample_kernel(orig, new)
+    assert k.shape == (nn, 1, 2 * width + o)
