@@ -150,6 +150,9 @@ typedef struct {
   int pads_are_zero; /* caller guarantees that elements between the logical extent and the next multiple of 8
                         (K for K-contiguous operands, rows for K-major ones) are zero in memory: lets operands whose
                         extent is not a multiple of 8 (e.g. 499 frames) take the direct-to-LDS path */
+  int colsum; /* != 0: `aux_out` is a float [N] vector that receives += the column sums of the stored C (after the epilogue:
+                 the bias gradient of the Linear that produced the GEMM's A operand side), summed in a fixed order;
+                 needs workspace >= ceil(M / 64) * N * 4 bytes; not with SSAK_EPI_GELU, split_k or batches */
 } ssak_gemm_desc;
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);

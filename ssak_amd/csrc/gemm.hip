@@ -722,6 +722,15 @@ int dispatch_layout(const GemmParams& p, int a_km, int b_km, bool dma, hipStream
 }
 
 
+// out[n] += sum over slots of partial[slot][n], fixed order (the column sums the epilogues left per wave-tile row)
+__global__ __launch_bounds__(256) void colsum_slots_kernel(const float* __restrict__ partial, int slots, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < slots; ++k) s += partial[(long)k * N + n];
+  out[n] += s;
+}
+
 // ---- kernel / tile / split-K selection ---------------------------------------------------------------------------
 // A small cost model in microseconds (constants fitted to tools/bench_gemm.py and tools/probes/p8_probe.hip on the
 // Wav2Vec2-base train-step shapes, MI355X): a workgroup costs a fixed prologue + epilogue plus a per-K-tile time, the
@@ -804,6 +813,18 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     fprintf(stderr, "gemm M=%d N=%d K=%d akm=%d bkm=%d nb=%dx%d epi=%d f32=%d acc=%d drop=%g dma=%d -> %s bm=%d split=%d cost=%.1f\n", d->M,
             d->N, d->K, d->a_kmajor, d->b_kmajor, d->nb1, d->nb2, d->epilogue, d->out_f32, d->accumulate, d->drop_p, (int)dma,
             plan.p8 ? "p8" : "tile128", plan.bm, plan.split, plan.cost);
+  // column sums of C (desc.colsum): fused into the LDS-free epilogue of the 256-wide kernel when every tile takes it,
+  // otherwise a separate pass over the stored bf16 C
+  float* colsum_out = nullptr;
+  bool colsum_fused = false;
+  if (d->colsum) {
+    SSAK_REQUIRE(aux_out && d->epilogue != SSAK_EPI_GELU && d->nb1 == 1 && d->nb2 == 1 && d->split_k <= 1 && !d->out_f32,
+                 "gemm: colsum needs aux_out = float[N], a bf16 C, no batches / split_k / GELU side output");
+    colsum_out = reinterpret_cast<float*>(aux_out);
+    aux_out = nullptr;
+    colsum_fused = plan.p8 && plan.split == 1 && (d->N % 256) == 0 && (d->ldc & 7) == 0 && workspace &&
+                   workspace_bytes >= (size_t)ssak_cdiv(d->M, 64) * d->N * sizeof(float);
+  }
   GemmParams p;
   p.A = (const bf16*)A;
   p.B = (const bf16*)B;
@@ -837,6 +858,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   p.drop_stream = d->drop_stream;
   p.drop_seed = d->drop_seed;
   p.bias_s2 = d->bias_s2;
+  p.colsum = nullptr;
   SSAK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p must be in [0,1)");
   SSAK_REQUIRE(!(d->drop_p > 0.f && d->split_k > 1), "gemm: dropout epilogue is not available with split_k");
   const int nkt = ssak_cdiv(d->K, BK);
@@ -861,6 +883,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   }();
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
   const int p8_bm = plan.bm;
+  if (colsum_fused) p.colsum = (float*)workspace;
   if (plan.p8) {
     p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
@@ -896,6 +919,15 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     splitk_reduce_kernel<<<blocks, 256, 0, st>>>(p);
     SSAK_LAUNCH_CHECK();
+  }
+  if (colsum_out) {
+    if (colsum_fused) {
+      const int slots = 2 * ssak_cdiv(d->M, p8_bm);  // (tile row, wave row) pairs, wave tiles of p8_bm / 2 rows
+      colsum_slots_kernel<<<ssak_cdiv(d->N, 256), 256, 0, st>>>((const float*)workspace, slots, d->N, colsum_out);
+      SSAK_LAUNCH_CHECK();
+    } else {
+      return k_colsum((const bf16*)C, d->ldc, d->M, d->N, colsum_out, st);
+    }
   }
   return SSAK_OK;
 }

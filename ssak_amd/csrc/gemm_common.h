@@ -28,6 +28,7 @@ struct GemmParams {
   uint64_t drop_seed;
   long bias_s2;
   uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
+  float* colsum;          // [wave-tile rows][N] column sums of the stored values (bias gradient of the producing Linear) or null
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -292,7 +293,7 @@ __device__ __forceinline__ void xpose4(uint32_t& r0, uint32_t& r1, uint32_t& r2,
 }
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // store 16 rows x 64 columns of bf16 held as v[j][r] (accumulator layout) at dst + row lm, columns 16*lq..
-__device__ __forceinline__ void store_bf16_rows(bf16* dst_lane /* + row lm, + 16*lq */, const float (&v)[4][4]) {
+__device__ __forceinline__ void store_bf16_rows(bf16* dst_lane /* + row lm, + 16*lq */, const float (&v)[4][4], bool rowok = true) {
   uint32_t lo[4], hi[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -303,30 +304,36 @@ __device__ __forceinline__ void store_bf16_rows(bf16* dst_lane /* + row lm, + 16
   }
   xpose4(lo[0], lo[1], lo[2], lo[3]);
   xpose4(hi[0], hi[1], hi[2], hi[3]);
-  *reinterpret_cast<u32x4*>(dst_lane) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
-  *reinterpret_cast<u32x4*>(dst_lane + 8) = (u32x4){lo[2], hi[2], lo[3], hi[3]};
+  if (rowok) {  // (after the swaps: those need every lane)
+    *reinterpret_cast<u32x4*>(dst_lane) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+    *reinterpret_cast<u32x4*>(dst_lane + 8) = (u32x4){lo[2], hi[2], lo[3], hi[3]};
+  }
 }
 // true when the wave tile [wm0, wm0 + rows) x [wn0, wn0 + 64) of this workgroup can take gemm_epilogue_direct
 __device__ __forceinline__ bool epilogue_direct_ok(const GemmParams& p, int bm0, int bn0, int wm0, int wn0, int rows, long coff) {
-  return bm0 + wm0 + rows <= p.M && bn0 + wn0 + 64 <= p.N && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (coff & 7) == 0 &&
+  (void)rows;  // tile rows beyond M are masked per lane by the epilogue itself
+  return bn0 + wn0 + 64 <= p.N && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (coff & 7) == 0 &&
          (((uintptr_t)p.aux_in | (uintptr_t)p.aux_out | (uintptr_t)p.C) & 15) == 0;
 }
 template <int MI>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 (&acc)[MI][4], const BiasRegs<4>& br, int bm0,
                                                      int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split) {
   const int lm = lane & 15, lq = lane >> 4;
+  const int rows_valid = p.M - (bm0 + wm0 + lm);  // this lane's row 16 * i + lm exists iff 16 * i < rows_valid
   if (p.split_k > 1) {  // raw partial sums into this split's slab
     float* S = p.slab + ((long)split * p.nz + z) * (long)p.M * p.N + (long)(bm0 + wm0 + lm) * p.N + bn0 + wn0 + 4 * lq;
     const long step = 16L * p.N;
 #pragma unroll
     for (int i = 0; i < MI; ++i, S += step)
+      if (16 * i < rows_valid) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(S + 16 * j) = acc[i][j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(S + 16 * j) = acc[i][j];
+      }
     return;
   }
   long orow = z1 * p.sc1 + z2 * p.sc2 + (long)(bm0 + wm0 + lm) * p.ldc + bn0 + wn0;  // row lm of the 16-row group, column 0
   const long step = 16L * p.ldc;
-  const bool plain = p.epilogue == SSAK_EPI_NONE && !p.drop_thresh;
+  const bool plain = p.epilogue == SSAK_EPI_NONE && !p.drop_thresh && !p.colsum;
   if (plain && !p.out_f32) {
 #pragma unroll
     for (int i = 0; i < MI; ++i, orow += step) {
@@ -335,14 +342,20 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] * p.alpha + br.v[j][r];
-      store_bf16_rows(reinterpret_cast<bf16*>(p.C) + orow + 16 * lq, v);
+      store_bf16_rows(reinterpret_cast<bf16*>(p.C) + orow + 16 * lq, v, 16 * i < rows_valid);
       __builtin_amdgcn_sched_barrier(0);  // keep the 16-row groups apart: hoisted addresses cost registers
     }
     return;
   }
+  float cs[4][4];  // column sums over this lane's rows (p.colsum)
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i, orow += step) {
     __builtin_amdgcn_sched_barrier(0);
+    const bool rowok = 16 * i < rows_valid;
     const long oa = orow + 4 * lq;  // this lane's chunk of column group j: oa + 16 * j
     float v[4][4];
 #pragma unroll
@@ -350,7 +363,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] * p.alpha + br.v[j][r];
     if (p.epilogue == SSAK_EPI_GELU) {
-      if (p.aux_out) store_bf16_rows(p.aux_out + orow + 16 * lq, v);
+      if (p.aux_out) store_bf16_rows(p.aux_out + orow + 16 * lq, v, rowok);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -362,7 +375,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
     } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
       bf16x4 a[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const bf16x4*>(p.aux_in + oa + 16 * j);
+      for (int j = 0; j < 4; ++j) a[j] = rowok ? *reinterpret_cast<const bf16x4*>(p.aux_in + oa + 16 * j) : (bf16x4){};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -383,16 +396,44 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
         v[j][3] = ((w1 >> 16) >= p.drop_thresh) ? v[j][3] * p.drop_scale : 0.f;
       }
     }
+    if (p.colsum) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[j][r] += rowok ? v[j][r] : 0.f;
+    }
     if (p.out_f32) {
       float* dst = reinterpret_cast<float*>(p.C) + oa;
+      if (rowok) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 t = {v[j][0], v[j][1], v[j][2], v[j][3]};
-        if (p.accumulate) t += *reinterpret_cast<const f32x4*>(dst + 16 * j);
-        *reinterpret_cast<f32x4*>(dst + 16 * j) = t;
+        for (int j = 0; j < 4; ++j) {
+          f32x4 t = {v[j][0], v[j][1], v[j][2], v[j][3]};
+          if (p.accumulate) t += *reinterpret_cast<const f32x4*>(dst + 16 * j);
+          *reinterpret_cast<f32x4*>(dst + 16 * j) = t;
+        }
       }
     } else {
-      store_bf16_rows(reinterpret_cast<bf16*>(p.C) + orow + 16 * lq, v);
+      store_bf16_rows(reinterpret_cast<bf16*>(p.C) + orow + 16 * lq, v, rowok);
+    }
+  }
+  if (p.colsum) {
+    // sum over the 16 lanes of a row group (the wave tile's rows), fixed order; lane lm == 0 of each group writes the
+    // 16 columns 16 * j + 4 * lq .. of its slot = (tile row, wave row); a small kernel adds the slots up afterwards
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = cs[j][r];
+        s += dpp_f<0xB1, 0xf>(0.f, s);
+        s += dpp_f<0x4E, 0xf>(0.f, s);
+        s += dpp_f<0x141, 0xf>(0.f, s);
+        s += dpp_f<0x140, 0xf>(0.f, s);
+        cs[j][r] = s;
+      }
+    if (lm == 0) {
+      float* dst = p.colsum + (long)((bm0 + wm0) / (16 * MI)) * p.N + bn0 + wn0 + 4 * lq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + 16 * j) = (f32x4){cs[j][0], cs[j][1], cs[j][2], cs[j][3]};
     }
   }
 }

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
   };
   // vector-memory instructions the LDS-free epilogue issues per wave (stores only; vmcnt counts them like the DMA)
   const int epi_vm = (p.split_k > 1 || p.out_f32 || (p.epilogue == SSAK_EPI_GELU && p.aux_out)) ? 8 * MH : 4 * MH;
-  const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD;  // epilogues that only store
+  const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD && !p.colsum;  // epilogues that only store (a fixed count)
 
   // Persistent over tiles (the host launches one workgroup per CU).  The next tile's first two K tiles are put in
   // flight BEFORE the current tile's epilogue, and the epilogue's stores are left to drain under the next main loop:
@@ -373,12 +373,13 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
       pe.M = grp.pr[c.g].M;
       pe.N = grp.pr[c.g].N;
     }
-    const bool interior = c.bm0 + BM <= pe.M && c.bn0 + 256 <= pe.N &&
-                          epilogue_direct_ok(pe, c.bm0, c.bn0, 0, 0, BM, c.z1 * p.sc1 + c.z2 * p.sc2);
+    // "interior" = every wave can take the LDS-free epilogue (whole 256 columns; rows beyond M are masked per lane there)
+    const bool interior = c.bn0 + 256 <= pe.N && epilogue_direct_ok(pe, c.bm0, c.bn0, 0, 0, BM, c.z1 * p.sc1 + c.z2 * p.sc2);
     primed = false;
     if (t + (int)gridDim.x < ntiles) {
       cur_t = decode(t + gridDim.x);
-      if (interior && epi_early) {
+      // early priming counts on the epilogue issuing exactly epi_vm stores per wave: only for tiles with all their rows
+      if (interior && epi_early && c.bm0 + BM <= pe.M) {
         prime(cur_t);
         primed = true;
       }

@@ -462,6 +462,12 @@ struct Gemm {
     d.alpha = a_;
     return *this;
   }
+  // += column sums of the stored C into `out` [N] (run() must be given a workspace of ceil(M / 64) * N floats)
+  Gemm& colsum(float* out) {
+    d.colsum = 1;
+    aux_out = out;
+    return *this;
+  }
   Gemm& drop(float p, uint32_t stream, uint64_t seed) {
     d.drop_p = p;
     d.drop_stream = stream;
@@ -979,9 +985,9 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     const bf16* dy2 = dY;
     wq.push(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
     TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
-            .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed).run(st));
+            .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed)
+            .colsum(Gd + L.b1).run(st, slab, p.slab_bytes));  // b1's gradient = column sums of dI, taken in the epilogue
     wq.push(Gemm(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
-    TRY(k_colsum(dI, I, M, I, Gd + L.b1, st));
     bf16* dX = BF(p.dB);
     TRY(Gemm(M, H, I).a(dI, I).b(W + L.w1, H, true).c(dX, H).run(st));
     bf16* dR1;

@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):
                 ("sa1", C.c_long), ("sa2", C.c_long), ("sb1", C.c_long), ("sb2", C.c_long), ("sc1", C.c_long),
                 ("sc2", C.c_long), ("alpha", C.c_float), ("epilogue", C.c_int), ("out_f32", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
-                ("drop_seed", C.c_uint64), ("bias_s2", C.c_long), ("pads_are_zero", C.c_int)]
+                ("drop_seed", C.c_uint64), ("bias_s2", C.c_long), ("pads_are_zero", C.c_int), ("colsum", C.c_int)]
 
 
 class W2V2Config(C.Structure):
@@ -216,13 +216,16 @@ def ctc_wer(hyp_ids: torch.Tensor, hyp_lens: torch.Tensor, labels: torch.Tensor,
 
 def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
-         accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0, pads_are_zero=False):
+         accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0, pads_are_zero=False, colsum_out=None):
     """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h)."""
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
                  sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k, float(drop_p),
-                 drop_stream, drop_seed, 0, int(pads_are_zero))
+                 drop_stream, drop_seed, 0, int(pads_are_zero), int(colsum_out is not None))
     n_slabs = split_k if split_k > 0 else max(1, min(32, ((K + 63) // 64) // 4))  # 0 = library-sized split
     ws = _ws(n_slabs * nb1 * nb2 * M * N * 4, A.device) if n_slabs > 1 else None
+    if colsum_out is not None:
+        aux_out = colsum_out
+        ws = _ws(((M + 63) // 64) * N * 4, A.device)
     check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
                              0 if ws is None else ws.numel(), stream()))
     return C_out
@@ -236,7 +239,7 @@ def gemm_grouped(problems, stream_=None):
     pa, pb, pc = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
     for i, (A, B, Cout, M, N, K, lda, ldb, ldc, akm, bkm) in enumerate(problems):
         descs[i] = GemmDesc(M, N, K, int(akm), int(bkm), lda, ldb, ldc, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0,
-                            int(Cout.dtype == torch.float32), 0, 1, 0.0, 0, 0, 0, 1)
+                            int(Cout.dtype == torch.float32), 0, 1, 0.0, 0, 0, 0, 1, 0)
         pa[i], pb[i], pc[i] = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
     check(lib.ssak_gemm_bf16_grouped(descs, n, pa, pb, pc, stream()))
 

@@ -23,6 +23,6 @@ def test_library_exports_header_symbols():
 def test_binding_rejects_without_gpu_compute():
     import ssak_amd.hip as h
     # argument validation happens on the host, before any launch
-    d = h.GemmDesc(0, 8, 8, 0, 0, 8, 8, 8, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0, 1, 0, 1, 0.0, 0, 0, 0, 0)
+    d = h.GemmDesc(0, 8, 8, 0, 0, 8, 8, 8, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0, 1, 0, 1, 0.0, 0, 0, 0, 0, 0)
     rc = h.lib.ssak_gemm_bf16(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
     assert rc == h.SSAK_ERR_INVALID and b"null" in h.lib.ssak_last_error()

@@ -429,3 +429,24 @@ def test_gemm_grouped_exact(hip, a_km, b_km):
     for (A, B, Cc, M, N, *_), ref in zip(probs, refs):
         assert torch.equal(Cc[:, :N].cpu(), ref), (M, N, (Cc[:, :N].cpu() - ref).abs().max())
         assert (Cc[:, N:] == -7.0).all()
+
+
+@pytest.mark.parametrize("M,N", [(1000, 512), (15968, 768), (700, 200)])
+def test_gemm_fused_column_sums(hip, M, N):
+    """desc.colsum: the bias gradient (column sums of the stored C, after GELU' and dropout) comes out of the GEMM -- fused
+    into the epilogue for 256-column tilings (M-edge tile rows masked), a separate pass otherwise; += semantics."""
+    g = torch.Generator().manual_seed(M + N)
+    K = 256
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    B = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    pre = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    Cg = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    cs = torch.full((N,), 3.0, dtype=torch.float32).cuda()
+    hip.gemm(A, B, Cg, M, N, K, lda=K, ldb=K, ldc=N, epilogue=hip.EPI_MUL_GELU_GRAD, aux_in=pre, drop_p=0.1, drop_stream=5,
+             drop_seed=77, colsum_out=cs)
+    C2 = torch.empty_like(Cg)
+    hip.gemm(A, B, C2, M, N, K, lda=K, ldb=K, ldc=N, epilogue=hip.EPI_MUL_GELU_GRAD, aux_in=pre, drop_p=0.1, drop_stream=5, drop_seed=77)
+    assert torch.equal(Cg, C2)  # the side output does not change C
+    want = C2.float().sum(0) + 3.0
+    tol = 2e-3 * C2.float().abs().sum(0) + 1e-3  # C2 is the bf16 rounding of what was summed in fp32
+    assert bool(((cs - want).abs() <= tol).all()), float((cs - want).abs().max())
