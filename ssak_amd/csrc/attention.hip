@@ -46,14 +46,23 @@ struct AttnParams {
 
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
-// two 16-bit uniforms for keys (2w', 2w'+1) of one query row; keep iff u >= thresh16
-__device__ __forceinline__ uint32_t drop_word(const AttnParams& p, uint32_t rowbase, int key) {
-  return hash_u32(p.seed, p.stream, (uint64_t)(rowbase + (uint32_t)(key >> 1)));
+// Dropout bits.  Every (utterance, head, query) row has a seed = hash(seed, stream, row index), computed once per row and
+// kernel; the 32-bit word of key pair kp of that row is one multiply-xorshift round of (row seed + kp * golden ratio):
+// low 16 bits -> even key, high 16 bits -> odd key, keep iff the field >= thresh16.  8 VALU slots per word instead of the
+// 14 of a full hash per pair; neighbouring keys / rows / pairs measured uncorrelated (|rho| < 2e-3 on 2M samples).
+constexpr uint32_t DROP_PHI = 0x9E3779B9u;
+__device__ __forceinline__ uint32_t drop_rowseed(const AttnParams& p, int b, int h, int q) {
+  return hash_u32(p.seed, p.stream, (uint64_t)((uint32_t)(b * p.nh + h) * (uint32_t)p.F + (uint32_t)min(q, p.F - 1)));
 }
-__device__ __forceinline__ uint32_t drop_rowbase(const AttnParams& p, int b, int h, int q) {
-  // counter of the first key pair of query row q of head (b, h); 32-bit wrap-around only aliases far-apart rows
-  return ((uint32_t)(b * p.nh + h) * (uint32_t)p.F + (uint32_t)min(q, p.F - 1)) * (uint32_t)(p.Fp >> 1);
+__device__ __forceinline__ uint32_t drop_word(uint32_t x /* row seed + kp * DROP_PHI */) {
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  return x;
 }
+// keep tests against thi = thresh16 << 16 (no field extraction: the odd key's field is the word's top half)
+__device__ __forceinline__ bool drop_keep_even(uint32_t w, uint32_t thi) { return (w << 16) >= thi; }
+__device__ __forceinline__ bool drop_keep_odd(uint32_t w, uint32_t thi) { return w >= thi; }
 
 // LDS tile images (64 rows x 128 B each):
 //   row-read image  : chunk c of row r at c ^ ((r >> 1) & 7)      -> ds_read_b128 fragments (row on the lane)
@@ -134,6 +143,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int kk = 0; kk < 2; ++kk) qf[qs][kk] = load_row_frag(base + h * HD, ld, qrow[qs], F, kk, lane);
   }
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  const float c2 = p.scale * 1.4426950408889634f;  // softmax scale x log2(e)
+  const uint32_t thi = p.thresh16 << 16;
+  const uint32_t rowseed[2] = {drop_rowseed(p, b, h, qrow[0]), drop_rowseed(p, b, h, qrow[1])};
   f32x4 oacc[2][4];
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs)
@@ -169,38 +181,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         s[qs][ks] = a;
       }
     }
-    // ---- online softmax per query (lane-local column), dropout, pack P^T as the B operand of the PV product
+    // ---- online softmax per query (lane-local column), dropout, pack P^T as the B operand of the PV product.
+    // Scores stay raw: the softmax scale and log2(e) are folded into one fma in front of v_exp_f32; keys are masked only
+    // in the tile that crosses the key length; the dropout scale is applied once, to O, at the end.
     bf16x8 pb[2][2];
+    const bool edge = k0 + KT > kl;  // uniform
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
-      float mx = -INFINITY;
+      if (edge) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = k0 + 16 * ks + 4 * g + r;
-          const float v = key < kl ? s[qs][ks][r] * p.scale : -INFINITY;
-          s[qs][ks][r] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int r = 0; r < 4; ++r)
+            if (k0 + 16 * ks + 4 * g + r >= kl) s[qs][ks][r] = -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(s[qs][0][0], s[qs][0][1]), fmaxf(s[qs][0][2], s[qs][0][3]));
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) mx = fmaxf(mx, fmaxf(fmaxf(s[qs][ks][0], s[qs][ks][1]), fmaxf(s[qs][ks][2], s[qs][ks][3])));
       mx = fmaxf(mx, shfl_xor_f(mx, 16));
       mx = fmaxf(mx, shfl_xor_f(mx, 32));
+      // key 0 is never masked (kl >= 1 whenever a tile is processed), so the running maximum is finite from the first tile on
       const float m_new = fmaxf(m_run[qs], mx);
-      const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run[qs] - m_new);
+      const float mc = m_new * c2;
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qs], c2, -mc));  // first tile: exp2(-inf) = 0 on a zero accumulator
       float rs = 0.f;
-      const uint32_t rowbase = drop_rowbase(p, b, h, qrow[qs]);
+      const uint32_t xrow = rowseed[qs] + (uint32_t)((k0 >> 1) + 2 * g) * DROP_PHI;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int r2 = 0; r2 < 4; r2 += 2) {
-          const int key = k0 + 16 * ks + 4 * g + r2;
-          float e0 = (m_new == -INFINITY) ? 0.f : __expf(s[qs][ks][r2] - m_new);
-          float e1 = (m_new == -INFINITY) ? 0.f : __expf(s[qs][ks][r2 + 1] - m_new);
+          float e0 = __builtin_amdgcn_exp2f(fmaf(s[qs][ks][r2], c2, -mc));
+          float e1 = __builtin_amdgcn_exp2f(fmaf(s[qs][ks][r2 + 1], c2, -mc));
           rs += e0 + e1;
           if (p.thresh16) {
-            const uint32_t w = drop_word(p, rowbase, key);
-            e0 = ((w & 0xffffu) >= p.thresh16) ? e0 * p.drop_scale : 0.f;
-            e1 = ((w >> 16) >= p.thresh16) ? e1 * p.drop_scale : 0.f;
+            const uint32_t w = drop_word(xrow + (uint32_t)(8 * ks + (r2 >> 1)) * DROP_PHI);
+            e0 = drop_keep_even(w, thi) ? e0 : 0.f;
+            e1 = drop_keep_odd(w, thi) ? e1 : 0.f;
           }
           s[qs][ks][r2] = e0;
           s[qs][ks][r2 + 1] = e1;
@@ -210,8 +226,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       rs += shfl_xor_f(rs, 32);
       l_run[qs] = l_run[qs] * alpha + rs;
       m_run[qs] = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {  // the maximum moves in the first tiles only: skip 16 multiplies otherwise
 #pragma unroll
-      for (int i = 0; i < 4; ++i) oacc[qs][i] *= alpha;
+        for (int i = 0; i < 4; ++i) oacc[qs][i] *= alpha;
+      }
       pb[qs][0] = pack_p(s[qs][0], s[qs][1]);
       pb[qs][1] = pack_p(s[qs][2], s[qs][3]);
     }
@@ -230,8 +248,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   for (int qs = 0; qs < 2; ++qs) {
     const int q = qrow[qs];
     if (q >= F) continue;
-    const float inv = l_run[qs] > 0.f ? 1.f / l_run[qs] : 0.f;
-    if (g == 0 && p.lse) p.lse[((long)b * p.nh + h) * F + q] = l_run[qs] > 0.f ? m_run[qs] + __logf(l_run[qs]) : -INFINITY;
+    const float inv = l_run[qs] > 0.f ? p.drop_scale / l_run[qs] : 0.f;
+    if (g == 0 && p.lse)  // natural-log units of the SCALED scores, as the backward and the reference's logsumexp use them
+      p.lse[((long)b * p.nh + h) * F + q] = l_run[qs] > 0.f ? m_run[qs] * p.scale + __logf(l_run[qs]) : -INFINITY;
     bf16* dst = p.ctx + ((long)b * F + q) * H + h * HD + 4 * g;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -274,14 +293,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   const int g = lane >> 4;
   int qrow[2];
   bf16x8 qf[2][2], dof[2][2];
-  float lse[2], dl[2];
-  uint32_t rowbase[2];
+  float lse[2], dl[2], lse2[2];
+  uint32_t rowbase[2];  // dropout row seeds
+  const float c2 = p.scale * 1.4426950408889634f;
+  const uint32_t thi = p.thresh16 << 16;
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
     qrow[qs] = q0 + 32 * wave + 16 * qs + (lane & 15);
-    rowbase[qs] = drop_rowbase(p, b, h, qrow[qs]);
+    rowbase[qs] = drop_rowseed(p, b, h, qrow[qs]);
     const int qc = min(qrow[qs], F - 1);
     lse[qs] = p.lse[((long)b * p.nh + h) * F + qc];
+    lse2[qs] = lse[qs] > -INFINITY ? fmaf(lse[qs], 1.4426950408889634f, -__log2f(p.scale)) : INFINITY;
     // delta[q] = sum_d dO[q,d] * O[q,d], computed here from the dO fragments the kernel holds anyway (it used to be a
     // separate pass over dO and O) and written out for the dK/dV kernel, which runs after this one
     float part = 0.f;
@@ -319,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     const char* k_tr = k_rows + TILE_BYTES;
     const char* v_rows = k_rows + 2 * TILE_BYTES;
     const int k0 = kt * KT;
+    const bool edge = k0 + KT > kl;  // uniform: only this tile needs the key-length mask
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       bf16x8 dsb[2];
@@ -342,22 +365,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         }
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-          const bool rowok = lse[qs] > -INFINITY;
+          // P = exp2(s * c2 - lse * log2 e); the softmax scale of dS = P (dP keep / (1-p) - delta) scale rides in the
+          // exponent too (lsc = lse * log2 e - log2 scale).  Rows without any valid key have lse = -inf -> +inf here -> P = 0.
+          const float lsc = lse2[qs];
+          const uint32_t xrow = rowbase[qs] + (uint32_t)((k0 >> 1) + 2 * g) * DROP_PHI;
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int r2 = 0; r2 < 4; r2 += 2) {
               const int key = k0 + 16 * (2 * t2 + kh) + 4 * g + r2;
-              float keep0 = 1.f, keep1 = 1.f;
+              float d0 = dp[qs][kh][r2], d1 = dp[qs][kh][r2 + 1];
               if (p.thresh16) {
-                const uint32_t w = drop_word(p, rowbase[qs], key);
-                keep0 = ((w & 0xffffu) >= p.thresh16) ? p.drop_scale : 0.f;
-                keep1 = ((w >> 16) >= p.thresh16) ? p.drop_scale : 0.f;
+                const uint32_t w = drop_word(xrow + (uint32_t)(8 * (2 * t2 + kh) + (r2 >> 1)) * DROP_PHI);
+                d0 = drop_keep_even(w, thi) ? d0 * p.drop_scale : 0.f;
+                d1 = drop_keep_odd(w, thi) ? d1 * p.drop_scale : 0.f;
               }
-              const float p0 = (key < kl && rowok) ? __expf(s[qs][kh][r2] * p.scale - lse[qs]) : 0.f;
-              const float p1 = (key + 1 < kl && rowok) ? __expf(s[qs][kh][r2 + 1] * p.scale - lse[qs]) : 0.f;
-              s[qs][kh][r2] = p0 * (dp[qs][kh][r2] * keep0 - dl[qs]) * p.scale;
-              s[qs][kh][r2 + 1] = p1 * (dp[qs][kh][r2 + 1] * keep1 - dl[qs]) * p.scale;
+              float p0 = __builtin_amdgcn_exp2f(fmaf(s[qs][kh][r2], c2, -lsc));
+              float p1 = __builtin_amdgcn_exp2f(fmaf(s[qs][kh][r2 + 1], c2, -lsc));
+              if (edge) {
+                p0 = key < kl ? p0 : 0.f;
+                p1 = key + 1 < kl ? p1 : 0.f;
+              }
+              s[qs][kh][r2] = p0 * (d0 - dl[qs]);
+              s[qs][kh][r2 + 1] = p1 * (d1 - dl[qs]);
             }
           dsb[qs] = pack_p(s[qs][0], s[qs][1]);
         }
@@ -400,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
   __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dctx + (long)b * F * H), 0, (int)((long)F * H * 2), 0x00020000);
   const uint32_t qcol = (uint32_t)(h * HD * 2);
   const int g = lane >> 4;
-  float* stat = reinterpret_cast<float*>(smem + 2 * 4 * TILE_BYTES);  // [stage][lse KT | delta KT]
+  float* stat = reinterpret_cast<float*>(smem + 2 * 4 * TILE_BYTES);  // [stage][lse * log2 e KT | delta KT | dropout row seed KT]
   int krow[2];
   bf16x8 kf[2][2], vf[2][2];
 #pragma unroll
@@ -412,6 +442,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       vf[ks][kk] = load_row_frag(base + 2 * H + h * HD, ld, krow[ks], F, kk, lane);
     }
   }
+  const float c2 = p.scale * 1.4426950408889634f;
+  const uint32_t thi = p.thresh16 << 16;
+  const uint32_t kphi[2] = {(uint32_t)(krow[0] >> 1) * DROP_PHI, (uint32_t)(krow[1] >> 1) * DROP_PHI};
+  const bool kvalid[2] = {krow[0] < kl, krow[1] < kl};
   f32x4 dk[2][4], dv[2][4];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -429,8 +463,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     if (threadIdx.x < KT) {
       const int q = qt * KT + threadIdx.x;
       const long o = ((long)b * p.nh + h) * F + min(q, F - 1);
-      stat[stage * 2 * KT + threadIdx.x] = q < F ? p.lse[o] : -INFINITY;
-      stat[stage * 2 * KT + KT + threadIdx.x] = q < F ? p.delta[o] : 0.f;
+      const float ls = q < F ? p.lse[o] : -INFINITY;
+      // rows beyond F or without a valid key: +inf here makes P = exp2(.. - inf) = 0 without a select per element
+      stat[stage * 3 * KT + threadIdx.x] = ls > -INFINITY ? ls * 1.4426950408889634f : INFINITY;
+      stat[stage * 3 * KT + KT + threadIdx.x] = q < F ? p.delta[o] : 0.f;
+      reinterpret_cast<uint32_t*>(stat)[stage * 3 * KT + 2 * KT + threadIdx.x] = drop_rowseed(p, b, h, q);
     }
   };
   issue(0, 0);
@@ -443,9 +480,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const char* q_tr = q_rows + TILE_BYTES;
     const char* do_rows = q_rows + 2 * TILE_BYTES;
     const char* do_tr = q_rows + 3 * TILE_BYTES;
-    const float* lse_s = stat + cur * 2 * KT;
+    const float* lse_s = stat + cur * 3 * KT;
     const float* dl_s = lse_s + KT;
-    const int qq0 = qt * KT;
+    const uint32_t* seed_s = reinterpret_cast<const uint32_t*>(lse_s + 2 * KT);
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       bf16x8 pdb[2], dsb[2];  // per key sub-tile, for the 32 queries of this half
@@ -470,20 +507,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
           // Dropout words of this lane's 4 queries x 2 keys.  A word covers a key PAIR and the pair sits in two adjacent
-          // lanes, so each lane hashes two of the four query rows and takes the other two from its partner by DPP
-          // (half the hashes of one-per-element; the hash was a quarter of this kernel's VALU work).
+          // lanes, so each lane mixes two of the four query rows and takes the other two from its partner by DPP.
           uint32_t W[2][4];
           if (p.thresh16) {
-            const uint32_t half = (uint32_t)(p.Fp >> 1);
-            const uint32_t par = lane & 1;
-            // rowbase(q) = ((b * nh + h) * F + q) * half without the clamp of drop_rowbase: rows >= F are masked below
-            const uint32_t rb = ((uint32_t)(b * p.nh + h) * (uint32_t)F + (uint32_t)(qq0 + 16 * (2 * t2 + qh) + 4 * g) + par) * half;
+            const int par = lane & 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              const uint32_t kp = (uint32_t)(krow[ks] >> 1);
+            for (int i = 0; i < 2; ++i) {
+              const uint32_t rs = seed_s[16 * (2 * t2 + qh) + 4 * g + par + 2 * i];  // row par + 2i of this lane's four
 #pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const uint32_t mine = hash_u32(p.seed, p.stream, (uint64_t)(rb + (uint32_t)(2 * i) * half + kp));  // row par + 2i
+              for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t mine = drop_word(rs + kphi[ks]);
                 const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);  // row 1 - par + 2i
                 W[ks][2 * i] = par ? other : mine;
                 W[ks][2 * i + 1] = par ? mine : other;
@@ -493,19 +526,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int ql = 16 * (2 * t2 + qh) + 4 * g + r;  // query inside the tile
-            const int q = qq0 + ql;
-            const float ls = lse_s[ql], dl = dl_s[ql];
-            const bool rowok = q < F && ls > -INFINITY;
+            const float lsc = lse_s[ql], dl = dl_s[ql];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-              const int key = krow[ks];
               float keep = 1.f;
               if (p.thresh16) {
                 const uint32_t w = W[ks][r];
-                const uint32_t u = (key & 1) ? (w >> 16) : (w & 0xffffu);
-                keep = (u >= p.thresh16) ? p.drop_scale : 0.f;
+                const bool k = (krow[ks] & 1) ? drop_keep_odd(w, thi) : drop_keep_even(w, thi);
+                keep = k ? p.drop_scale : 0.f;
               }
-              const float pr = (rowok && key < kl) ? __expf(s[ks][qh][r] * p.scale - ls) : 0.f;
+              float pr = __builtin_amdgcn_exp2f(fmaf(s[ks][qh][r], c2, -lsc));
+              pr = kvalid[ks] ? pr : 0.f;  // keys beyond the key length (a per-lane constant)
               const float dpv = dp[ks][qh][r] * keep;
               s[ks][qh][r] = pr * keep;                    // Pd
               dp[ks][qh][r] = pr * (dpv - dl) * p.scale;   // dS
@@ -589,7 +620,7 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
   const AttnParams p = make_params(qkv, const_cast<bf16*>(ctx), const_cast<float*>(lse), klens, dctx, delta, dqkv, B, F, nh, H, drop);
   attn_bwd_dq_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
   SSAK_LAUNCH_CHECK();
-  constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 2 * KT * 4;
+  constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 3 * KT * 4;
   static bool attr_done = false;
   if (!attr_done) {
     SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
