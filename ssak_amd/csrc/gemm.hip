@@ -722,13 +722,23 @@ int dispatch_layout(const GemmParams& p, int a_km, int b_km, bool dma, hipStream
 }
 
 
-// out[n] += sum over slots of partial[slot][n], fixed order (the column sums the epilogues left per wave-tile row)
-__global__ __launch_bounds__(256) void colsum_slots_kernel(const float* __restrict__ partial, int slots, int N, float* __restrict__ out) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+// out[n] += sum over slots of partial[slot][n], fixed order (the column sums the epilogues left per wave-tile row).
+// Workgroup = 64 columns x 16 slot groups; the groups are combined in LDS in a fixed order.
+__global__ __launch_bounds__(1024) void colsum_slots_kernel(const float* __restrict__ partial, int slots, int N, float* __restrict__ out) {
+  __shared__ float red[16][65];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int k = 0; k < slots; ++k) s += partial[(long)k * N + n];
-  out[n] += s;
+  if (n < N)
+    for (int k = ry; k < slots; k += 16) s += partial[(long)k * N + n];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cx];
+    out[n] += t;
+  }
 }
 
 // ---- kernel / tile / split-K selection ---------------------------------------------------------------------------
@@ -923,7 +933,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   if (colsum_out) {
     if (colsum_fused) {
       const int slots = 2 * ssak_cdiv(d->M, p8_bm);  // (tile row, wave row) pairs, wave tiles of p8_bm / 2 rows
-      colsum_slots_kernel<<<ssak_cdiv(d->N, 256), 256, 0, st>>>((const float*)workspace, slots, d->N, colsum_out);
+      colsum_slots_kernel<<<ssak_cdiv(d->N, 64), 1024, 0, st>>>((const float*)workspace, slots, d->N, colsum_out);
       SSAK_LAUNCH_CHECK();
     } else {
       return k_colsum((const bf16*)C, d->ldc, d->M, d->N, colsum_out, st);
