@@ -565,7 +565,7 @@ extern "C" int ssak_w2v2_create(const ssak_w2v2_config* cfg, ssak_w2v2** out) {
   }
   SSAK_HIP(hipMalloc((void**)&e->pc_wf, (size_t)H * K * cg * sizeof(bf16)));
   SSAK_HIP(hipMalloc((void**)&e->pc_wb, (size_t)H * K * cg * sizeof(bf16)));
-  SSAK_HIP(hipMalloc((void**)&e->pc_norms, (size_t)(2 + 256) * K * sizeof(float)));
+  SSAK_HIP(hipMalloc((void**)&e->pc_norms, (size_t)(2 + c.hidden_size) * K * sizeof(float)));  // norms | dot | [H][K] partials
   *out = e;
   return SSAK_OK;
 }
