@@ -190,11 +190,12 @@ int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer
  * (docker/transformers_modified/trainer.py:1827-1855; ssak/train/transformers/wav2vec_train.py:353-384).
- * ssak_grad_sumsq: out[0] = sum(grads^2).  ssak_adamw_step: g' = grads * grad_scale * min(1, max_norm /
+ * ssak_grad_sumsq: out[0] = sum(grads^2), summed in a fixed order (per-workgroup partials in `workspace`, >= 4096 bytes,
+ * then one pass): the clip coefficient is reproducible run to run.  ssak_adamw_step: g' = grads * grad_scale * min(1, max_norm /
  * (sqrt(gnorm_sq[0]) * grad_scale + 1e-6)) (no clipping when gnorm_sq is NULL or max_norm <= 0), then the
  * AdamW update with bias correction for 1-based `step`; shadow_bf16 (or NULL) receives the bf16 copy of the
  * new parameters.  The clip coefficient is read on the device: no host synchronisation. */
-int ssak_grad_sumsq(const float* grads, long n, float* out, void* stream);
+int ssak_grad_sumsq(const float* grads, long n, float* out, void* workspace, size_t workspace_bytes, void* stream);
 int ssak_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
                     const float* gnorm_sq, float max_norm, float grad_scale, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, void* stream);

@@ -21,12 +21,15 @@ int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int ro
                   int rows_per_batch, const DropSpec& drop, hipStream_t st);
 int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
                   hipStream_t st);
-int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st);
+// out[n] += column sums of X; with a scratch of >= min(64, ceil(M/32)) * N floats the sum is two-stage and deterministic
+// (without one: float atomics).  rowmask / flens / F: only masked, non-padding rows (SpecAugment embedding gradient).
+int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0,
+             const uint8_t* rowmask = nullptr, const int32_t* flens = nullptr, int F = 0);
 int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st);
 int k_specaug_fwd(bf16* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
                   hipStream_t st);
 int k_specaug_bwd(bf16* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
-                  hipStream_t st);
+                  hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
 
 int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStream_t st);
 int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st);
@@ -65,7 +68,8 @@ int k_col2im_k3s2(const bf16* dxcol, const bf16* pre, bf16* out, int B, int F, i
 int k_conv_wgrad_unrearrange(const float* dwr, float* g, int Co, int Ci, int k, hipStream_t st);
 
 // optim.hip
-int k_sumsq(const float* g, long n, float* out /*[1], zeroed by caller*/, hipStream_t st);
+// out[0] = sum g^2: 1024 per-workgroup partials in `partial` (>= 1024 floats), then one fixed-order pass -- deterministic
+int k_sumsq(const float* g, long n, float* out /*[1]*/, float* partial, hipStream_t st);
 int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, const float* gnorm_sq, float max_norm,
             float grad_scale, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t st);
 

@@ -450,15 +450,20 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
 }
 
 // ---------------------------------------------------------------------------------------------- column sums
-// out[n] += sum_m X[m, n]  (bias gradients).  Workgroup: 8 threads across 64 columns x 32 row lanes.
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, long ld, int M, int N,
-                                                     float* __restrict__ out) {
+// out[n] += sum_m X[m, n]  (bias gradients).  Workgroup: 8 threads across 64 columns x 32 row lanes; gridDim.y row groups.
+// With a `partial` buffer [gridDim.y][N] every group writes its own row (summed afterwards in a fixed order: deterministic);
+// without one the groups add into `out` atomically.  rowmask (optional): only rows with rowmask[m] != 0 that are not
+// padding (frame < flens[m / F]) count -- the gradient of the SpecAugment mask embedding.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, long ld, int M, int N, float* __restrict__ out,
+                                                     float* __restrict__ partial, const uint8_t* __restrict__ rowmask,
+                                                     const int32_t* __restrict__ flens, int F) {
   __shared__ float red[32][65];
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
   const int c0 = blockIdx.x * 64 + cx * 8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < N) {
     for (int m = blockIdx.y * 32 + ry; m < M; m += gridDim.y * 32) {
+      if (rowmask && (!rowmask[m] || (flens && m % F >= flens[m / F]))) continue;
       float f[8];
       unpack8(*reinterpret_cast<const uint4*>(X + (size_t)m * ld + c0), f);
 #pragma unroll
@@ -473,7 +478,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X,
 #pragma unroll
     for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < N) atomicAdd(out + c, s);
+    if (c < N) {
+      if (partial)
+        partial[(size_t)blockIdx.y * N + c] = s;
+      else
+        atomicAdd(out + c, s);
+    }
+  }
+}
+// out[n] += sum over `slots` rows of partial [slots][N], fixed order; workgroup = 64 columns x 16 slot groups
+__global__ __launch_bounds__(1024) void colsum_rows_kernel(const float* __restrict__ partial, int slots, int N, float* __restrict__ out) {
+  __shared__ float red[16][65];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
+  float s = 0.f;
+  if (n < N)
+    for (int k = ry; k < slots; k += 16) s += partial[(long)k * N + n];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cx];
+    out[n] += t;
   }
 }
 
@@ -507,9 +534,7 @@ __global__ void specaug_bwd_kernel(bf16* __restrict__ dh, const uint8_t* __restr
   const bool mk = mask && mask[row];
   if (!pad && !mk) return;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const size_t o = (size_t)row * C + c;
-    if (!pad && dembed) atomicAdd(dembed + c, (float)dh[o]);
-    dh[o] = (bf16)0.f;
+    dh[(size_t)row * C + c] = (bf16)0.f;  // (the masked rows' sum -> d embed is taken before, by the masked column sum)
   }
 }
 
@@ -622,11 +647,17 @@ int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, 
   return SSAK_OK;
 }
 
-int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st) {
+int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch, size_t scratch_floats,
+             const uint8_t* rowmask, const int32_t* flens, int F) {
   SSAK_REQUIRE(M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ld);
   dim3 grid(ssak_cdiv(N, 64), min(64, ssak_cdiv(M, 32)));
-  colsum_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, out);
+  const bool det = scratch && scratch_floats >= (size_t)grid.y * N;  // deterministic two-stage sum when a scratch is given
+  colsum_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, out, det ? scratch : nullptr, rowmask, flens, F > 0 ? F : 1);
   SSAK_LAUNCH_CHECK();
+  if (det) {
+    colsum_rows_kernel<<<ssak_cdiv(N, 64), 1024, 0, st>>>(scratch, (int)grid.y, N, out);
+    SSAK_LAUNCH_CHECK();
+  }
   return SSAK_OK;
 }
 
@@ -646,8 +677,11 @@ int k_specaug_fwd(bf16* h, const uint8_t* mask, const int32_t* flens, const floa
 }
 
 int k_specaug_bwd(bf16* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
-                  hipStream_t st) {
+                  hipStream_t st, float* scratch, size_t scratch_floats) {
   if (!mask && !flens) return SSAK_OK;
+  // d embed = sum of the masked (non-padding) rows of dh, taken before they are zeroed
+  if (mask && dembed)
+    if (int rc = k_colsum(dh, C, B * F, C, dembed, st, scratch, scratch_floats, mask, flens, F)) return rc;
   specaug_bwd_kernel<<<B * F, 128, 0, st>>>(dh, mask, flens, dembed, B * F, F, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;

@@ -20,7 +20,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (blockIdx.x == 0)
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;  // per-workgroup partial; summed in a fixed order by sumsq_final_kernel
+}
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = threadIdx.x < n ? partial[threadIdx.x] : 0.f;
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -77,9 +83,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-int k_sumsq(const float* g, long n, float* out, hipStream_t st) {
+int k_sumsq(const float* g, long n, float* out, float* partial, hipStream_t st) {
   if (n <= 0) return SSAK_OK;
-  sumsq_kernel<<<(int)fmin(2048.0, (double)ssak_cdiv(n, 1024)), 256, 0, st>>>(g, n, out);
+  const int blocks = (int)fmin(1024.0, (double)ssak_cdiv(n, 1024));
+  sumsq_kernel<<<blocks, 256, 0, st>>>(g, n, partial);
+  SSAK_LAUNCH_CHECK();
+  sumsq_final_kernel<<<1, 1024, 0, st>>>(partial, blocks, out);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -96,11 +105,11 @@ int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, 
   return SSAK_OK;
 }
 
-extern "C" int ssak_grad_sumsq(const float* grads, long n, float* out, void* stream) {
+extern "C" int ssak_grad_sumsq(const float* grads, long n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   SSAK_REQUIRE(grads && out && n > 0, "grad_sumsq: bad arguments");
   SSAK_REQUIRE(((uintptr_t)grads & 15) == 0, "grad_sumsq: buffer must be 16-byte aligned");
-  SSAK_HIP(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream));
-  return k_sumsq(grads, n, out, (hipStream_t)stream);
+  SSAK_REQUIRE(workspace && workspace_bytes >= 1024 * sizeof(float), "grad_sumsq: workspace of 4096 bytes needed");
+  return k_sumsq(grads, n, out, (float*)workspace, (hipStream_t)stream);
 }
 
 extern "C" int ssak_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,

@@ -905,6 +905,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   };
   const DropSpec none;
   void* slab = ws + p.slab;
+  const size_t cs_floats = (size_t)LN_BWD_BLOCKS * 3 * std::max(H, C);  // p.lnpart doubles as the column-sum scratch
   const float scale = 1.f / sqrtf((float)hd);
 
   const long n_grad = (e->cfg.arch == 1 || e->cfg.freeze_feature_encoder) ? e->n_train : e->n_total;
@@ -914,7 +915,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
   const bf16* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
   TRY(Gemm(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
-  TRY(k_colsum(dlog, V, M, V, Gd + e->p_lm_b, st));
+  TRY(k_colsum(dlog, V, M, V, Gd + e->p_lm_b, st, FP(p.lnpart), cs_floats));
   auto announce = [&](long off, long cnt) {
     if (e->on_ready && cnt > 0) e->on_ready(off, cnt, e->on_ready_user);
   };
@@ -1025,7 +1026,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
     }
     wq.push(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
-    TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st));
+    TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, FP(p.lnpart), cs_floats));
     TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
     wq.ann_off[wq.layers++] = L.wqkv;
     // launch when a second layer is queued, or when another layer would spill into a second round of workgroups
@@ -1057,7 +1058,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     const int NM = c.num_mel_bins, Tin = p.Tin, RS1 = p.RS1, RS2 = p.RS2;
     bf16* dpre2 = BF(p.dY);
     TRY(k_gelu_grad_mul(dh1, BF(p.wpre2), dpre2, (long)M * H, st));
-    TRY(k_colsum(dpre2, H, M, H, Gd + e->p_c2b, st));
+    TRY(k_colsum(dpre2, H, M, H, Gd + e->p_c2b, st, FP(p.lnpart), cs_floats));
     TRY(k_copy_rows_padded(dpre2, BF(p.dpre2pad), B, F, RS2, H, st));
     // dW2[n][tap*H + c] = sum over rows kk = b*RS2 + t of dy[kk][n] * h1pad[2*kk + tap][c]   (one long-K GEMM)
     TRY(Gemm(H, 3 * H, B * RS2).a(BF(p.dpre2pad), H, true).b(BF(p.h1pad), 2 * H, true).c(FP(p.dwr), 3 * H, true)
@@ -1066,7 +1067,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     // input gradient in column form, then col2im (+ GELU' of conv1's pre-activation)
     TRY(Gemm(M, 3 * H, H).a(dpre2, H).b(e->conv_w[2], 3 * H, true).c(BF(p.dxcol), 3 * H).run(st));
     TRY(k_col2im_k3s2(BF(p.dxcol), BF(p.pre1), BF(p.dpre1pad), B, F, Tin, RS1, H, st));
-    TRY(k_colsum(BF(p.dpre1pad), H, B * RS1, H, Gd + e->p_c1b, st));
+    TRY(k_colsum(BF(p.dpre1pad), H, B * RS1, H, Gd + e->p_c1b, st, FP(p.lnpart), cs_floats));
     TRY(Gemm(H, 3 * NM, B * RS1).a(BF(p.dpre1pad), H, true).b(BF(p.melcl), NM, true).c(FP(p.dwr), 3 * NM, true)
             .run_wgrad(st, slab, p.slab_bytes));
     TRY(k_conv_wgrad_unrearrange(FP(p.dwr), Gd + e->p_c1w, H, NM, 3, st));
@@ -1075,7 +1076,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   } else {
   bf16* dpre = BF(p.dY);
   TRY(k_gelu_grad_mul(dh1, BF(p.pc_pre), dpre, (long)M * H, st));
-  TRY(k_colsum(dpre, H, M, H, Gd + e->p_pc_b, st));
+  TRY(k_colsum(dpre, H, M, H, Gd + e->p_pc_b, st, FP(p.lnpart), cs_floats));
   TRY(k_posconv_pack(dpre, BF(p.pgdy), B, F, H, G, K, st));
   {
     const int lead = K / 2, RS = F + K;
@@ -1100,7 +1101,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   }
   bf16* dh0 = (dh1 == BF(p.dA)) ? BF(p.dC) : BF(p.dA);
   TRY(k_add_bf16(dh1, BF(p.dB), dh0, (long)M * H, st));
-  TRY(k_specaug_bwd(dh0, e->spec_mask, flens, Gd + e->p_mse, B, F, H, st));
+  TRY(k_specaug_bwd(dh0, e->spec_mask, flens, Gd + e->p_mse, B, F, H, st, FP(p.lnpart), cs_floats));
   // ---- feature projection
   const bf16* dh0d = dh0;
   if (c.feat_proj_dropout > 0.f) {
@@ -1110,7 +1111,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     dh0d = BF(p.scratchH);
   }
   TRY(Gemm(H, C, M).a(dh0d, H, true).b(BF(p.ln0), C, true).c(Gd + e->p_fp_w, C, true).run_wgrad(st, slab, p.slab_bytes));
-  TRY(k_colsum(dh0d, H, M, H, Gd + e->p_fp_b, st));
+  TRY(k_colsum(dh0d, H, M, H, Gd + e->p_fp_b, st, FP(p.lnpart), cs_floats));
   TRY(Gemm(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
   bf16* dfeat = p.fe_train ? (((nc - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da)) : BF(p.ln0);  // frozen: scratch, never read
   TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, dfeat, nullptr,

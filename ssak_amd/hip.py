@@ -74,7 +74,7 @@ def _load():
         "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
         "ssak_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
-        "ssak_grad_sumsq": (i32, [vp, C.c_long, vp, vp]),
+        "ssak_grad_sumsq": (i32, [vp, C.c_long, vp, vp, sz, vp]),
         "ssak_adamw_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
         "ssak_w2v2_create": (i32, [C.POINTER(W2V2Config), C.POINTER(vp)]),
         "ssak_w2v2_destroy": (None, [vp]),

@@ -38,6 +38,7 @@ class AdamW:
         self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=model.device)
         self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=model.device)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=model.device)
+        self._sumsq_ws = torch.empty(1024, dtype=torch.float32, device=model.device)  # per-workgroup partials of the norm
         self.step_count = 0
 
     def current_lr(self) -> float:
@@ -49,7 +50,8 @@ class AdamW:
         self.step_count += 1
         with torch.cuda.device(m.device):
             st = hip.stream()
-            hip.check(hip.lib.ssak_grad_sumsq(hip.ptr(m.grads), self.n, hip.ptr(self.gnorm_sq), st))
+            hip.check(hip.lib.ssak_grad_sumsq(hip.ptr(m.grads), self.n, hip.ptr(self.gnorm_sq), hip.ptr(self._sumsq_ws),
+                                              self._sumsq_ws.numel() * 4, st))
             hip.check(hip.lib.ssak_adamw_step(hip.ptr(m.params), hip.ptr(m.grads), hip.ptr(self.exp_avg),
                                               hip.ptr(self.exp_avg_sq), hip.ptr(m.shadow), self.n, hip.ptr(self.gnorm_sq),
                                               self.max_grad_norm, grad_scale, lr, self.betas[0], self.betas[1], self.eps,

@@ -251,3 +251,29 @@ def test_dp2_trainer_equals_single_process(tmp_path):
     du_ref, du_dp = ref - p_init, got["params"] - p_init
     rel = float((du_dp - du_ref).norm() / du_ref.norm())
     assert du_ref.abs().max() > 1e-3 and rel < 0.1, rel
+
+
+def test_train_step_is_bitwise_reproducible():
+    """No float atomics on the path: two runs from the same seed (dropout, LayerDrop and SpecAugment ON) end in bit-identical
+    parameters and losses -- bias gradients, the SpecAugment embedding gradient and the clip norm are all fixed-order sums."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    oc = R.W2V2Config.tiny()
+    oc = dataclasses.replace(oc, mask_time_prob=0.2)
+    p0 = R.init_params(oc, 5)
+    rng = np.random.default_rng(1)
+    x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(12000).astype(np.float32) for _ in range(6)])).cuda()
+    labels = torch.tensor(R.pad_labels([list(rng.integers(1, 32, n)) for n in (6, 4, 7, 5, 3, 8)])).cuda()
+
+    def run():
+        model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc), seed=123).train()
+        model.load_state_dict(p0)
+        tr = Trainer(model, AdamW(model, lr=1e-3, warmup_steps=1, total_steps=100, max_grad_norm=1.0))
+        losses = [tr.train_step(x, None, labels, raw=False).item() for _ in range(5)]
+        return losses, model.params.clone()
+
+    (l1, p1), (l2, p2) = run(), run()
+    assert l1 == l2
+    assert torch.equal(p1, p2)
