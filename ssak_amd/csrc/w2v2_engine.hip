@@ -493,7 +493,11 @@ struct WgradQueue {
   const void* B[8];
   void* C[8];
   int n = 0, layers = 0, tiles = 0;
-  long ann_off[2] = {0, 0};
+  // gradient ranges to announce once the queued products have been launched, in LAYER ORDER: a data-parallel caller
+  // pairs the k-th announcement of every rank in one collective, and LayerDrop decisions differ between ranks, so a
+  // dropped layer's (zero) range must not overtake the kept layers still waiting here
+  long ann_off[64];
+  int n_ann = 0;
   static int tiles_of(const ssak_gemm_desc& g) { return ssak_cdiv(g.M, 256) * ssak_cdiv(g.N, 256); }
   void push(const Gemm& g) {
     d[n] = g.d;
@@ -943,7 +947,8 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
                           2 * ssak_cdiv(I, 256) * ssak_cdiv(H, 256);
   auto flush_wgrads = [&]() -> int {
     TRY(wq.flush(st, slab, p.slab_bytes));
-    for (int i = 0; i < wq.layers; ++i) announce(wq.ann_off[i], layer_span);
+    for (int i = 0; i < wq.n_ann; ++i) announce(wq.ann_off[i], layer_span);
+    wq.n_ann = 0;
     wq.layers = 0;
     return SSAK_OK;
   };
@@ -954,7 +959,11 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     const long nxt_w = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1w : e->p_eln_w;
     const long nxt_b = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1b : e->p_eln_b;
     if (!e->keep[l]) {
-      announce(L.wqkv, layer_span);  // zeros (memset above), still part of the all-reduce
+      // zeros (memset above), still part of the all-reduce; behind any kept layer whose gradients are still queued
+      if (wq.n_ann > 0)
+        wq.ann_off[wq.n_ann++] = L.wqkv;
+      else
+        announce(L.wqkv, layer_span);
       if (!stable) continue;  // identity layer: gradient passes through unchanged
       // x[l+1] = LN_next(r): its gradient joins the residual-stream gradient; nothing consumed x[l]
       bf16* dr = free_buf(gA, gB, Gres);
@@ -1028,7 +1037,8 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     wq.push(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
     TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, FP(p.lnpart), cs_floats));
     TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
-    wq.ann_off[wq.layers++] = L.wqkv;
+    wq.ann_off[wq.n_ann++] = L.wqkv;
+    ++wq.layers;
     // launch when a second layer is queued, or when another layer would spill into a second round of workgroups
     if (wq.layers == 2 || wq.tiles + layer_tiles > 256) TRY(flush_wgrads());
     if (!stable) {

@@ -277,3 +277,38 @@ def test_train_step_is_bitwise_reproducible():
     (l1, p1), (l2, p2) = run(), run()
     assert l1 == l2
     assert torch.equal(p1, p2)
+
+
+def _dp_layerdrop_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    oc = dataclasses.replace(R.W2V2Config.tiny(), layerdrop=0.5)
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc), seed=100 + rank).train()  # per-rank LayerDrop / dropout draws
+    model.load_state_dict(R.init_params(oc, 21))
+    tr = Trainer(model, AdamW(model, lr=1e-3, warmup_steps=1, total_steps=100, max_grad_norm=1.0))
+    tr.broadcast_parameters()
+    rng = np.random.default_rng(50 + rank)
+    x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(9000).astype(np.float32) for _ in range(4)])).cuda()
+    labels = torch.tensor(R.pad_labels([list(rng.integers(1, 32, 5)) for _ in range(4)])).cuda()
+    for _ in range(6):
+        tr.train_step(x, None, labels, raw=False)
+    torch.save(model.params[:model.num_trainable].cpu(), os.path.join(out_dir, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp2_ranks_stay_identical_with_per_rank_layerdrop(tmp_path):
+    """Ranks that drop DIFFERENT layers still pair the same gradient ranges in every collective (announcements stay in layer
+    order whatever a rank kept or dropped): after six steps both ranks hold bit-identical parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_layerdrop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(a, b)
