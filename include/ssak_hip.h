@@ -213,7 +213,7 @@ typedef struct {
   int num_conv_layers;
   int conv_dim[8], conv_kernel[8], conv_stride[8];
   int conv_bias;            /* 0 (base) */
-  int feat_extract_norm;    /* 0 = "group" (base), 1 = "layer" (XLSR; not built yet) */
+  int feat_extract_norm;    /* 0 = "group" (base), 1 = "layer" (XLSR) */
   int do_stable_layer_norm; /* 0 = post-LN (base) */
   int num_conv_pos_embeddings, num_conv_pos_embedding_groups;
   float layer_norm_eps;

@@ -410,6 +410,78 @@ __global__ void posconv_pack_kernel(const bf16* __restrict__ h, bf16* __restrict
 
 }  // namespace
 
+namespace {
+
+// conv0 weight gradient for the layer-norm feature encoder (the gradient w.r.t. the conv output is materialised there):
+// dw[c][k] = sum_{b,t} d[b,t,c] * x[b, stride t + k].  Workgroup = a contiguous range of frames of one utterance; thread =
+// two channels, 2 * ksize accumulators in registers; the frame's taps are read once per workgroup into LDS.
+constexpr int C0W_BLOCKS_PER_UTT = 32;
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const bf16* __restrict__ d, const float* __restrict__ x, float* __restrict__ partial,
+                                                          int T, int T0, int C, int ksize, int stride) {
+  __shared__ float xs[64 * 5 + 16];  // the samples of 64 frames (stride 5, kernel 10)
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int per = (T0 + C0W_BLOCKS_PER_UTT - 1) / C0W_BLOCKS_PER_UTT;
+  const int t_lo = blk * per, t_hi = min(T0, t_lo + per);
+  float acc[2][10];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[u][k] = 0.f;
+  const float* xb = x + (size_t)b * T;
+  for (int t0 = t_lo; t0 < t_hi; t0 += 64) {
+    const int nt = min(64, t_hi - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * stride + ksize; i += 256) {
+      const long xi = (long)t0 * stride + i;
+      xs[i] = xi < T ? xb[xi] : 0.f;
+    }
+    __syncthreads();
+    for (int c2 = threadIdx.x; c2 < C / 2; c2 += 256)  // (C <= 512: one pass)
+      for (int tt = 0; tt < nt; ++tt) {
+        const bf16x2 dv = *reinterpret_cast<const bf16x2*>(d + ((size_t)b * T0 + t0 + tt) * C + 2 * c2);
+        const float d0 = (float)dv[0], d1 = (float)dv[1];
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+          if (k < ksize) {
+            const float xv = xs[tt * stride + k];
+            acc[0][k] = fmaf(d0, xv, acc[0][k]);
+            acc[1][k] = fmaf(d1, xv, acc[1][k]);
+          }
+      }
+  }
+  float* out = partial + ((size_t)b * gridDim.x + blk) * C * ksize;
+  const int c2 = threadIdx.x;
+  if (c2 < C / 2)
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+      if (k < ksize) {
+        out[(2 * c2) * ksize + k] = acc[0][k];
+        out[(2 * c2 + 1) * ksize + k] = acc[1][k];
+      }
+}
+__global__ void conv0_wgrad_sum_kernel(const float* __restrict__ partial, int nslab, int n, float* __restrict__ dw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * n + e];
+  dw[e] += s;
+}
+
+}  // namespace
+
+size_t k_conv0_wgrad_scratch_floats(int B, int C, int ksize) { return (size_t)B * C0W_BLOCKS_PER_UTT * C * ksize; }
+
+int k_conv0_wgrad(const bf16* d, const float* x, float* dw, float* scratch, int B, int T, int T0, int C, int ksize, int stride,
+                  hipStream_t st) {
+  SSAK_REQUIRE(ksize <= 10 && stride * 64 + ksize <= 64 * 5 + 16 && C <= 512 && (C & 1) == 0,
+               "conv0_wgrad: kernel %d / stride %d / C %d outside what is built (k <= 10, stride <= 5, C <= 512)", ksize, stride, C);
+  conv0_wgrad_kernel<<<dim3(C0W_BLOCKS_PER_UTT, B), 256, 0, st>>>(d, x, scratch, T, T0, C, ksize, stride);
+  SSAK_LAUNCH_CHECK();
+  conv0_wgrad_sum_kernel<<<ssak_cdiv(C * ksize, 256), 256, 0, st>>>(scratch, B * C0W_BLOCKS_PER_UTT, C * ksize, dw);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
 size_t k_conv0_stats_doubles(int B, int T0, int C) { return (size_t)B * 2 * C * (1 + ssak_cdiv(T0, FR_STATS)); }
 
 int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,

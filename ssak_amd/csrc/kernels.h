@@ -15,7 +15,8 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
                     const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
                     float* partial /*[LN_BWD_BLOCKS*3*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
-                    hipStream_t st, const DropSpec& mid = DropSpec(), float* dy_colsum = nullptr /*[C] += column sums of dy*/);
+                    hipStream_t st, const DropSpec& mid = DropSpec(), float* dy_colsum = nullptr /*[C] += column sums of dy*/,
+                    const float* post_gelu_beta = nullptr /*forward was gelu(LN(x)): beta of that LN*/);
 constexpr int LN_BWD_BLOCKS = 512;
 int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
                   int rows_per_batch, const DropSpec& drop, hipStream_t st);
@@ -38,6 +39,11 @@ int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st);
 size_t k_conv0_stats_doubles(int B, int T0, int C);
 int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,
                     int B, int T, int T0, int C, int ksize, int stride, hipStream_t st);
+// dw [C][ksize] += sum over frames of d[b,t,c] * x[b, stride*t + k] (conv0 weight gradient of the layer-norm feature encoder,
+// Cin = 1); scratch >= k_conv0_wgrad_scratch_floats() floats; deterministic (per-workgroup partials, fixed-order sum)
+size_t k_conv0_wgrad_scratch_floats(int B, int C, int ksize);
+int k_conv0_wgrad(const bf16* d, const float* x, float* dw, float* scratch, int B, int T, int T0, int C, int ksize, int stride,
+                  hipStream_t st);
 int k_conv0_bias(const float* x, const float* w, const float* bias, bf16* out, int B, int T, int T0, int C, int ksize,
                  int stride, hipStream_t st);
 int k_col2im(const bf16* dxcol, bf16* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st);

@@ -148,6 +148,8 @@ struct LnBwdParams {
   float* dbeta;
   float* partial;     // [gridDim.x][3][C] per-workgroup column partials
   float* dy_colsum;   // [C] += column sums of dy (the bias gradient of the Linear that produced the branch) or null
+  const float* beta;  // non-null: the forward applied GELU after the affine (layer-norm conv layers of the XLSR feature
+                      // encoder): the incoming gradient is multiplied by gelu'(xhat * gamma + beta) first
   int M, C;
   uint64_t seed;
   uint32_t pre_stream, pre_thresh, post_stream, post_thresh;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.C >> 3;
   const int wid = blockIdx.x * (ROW_THREADS / 64) + wave;
-  float ag[NCH][8], ab[NCH][8], gm[NCH][8], ay[NCH][8];
+  float ag[NCH][8], ab[NCH][8], gm[NCH][8], ay[NCH][8], bt[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
       ab[i][k] = 0.f;
       ay[i][k] = 0.f;
       gm[i][k] = (ch < nch) ? p.gamma[ch * 8 + k] : 0.f;
+      bt[i][k] = (ch < nch && p.beta) ? p.beta[ch * 8 + k] : 0.f;
     }
   }
   // raw operands of the row a wave works on are fetched one row ahead: a wave owns ~8 rows and every row is a dependent
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
         for (int k = 0; k < 8; ++k) {
           if (p.post_thresh) a[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? a[k] * p.post_scale : 0.f;
           xh[i][k] = (x[k] - mean) * rstd;
+          if (p.beta) a[k] *= gelu_grad_f(fmaf(xh[i][k], gm[i][k], bt[i][k]));
           ag[i][k] += a[k] * xh[i][k];
           ab[i][k] += a[k];
           dyv[i][k] = a[k] * gm[i][k];
@@ -590,10 +594,10 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
                     const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
                     float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st,
-                    const DropSpec& mid, float* dy_colsum) {
+                    const DropSpec& mid, float* dy_colsum, const float* post_gelu_beta) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm_bwd: C=%d must be a multiple of 8 and <= 1536", C);
   SSAK_REQUIRE(!dy_colsum || dy, "layernorm_bwd: the dy column sum needs the dy output");
-  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, M, C, pre.seed,
+  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, post_gelu_beta, M, C, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
                 scale_of(pre.p), scale_of(post.p), 1,
                 mid.stream, thresh_of(mid.p), scale_of(mid.p)};

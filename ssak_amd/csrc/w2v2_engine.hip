@@ -70,6 +70,7 @@ struct Plan {
   // --no_freeze: every conv activation / pre-activation is kept, plus backward temporaries
   bool fe_train = false;
   size_t act[8] = {0}, cpre[8] = {0}, fe_dp = 0, fe_da = 0, fe_db = 0, fe_dxcol = 0, fe_slab = 0, fe_dwr = 0, fe_c0 = 0;
+  size_t fe_st[8] = {0};  // layer-norm feature encoder: per-frame mean | rstd of every conv layer's LayerNorm
   size_t melcl, h1pad, pre1, wpre2, we, dpre2pad, dxcol, dpre1pad, dwr;
   size_t slab_bytes = 0;
   size_t total = 0;
@@ -312,19 +313,25 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     size_t max_col = 0, max_w = 0;
     for (int i = 0; i < nc; ++i) {
       if (i < nc - 1) p.act[i] = cv.take((size_t)B * p.Tl[i] * c.conv_dim[i] * b2);
+      if (c.feat_extract_norm == 1) {  // pre-LayerNorm conv outputs of ALL layers + their statistics
+        if (i == 0) p.cpre[0] = cv.take((size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
+        p.fe_st[i] = cv.take((size_t)2 * B * p.Tl[i] * sizeof(float));
+      }
       if (i > 0) {
         p.cpre[i] = cv.take((size_t)B * p.Tl[i] * c.conv_dim[i] * b2);
         max_col = std::max(max_col, (size_t)B * p.Tl[i] * c.conv_kernel[i] * c.conv_dim[i - 1]);
         max_w = std::max(max_w, (size_t)c.conv_dim[i] * c.conv_kernel[i] * c.conv_dim[i - 1]);
       }
     }
-    p.fe_dp = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
+    if (c.feat_extract_norm != 1) p.fe_dp = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
     p.fe_da = cv.take((size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
     p.fe_db = cv.take((size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
     p.fe_dxcol = cv.take(max_col * b2);
     p.fe_slab = cv.take((size_t)B * max_w * sizeof(float));
     p.fe_dwr = cv.take(max_w * sizeof(float));
-    p.fe_c0 = cv.take(k_conv0_bwd_scratch_floats(B, p.Tl[0], c.conv_dim[0]) * sizeof(float));
+    p.fe_c0 = cv.take(std::max(k_conv0_bwd_scratch_floats(B, p.Tl[0], c.conv_dim[0]),
+                               k_conv0_wgrad_scratch_floats(B, c.conv_dim[0], c.conv_kernel[0])) * sizeof(float));
+    if (c.feat_extract_norm == 1) p.fe_dp = cv.take((size_t)B * p.Tl[0] * c.conv_dim[0] * b2);  // (d conv0 output lives here too)
   }
   p.bufA = cv.take(whisper ? 256 : (size_t)B * p.Tl[0] * c.conv_dim[0] * b2);
   p.bufB = cv.take(whisper ? 256 : (size_t)B * p.Tl[1] * c.conv_dim[1] * b2);
@@ -749,9 +756,12 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
                         c.conv_kernel[0], c.conv_stride[0], st));
   } else {
     // layer-norm variant (XLSR, modeling_wav2vec2.py:275-299): conv + bias -> LayerNorm over channels -> GELU
-    TRY(k_conv0_bias(input_values, P + e->p_conv_w[0], c.conv_bias ? P + e->p_conv_b[0] : nullptr, BF(p.bufA), B, T,
+    // (--no_freeze keeps the pre-LayerNorm conv output and the statistics of every layer for the backward)
+    bf16* pre0 = p.fe_train ? BF(p.cpre[0]) : BF(p.bufA);
+    TRY(k_conv0_bias(input_values, P + e->p_conv_w[0], c.conv_bias ? P + e->p_conv_b[0] : nullptr, pre0, B, T,
                      p.Tl[0], c.conv_dim[0], c.conv_kernel[0], c.conv_stride[0], st));
-    TRY(k_layernorm_fwd(BF(p.bufA), nullptr, P + e->p_cln_w[0], P + e->p_cln_b[0], nullptr, BF(p.bufA), nullptr, nullptr,
+    TRY(k_layernorm_fwd(pre0, nullptr, P + e->p_cln_w[0], P + e->p_cln_b[0], nullptr, p.fe_train ? BF(p.act[0]) : BF(p.bufA),
+                        p.fe_train ? FP(p.fe_st[0]) : nullptr, p.fe_train ? FP(p.fe_st[0]) + (size_t)B * p.Tl[0] : nullptr,
                         B * p.Tl[0], c.conv_dim[0], 1e-5f, none, none, st, none, true));
   }
   {
@@ -759,15 +769,17 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
     for (int i = 1; i < nc; ++i) {
       bf16* dst = (i == nc - 1) ? BF(p.feat) : (p.fe_train ? BF(p.act[i]) : ((i & 1) ? BF(p.bufB) : BF(p.bufA)));
       const int Ci = c.conv_dim[i - 1], Co = c.conv_dim[i], k = c.conv_kernel[i], s = c.conv_stride[i];
+      bf16* conv_out = (ln_fe && p.fe_train) ? BF(p.cpre[i]) : dst;  // layer-norm variant, training: pre-LN values are kept
       Gemm g(p.Tl[i], Co, k * Ci);
-      g.a(src, (long)s * Ci).b(e->conv_w[i], (long)k * Ci).c(dst, Co)
+      g.a(src, (long)s * Ci).b(e->conv_w[i], (long)k * Ci).c(conv_out, Co)
           .batch(B, 1, (long)p.Tl[i - 1] * Ci, 0, 0, 0, (long)p.Tl[i] * Co, 0);
       if (c.conv_bias) g.with_bias(P + e->p_conv_b[i]);
       if (!ln_fe) g.epi(SSAK_EPI_GELU, nullptr, p.fe_train ? BF(p.cpre[i]) : nullptr);
       TRY(g.run(st));
       if (ln_fe)
-        TRY(k_layernorm_fwd(dst, nullptr, P + e->p_cln_w[i], P + e->p_cln_b[i], nullptr, dst, nullptr, nullptr, B * p.Tl[i], Co,
-                            1e-5f, none, none, st, none, true));
+        TRY(k_layernorm_fwd(conv_out, nullptr, P + e->p_cln_w[i], P + e->p_cln_b[i], nullptr, dst,
+                            p.fe_train ? FP(p.fe_st[i]) : nullptr, p.fe_train ? FP(p.fe_st[i]) + (size_t)B * p.Tl[i] : nullptr,
+                            B * p.Tl[i], Co, 1e-5f, none, none, st, none, true));
       src = dst;
     }
   }
@@ -881,8 +893,6 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
     return SSAK_ERR_STATE;
   }
   SSAK_REQUIRE(e->G, "w2v2_backward: no gradient buffer bound");
-  SSAK_REQUIRE(e->cfg.arch == 1 || e->cfg.freeze_feature_encoder || e->cfg.feat_extract_norm == 0,
-               "w2v2_backward: --no_freeze is built for the group-norm (base) feature encoder only");
   Plan& p = e->plan;
   SSAK_REQUIRE(workspace_bytes >= p.total, "w2v2_backward: workspace too small");
   const ssak_w2v2_config& c = e->cfg;
@@ -1127,6 +1137,7 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, dfeat, nullptr,
                       Gd + e->p_fpln_w, Gd + e->p_fpln_b, FP(p.lnpart), M, C, none, none, st));
   if (p.fe_train) {
+    const bool ln_fe = c.feat_extract_norm == 1;
     // ---- a3 backward (--no_freeze): conv stack in reverse.  Per layer: GELU', weight gradient as per-utterance
     // K-major GEMMs on the overlapping-row operand (slabs summed in a fixed order), input gradient in column form
     // (one GEMM) + col2im; finally conv0 + GroupNorm + GELU backward by recomputation from the waveform.
@@ -1136,7 +1147,15 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
       const bf16* dact = (i & 1) ? BF(p.fe_db) : BF(p.fe_da);
       bf16* dprev = ((i - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da);
       const bf16* act_prev = BF(p.act[i - 1]);
-      TRY(k_gelu_grad_mul(dact, BF(p.cpre[i]), BF(p.fe_dp), (long)B * Ti * Co, st));
+      if (ln_fe) {
+        // layer-norm variant: act = gelu(LN(conv + bias)); one kernel takes d act through GELU' and the LayerNorm
+        // (recomputed from the kept pre-LN values + statistics) and sums d gamma / d beta and the conv bias gradient
+        TRY(k_layernorm_bwd(dact, nullptr, BF(p.cpre[i]), FP(p.fe_st[i]), FP(p.fe_st[i]) + (size_t)B * Ti, P + e->p_cln_w[i], nullptr,
+                            BF(p.fe_dp), BF(p.fe_dp), Gd + e->p_cln_w[i], Gd + e->p_cln_b[i], FP(p.lnpart), B * Ti, Co, none, none, st, none,
+                            c.conv_bias ? Gd + e->p_conv_b[i] : nullptr, P + e->p_cln_b[i]));
+      } else {
+        TRY(k_gelu_grad_mul(dact, BF(p.cpre[i]), BF(p.fe_dp), (long)B * Ti * Co, st));
+      }
       TRY(Gemm(Co, k * Ci, Ti).a(BF(p.fe_dp), Co, true).b(act_prev, (long)s * Ci, true).c(FP(p.fe_slab), (long)k * Ci, true)
               .batch(B, 1, (long)Ti * Co, 0, (long)Tp * Ci, 0, (long)Co * k * Ci, 0).run(st));
       TRY(k_sum_slabs(FP(p.fe_slab), B, (long)Co * k * Ci, FP(p.fe_dwr), st));
@@ -1145,9 +1164,18 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
               .batch(B, 1, (long)Ti * Co, 0, 0, 0, (long)Ti * k * Ci, 0).run(st));
       TRY(k_col2im(BF(p.fe_dxcol), dprev, B, Tp, Ti, Ci, k, s, st));
     }
-    TRY(k_conv0_gn_gelu_bwd(e->last_input, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0], BF(p.fe_da),
-                            (const double*)(ws + p.stats0), FP(p.fe_c0), Gd + e->p_conv_w[0], Gd + e->p_cln_w[0],
-                            Gd + e->p_cln_b[0], B, p.T, p.Tl[0], c.conv_dim[0], st));
+    if (ln_fe) {
+      const int C0 = c.conv_dim[0], T0 = p.Tl[0];
+      TRY(k_layernorm_bwd(BF(p.fe_da), nullptr, BF(p.cpre[0]), FP(p.fe_st[0]), FP(p.fe_st[0]) + (size_t)B * T0, P + e->p_cln_w[0], nullptr,
+                          BF(p.fe_dp), BF(p.fe_dp), Gd + e->p_cln_w[0], Gd + e->p_cln_b[0], FP(p.lnpart), B * T0, C0, none, none, st, none,
+                          c.conv_bias ? Gd + e->p_conv_b[0] : nullptr, P + e->p_cln_b[0]));
+      TRY(k_conv0_wgrad(BF(p.fe_dp), e->last_input, Gd + e->p_conv_w[0], FP(p.fe_c0), B, p.T, T0, C0, c.conv_kernel[0],
+                        c.conv_stride[0], st));
+    } else {
+      TRY(k_conv0_gn_gelu_bwd(e->last_input, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0], BF(p.fe_da),
+                              (const double*)(ws + p.stats0), FP(p.fe_c0), Gd + e->p_conv_w[0], Gd + e->p_cln_w[0],
+                              Gd + e->p_cln_b[0], B, p.T, p.Tl[0], c.conv_dim[0], st));
+    }
   }
   }
   // everything else: the leading small matrices and the whole vector region (biases, LayerNorm affine)

@@ -296,3 +296,28 @@ def test_no_freeze_feature_encoder_gradients(mods):
     w_before = model.param("wav2vec2.feature_extractor.conv_layers.3.conv.weight").clone()
     AdamW(model, lr=1e-3, warmup_steps=0).step()
     assert (model.param("wav2vec2.feature_extractor.conv_layers.3.conv.weight") - w_before).abs().max().item() > 0
+
+
+def test_no_freeze_layer_norm_feature_encoder_gradients(mods):
+    """--no_freeze with the XLSR-style feature encoder (conv + bias -> LayerNorm -> GELU on every layer, stable-layer-norm
+    encoder, ragged lengths): conv weights / biases and LayerNorm affines against the oracle's autograd."""
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    oc = R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True).deterministic()
+    p = R.init_params(oc, 23)
+    rng = np.random.default_rng(8)
+    lens = [8000, 6100, 7333]
+    waves = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    x = R.zero_mean_unit_var_norm(waves)
+    labels = R.pad_labels([list(rng.integers(1, 32, n)) for n in (7, 3, 5)])
+    loss, logits, grads = R.loss_and_grads(p, oc, torch.tensor(x), lens, torch.tensor(labels), freeze_feature_encoder=False)
+    model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc), freeze_feature_encoder=False).train()
+    model.load_state_dict(p)
+    assert model.num_trainable == model.num_params
+    out = model(torch.tensor(x), lengths=torch.tensor(lens), labels=torch.tensor(labels))
+    assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
+    model.backward()
+    fe = {n: g.numpy() for n, g in grads.items() if n.startswith("wav2vec2.feature_extractor.")}
+    assert len(fe) == 7 * 4  # conv weight + bias, LayerNorm weight + bias per layer
+    worst = _check_grads(model, fe, 8e-2)
+    print("no_freeze (layer-norm FE) worst FE grad", worst)
+    _check_grads(model, {n: g.numpy() for n, g in grads.items() if not n.startswith("wav2vec2.feature_extractor.")}, 6e-2)
