@@ -196,6 +196,9 @@ int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const
  * AdamW update with bias correction for 1-based `step`; shadow_bf16 (or NULL) receives the bf16 copy of the
  * new parameters.  The clip coefficient is read on the device: no host synchronisation. */
 int ssak_grad_sumsq(const float* grads, long n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* out[0] += sum g^2: the joint norm over several buffers (the SpeechBrain recipe clips the wav2vec2 and head gradients as one
+ * vector, speechbrain core Brain.check_gradients under ssak/train/speechbrain/wav2vec_train.py:113,125) */
+int ssak_grad_sumsq_add(const float* grads, long n, float* out, void* workspace, size_t workspace_bytes, void* stream);
 int ssak_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
                     const float* gnorm_sq, float max_norm, float grad_scale, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, void* stream);
@@ -257,6 +260,54 @@ typedef void (*ssak_grad_ready_fn)(long offset, long count, void* user);
 int ssak_w2v2_set_grad_ready_callback(ssak_w2v2* h, ssak_grad_ready_fn fn, void* user);
 /* dlogits [B,F,V] fp32 (e.g. from ssak_ctc_loss_fwd_bwd); overwrites grads[0, num_trainable). */
 int ssak_w2v2_backward(ssak_w2v2* h, const float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
+/* The same model stopped at the encoder's last hidden state -- `self.modules.wav2vec2(wavs)` of the SpeechBrain recipe
+ * (ssak/train/speechbrain/wav2vec_train.py:51; HuggingFaceWav2Vec2 returns Wav2Vec2Model(wav)[0]): hidden [B,F,H] bf16 out, no
+ * final dropout, no lm_head.  ssak_w2v2_backward_hidden continues from d loss / d hidden [B,F,H] bf16 (the unfrozen case,
+ * :95-137); the lm_head gradient stays zero.  A backward must match the kind of forward that preceded it. */
+int ssak_w2v2_forward_hidden(ssak_w2v2* h, const float* input_values, const int32_t* lens, int B, int T,
+                             const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed, int training,
+                             void* hidden_bf16, int32_t* frame_lens, void* workspace, size_t workspace_bytes, void* stream);
+int ssak_w2v2_backward_hidden(ssak_w2v2* h, const void* dhidden_bf16, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- f4: the SpeechBrain recipe's acoustic head ------------------------------------------------
+ * Row-wise pieces of `x = enc(feats); logits = ctc_lin(x)` (ssak/train/speechbrain/wav2vec_train.py:51-54) with the modules
+ * of ssak/train/speechbrain/fr/hyperparameters_wav2vec_finetune_cv-fr.yaml:87-137; the Linears are ssak_gemm_bf16, log-softmax
+ * + ctc_cost is ssak_ctc_loss_fwd_bwd.  Host-side composition: ssak_amd/sb_head.py.
+ *
+ * ssak_utt_norm_*: F.layer_norm(x, x.shape[1:]) without affine parameters -- the wrapper's waveform normalisation (fp32,
+ * is_bf16 = 0) and its output_norm over (frames x features) (bf16, is_bf16 = 1).  x, y [B, n]; stats [B][2] = (mean, rstd) out
+ * (may be NULL in the forward when no backward follows); the backward takes y, the forward's OUTPUT.  n a multiple of 8 / 4. */
+size_t ssak_utt_norm_workspace_bytes(int B);
+int ssak_utt_norm_fwd(const void* x, void* y, int B, long n, int is_bf16, float eps, float* stats, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int ssak_utt_norm_bwd(const void* dy, const void* y, void* dx, int B, long n, int is_bf16, const float* stats, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* BatchNorm1d over all M = B*T rows of x [M, C] bf16 (speechbrain BatchNorm1d on [B,T,C]: statistics over batch and time,
+ * padding frames included), then LeakyReLU(leaky_slope) and dropout(drop_p), one fused apply pass: y [M, C] bf16.
+ * training != 0: batch statistics (biased variance), running_mean / running_var (or NULL) updated with `momentum` and the
+ * unbiased variance; training == 0: the running statistics, no dropout.  save_mean / save_rstd [C] out are what the backward
+ * needs together with x.  Backward: dy -> dx, dgamma / dbeta [C] overwritten; the dropout mask is recomputed from
+ * (seed, drop_stream, element index).  Sums are two-stage and fixed-order (deterministic).  C a multiple of 8. */
+size_t ssak_batchnorm_workspace_bytes(int C);
+int ssak_batchnorm_act_fwd(const void* x, void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, int training, float leaky_slope, float drop_p,
+                           uint64_t seed, uint32_t drop_stream, float* save_mean, float* save_rstd, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int ssak_batchnorm_act_bwd(const void* dy, const void* x, void* dx, int M, int C, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_rstd, float leaky_slope, float drop_p, uint64_t seed,
+                           uint32_t drop_stream, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.Adadelta (yaml :119-122: lr 1.0, rho 0.95, eps 1e-8): square_avg = rho sq + (1-rho) g^2;
+ * delta = sqrt(acc_delta + eps) / sqrt(square_avg + eps) * g; acc_delta = rho acc + (1-rho) delta^2; p -= lr * delta.
+ * g is first multiplied by grad_scale (1 / world size after a sum all-reduce) and by min(1, max_norm / (sqrt(*gnorm_sq) *
+ * grad_scale + 1e-6)) when gnorm_sq != NULL and max_norm > 0 -- the convention of ssak_adamw_step. */
+int ssak_adadelta_step(float* params, const float* grads, float* square_avg, float* acc_delta, void* shadow_bf16, long n,
+                       const float* gnorm_sq, float max_norm, float grad_scale, float lr, float rho, float eps, float weight_decay,
+                       void* stream);
+int ssak_cast_f32_bf16(const float* src, void* dst_bf16, long n, void* stream);
+/* out[N] = column sums of X [M, N] bf16 (row stride ld): the bias gradient of a Linear from its output gradient.  Two-stage,
+ * fixed-order; N and ld multiples of 8. */
+size_t ssak_colsum_workspace_bytes(int N);
+int ssak_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -333,6 +333,8 @@ def forward(p: Dict[str, torch.Tensor], cfg: W2V2Config, input_values: torch.Ten
             stages[f"layer{l}"] = h
     if cfg.do_stable_layer_norm:
         h = _ln(p, "wav2vec2.encoder.layer_norm", h, eps)
+    if stages is not None:
+        stages["last_hidden"] = h  # Wav2Vec2Model(...)[0]: what the SpeechBrain recipe's wav2vec2 module returns
     h = F.dropout(h, p=cfg.final_dropout, training=train)
     logits = F.linear(h, p["lm_head.weight"], p["lm_head.bias"])
     loss = None

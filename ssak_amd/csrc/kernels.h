@@ -75,7 +75,7 @@ int k_conv_wgrad_unrearrange(const float* dwr, float* g, int Co, int Ci, int k, 
 
 // optim.hip
 // out[0] = sum g^2: 1024 per-workgroup partials in `partial` (>= 1024 floats), then one fixed-order pass -- deterministic
-int k_sumsq(const float* g, long n, float* out /*[1]*/, float* partial, hipStream_t st);
+int k_sumsq(const float* g, long n, float* out /*[1]*/, float* partial, hipStream_t st, bool add = false /*out[0] += */);
 int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, const float* gnorm_sq, float max_norm,
             float grad_scale, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t st);
 

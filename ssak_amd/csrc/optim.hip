@@ -22,11 +22,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = block_sum(s, red);
   if (threadIdx.x == 0) out[blockIdx.x] = s;  // per-workgroup partial; summed in a fixed order by sumsq_final_kernel
 }
-__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out,
+                                                           int add) {
   __shared__ float red[16];
   float s = threadIdx.x < n ? partial[threadIdx.x] : 0.f;
   s = block_sum(s, red);
-  if (threadIdx.x == 0) out[0] = s;
+  if (threadIdx.x == 0) out[0] = add ? out[0] + s : s;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -83,12 +84,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-int k_sumsq(const float* g, long n, float* out, float* partial, hipStream_t st) {
+int k_sumsq(const float* g, long n, float* out, float* partial, hipStream_t st, bool add) {
   if (n <= 0) return SSAK_OK;
   const int blocks = (int)fmin(1024.0, (double)ssak_cdiv(n, 1024));
   sumsq_kernel<<<blocks, 256, 0, st>>>(g, n, partial);
   SSAK_LAUNCH_CHECK();
-  sumsq_final_kernel<<<1, 1024, 0, st>>>(partial, blocks, out);
+  sumsq_final_kernel<<<1, 1024, 0, st>>>(partial, blocks, out, add ? 1 : 0);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -110,6 +111,13 @@ extern "C" int ssak_grad_sumsq(const float* grads, long n, float* out, void* wor
   SSAK_REQUIRE(((uintptr_t)grads & 15) == 0, "grad_sumsq: buffer must be 16-byte aligned");
   SSAK_REQUIRE(workspace && workspace_bytes >= 1024 * sizeof(float), "grad_sumsq: workspace of 4096 bytes needed");
   return k_sumsq(grads, n, out, (float*)workspace, (hipStream_t)stream);
+}
+
+extern "C" int ssak_grad_sumsq_add(const float* grads, long n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(grads && out && n > 0, "grad_sumsq_add: bad arguments");
+  SSAK_REQUIRE(((uintptr_t)grads & 15) == 0, "grad_sumsq_add: buffer must be 16-byte aligned");
+  SSAK_REQUIRE(workspace && workspace_bytes >= 1024 * sizeof(float), "grad_sumsq_add: workspace of 4096 bytes needed");
+  return k_sumsq(grads, n, out, (float*)workspace, (hipStream_t)stream, true);
 }
 
 extern "C" int ssak_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,

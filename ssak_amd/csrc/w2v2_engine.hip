@@ -99,6 +99,7 @@ struct ssak_w2v2 {
   float* pc_norms = nullptr;  // [2K]: ||v||^2 per tap | scratch
   Plan plan;
   bool have_fwd = false;
+  bool fwd_hidden = false;  // the kept forward ended at the hidden state (ssak_w2v2_forward_hidden)
   uint64_t seed = 0;
   const uint8_t* spec_mask = nullptr;
   const int32_t* lens = nullptr;
@@ -676,11 +677,12 @@ extern "C" int ssak_w2v2_num_frames(const ssak_w2v2* e, int T) {
   return L;
 }
 
-extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const int32_t* lens, int B, int T,
-                                 const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed,
-                                 int training, float* logits, int32_t* frame_lens, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  SSAK_REQUIRE(e && input_values && logits && workspace, "w2v2_forward: null pointer");
+// logits != NULL: through final dropout + lm_head (Wav2Vec2ForCTC); hidden != NULL: the encoder's last hidden state
+// (Wav2Vec2Model()[0], what the SpeechBrain recipe's wav2vec2 module returns) and no head.
+static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* lens, int B, int T, const uint8_t* spec_mask,
+                        const uint8_t* layer_keep /*host*/, uint64_t seed, int training, float* logits, bf16* hidden,
+                        int32_t* frame_lens, void* workspace, size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(e && input_values && (logits || hidden) && workspace, "w2v2_forward: null pointer");
   SSAK_REQUIRE(e->P && e->W, "w2v2_forward: bind + sync_weights first");
   SSAK_REQUIRE(B > 0 && T > 0, "w2v2_forward: bad shape B=%d T=%d", B, T);
   SSAK_REQUIRE(((uintptr_t)workspace & 255) == 0, "w2v2_forward: workspace must be 256-byte aligned");
@@ -875,6 +877,13 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   }
   // ---- a8: final dropout + lm_head -> fp32 logits
   const bf16* xl = BF(p.x[c.num_layers]);
+  if (hidden) {
+    SSAK_HIP(hipMemcpyAsync(hidden, xl, (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
+    e->have_fwd = tr;
+    e->fwd_hidden = true;
+    return SSAK_OK;
+  }
+  e->fwd_hidden = false;
   if (tr && c.final_dropout > 0.f) {
     TRY(k_layernorm_fwd(xl, nullptr, nullptr, nullptr, BF(p.xf), nullptr, nullptr, nullptr, M, H, 0.f,
                         DS(c.final_dropout, DS_FINAL), none, st));
@@ -885,11 +894,30 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
   return SSAK_OK;
 }
 
-extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
-  SSAK_REQUIRE(e && dlogits && workspace, "w2v2_backward: null pointer");
-  if (!e->have_fwd) {
-    ssak_set_error("w2v2_backward: no training-mode forward to differentiate");
+extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const int32_t* lens, int B, int T,
+                                 const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed,
+                                 int training, float* logits, int32_t* frame_lens, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(logits, "w2v2_forward: null pointer");
+  return forward_impl(e, input_values, lens, B, T, spec_mask, layer_keep, seed, training, logits, nullptr, frame_lens, workspace,
+                      workspace_bytes, stream);
+}
+
+extern "C" int ssak_w2v2_forward_hidden(ssak_w2v2* e, const float* input_values, const int32_t* lens, int B, int T,
+                                        const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed,
+                                        int training, void* hidden_bf16, int32_t* frame_lens, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(hidden_bf16, "w2v2_forward_hidden: null pointer");
+  return forward_impl(e, input_values, lens, B, T, spec_mask, layer_keep, seed, training, nullptr, (bf16*)hidden_bf16, frame_lens,
+                      workspace, workspace_bytes, stream);
+}
+
+// dlogits (after ssak_w2v2_forward) or dhidden (after ssak_w2v2_forward_hidden): exactly one is non-null
+static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  SSAK_REQUIRE(e && (dlogits || dhidden) && workspace, "w2v2_backward: null pointer");
+  if (!e->have_fwd || e->fwd_hidden != (dhidden != nullptr)) {
+    ssak_set_error("w2v2_backward: no matching training-mode forward to differentiate");
     return SSAK_ERR_STATE;
   }
   SSAK_REQUIRE(e->G, "w2v2_backward: no gradient buffer bound");
@@ -924,12 +952,14 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
 
   const long n_grad = (e->cfg.arch == 1 || e->cfg.freeze_feature_encoder) ? e->n_train : e->n_total;
   SSAK_HIP(hipMemsetAsync(Gd, 0, (size_t)n_grad * sizeof(float), st));
-  // ---- lm_head
+  // ---- lm_head (its gradient stays zero when the backward starts from the hidden state)
   bf16* dlog = BF(p.dlog);
-  TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
-  const bf16* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
-  TRY(Gemm(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
-  TRY(k_colsum(dlog, V, M, V, Gd + e->p_lm_b, st, FP(p.lnpart), cs_floats));
+  if (dlogits) {
+    TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
+    const bf16* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
+    TRY(Gemm(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_colsum(dlog, V, M, V, Gd + e->p_lm_b, st, FP(p.lnpart), cs_floats));
+  }
   auto announce = [&](long off, long cnt) {
     if (e->on_ready && cnt > 0) e->on_ready(off, cnt, e->on_ready_user);
   };
@@ -937,8 +967,11 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   announce(e->p_lm_w, (long)V * H);
   bf16* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
   bf16* gB = nullptr;
-  TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).run(st));
-  if (c.final_dropout > 0.f)  // replay the final-dropout mask with the kernel that applied it in the forward
+  if (dhidden)
+    SSAK_HIP(hipMemcpyAsync(gA, dhidden, (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
+  else
+    TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).run(st));
+  if (dlogits && c.final_dropout > 0.f)  // replay the final-dropout mask with the kernel that applied it in the forward
     TRY(k_layernorm_fwd(gA, nullptr, nullptr, nullptr, gA, nullptr, nullptr, nullptr, M, H, 0.f, DS(c.final_dropout, DS_FINAL),
                         none, st));
   // ---- encoder layers, last to first.  gA (+gB) = gradient w.r.t. x[l+1], the layer output (post-LN) or the
@@ -1183,4 +1216,15 @@ extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* work
   announce(e->p_lm_w + (long)V * H, n_grad - (e->p_lm_w + (long)V * H));
   e->have_fwd = false;
   return SSAK_OK;
+}
+
+extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* workspace, size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(dlogits, "w2v2_backward: null pointer");
+  return backward_impl(e, dlogits, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssak_w2v2_backward_hidden(ssak_w2v2* e, const void* dhidden_bf16, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  SSAK_REQUIRE(dhidden_bf16, "w2v2_backward_hidden: null pointer");
+  return backward_impl(e, nullptr, (const bf16*)dhidden_bf16, workspace, workspace_bytes, stream);
 }

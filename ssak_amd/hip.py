@@ -90,6 +90,20 @@ def _load():
         "ssak_w2v2_forward": (i32, [vp, vp, vp, i32, i32, vp, vp, C.c_uint64, i32, vp, vp, vp, sz, vp]),
         "ssak_w2v2_backward": (i32, [vp, vp, vp, sz, vp]),
         "ssak_w2v2_set_grad_ready_callback": (i32, [vp, GRAD_READY_FN, vp]),
+        "ssak_w2v2_forward_hidden": (i32, [vp, vp, vp, i32, i32, vp, vp, C.c_uint64, i32, vp, vp, vp, sz, vp]),
+        "ssak_w2v2_backward_hidden": (i32, [vp, vp, vp, sz, vp]),
+        "ssak_grad_sumsq_add": (i32, [vp, C.c_long, vp, vp, sz, vp]),
+        "ssak_utt_norm_workspace_bytes": (sz, [i32]),
+        "ssak_utt_norm_fwd": (i32, [vp, vp, i32, C.c_long, i32, f32, vp, vp, sz, vp]),
+        "ssak_utt_norm_bwd": (i32, [vp, vp, vp, i32, C.c_long, i32, vp, vp, sz, vp]),
+        "ssak_batchnorm_workspace_bytes": (sz, [i32]),
+        "ssak_batchnorm_act_fwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, f32, f32, C.c_uint64, C.c_uint32, vp, vp,
+                                         vp, sz, vp]),
+        "ssak_batchnorm_act_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, C.c_uint64, C.c_uint32, vp, vp, vp, sz, vp]),
+        "ssak_adadelta_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, vp]),
+        "ssak_cast_f32_bf16": (i32, [vp, vp, C.c_long, vp]),
+        "ssak_colsum_workspace_bytes": (sz, [i32]),
+        "ssak_colsum_bf16": (i32, [vp, C.c_long, i32, i32, vp, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

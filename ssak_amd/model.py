@@ -213,8 +213,9 @@ class Wav2Vec2ForCTC:
                  lengths=None):
         return self.forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths)
 
-    def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                labels: Optional[torch.Tensor] = None, mask_time_indices=None, layer_keep=None, lengths=None):
+    def _prelude(self, input_values, attention_mask, mask_time_indices, layer_keep, lengths, training):
+        """Everything before the engine call: device copies, workspace, the host-drawn SpecAugment spans / LayerDrop
+        decisions and the step's dropout seed."""
         cfg = self.config
         x = input_values.to(device=self.device, dtype=torch.float32).contiguous()
         B, T = x.shape[0], x.shape[-1]  # [B, samples] (wav2vec2) or [B, mel bins, feature frames] (Whisper encoder)
@@ -224,14 +225,6 @@ class Wav2Vec2ForCTC:
         if lengths is not None:
             lens_dev = torch.as_tensor(lengths).to(device=self.device, dtype=torch.int32).contiguous()
         F = self.num_frames(T)
-        training = self.training
-        if labels is not None:
-            labels = torch.as_tensor(labels)
-            # the reference checks labels.max() on every call, which forces a device sync when the labels live on
-            # the GPU (modeling_wav2vec2.py:1686-1687); here host-resident labels are checked on the host and
-            # device-resident ones are validated inside the CTC kernel (bad label -> NaN loss), so the step never syncs
-            if not labels.is_cuda and labels.numel() and int(labels.max()) >= cfg.vocab_size:
-                raise ValueError(f"Label values must be <= vocab_size: {cfg.vocab_size}")
         ws = self._workspace(B, T, training)
         # stochastic regularisers drawn on the host ahead of the step, as the reference does
         mask_dev, keep_arr = None, None
@@ -263,9 +256,24 @@ class Wav2Vec2ForCTC:
         if layer_keep is not None:
             keep_arr = (C.c_uint8 * cfg.num_hidden_layers)(*[int(bool(k)) for k in layer_keep])
         self._step_seed = (int(self._step_seed) * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        flens = torch.empty(B, dtype=torch.int32, device=self.device) if lens_dev is not None else None
+        return x, B, T, F, lens_dev, ws, mask_dev, keep_arr, flens
+
+    def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                labels: Optional[torch.Tensor] = None, mask_time_indices=None, layer_keep=None, lengths=None):
+        cfg = self.config
+        training = self.training
+        if labels is not None:
+            labels = torch.as_tensor(labels)
+            # the reference checks labels.max() on every call, which forces a device sync when the labels live on
+            # the GPU (modeling_wav2vec2.py:1686-1687); here host-resident labels are checked on the host and
+            # device-resident ones are validated inside the CTC kernel (bad label -> NaN loss), so the step never syncs
+            if not labels.is_cuda and labels.numel() and int(labels.max()) >= cfg.vocab_size:
+                raise ValueError(f"Label values must be <= vocab_size: {cfg.vocab_size}")
+        x, B, T, F, lens_dev, ws, mask_dev, keep_arr, flens = self._prelude(input_values, attention_mask, mask_time_indices,
+                                                                            layer_keep, lengths, training)
         Vp = self._c.vocab_size
         logits = torch.empty((B, F, Vp), dtype=torch.float32, device=self.device)
-        flens = torch.empty(B, dtype=torch.int32, device=self.device) if lens_dev is not None else None
         with torch.cuda.device(self.device):
             hip.check(hip.lib.ssak_w2v2_forward(self._h, hip.ptr(x), hip.ptr(lens_dev), B, T, hip.ptr(mask_dev), keep_arr,
                                                 C.c_uint64(int(self._step_seed)), int(training), hip.ptr(logits),
@@ -279,9 +287,35 @@ class Wav2Vec2ForCTC:
             logits = logits[..., :cfg.vocab_size]  # view: the inert padding classes are not part of the contract
         return CTCOutput(loss, logits, nll, flens)
 
+    def forward_hidden(self, input_values: torch.Tensor, attention_mask=None, mask_time_indices=None, layer_keep=None,
+                       lengths=None, keep_graph: Optional[bool] = None):
+        """The encoder's last hidden state [B, F, H] bf16 -- ``Wav2Vec2Model(wav)[0]``, what the SpeechBrain recipe's
+        ``modules.wav2vec2`` wraps (ssak/train/speechbrain/wav2vec_train.py:51).  ``keep_graph`` (default: training mode)
+        keeps the activations for :meth:`backward_hidden`."""
+        training = self.training
+        x, B, T, F, lens_dev, ws, mask_dev, keep_arr, flens = self._prelude(input_values, attention_mask, mask_time_indices,
+                                                                            layer_keep, lengths, training)
+        hidden = torch.empty((B, F, self.config.hidden_size), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib.ssak_w2v2_forward_hidden(self._h, hip.ptr(x), hip.ptr(lens_dev), B, T, hip.ptr(mask_dev), keep_arr,
+                                                       C.c_uint64(int(self._step_seed)), int(training), hip.ptr(hidden),
+                                                       hip.ptr(flens), hip.ptr(ws), ws.numel(), hip.stream()))
+        self._last = ("hidden", mask_dev, lens_dev, x) if training else None
+        return hidden, flens
+
+    def backward_hidden(self, dhidden: torch.Tensor):
+        """d loss / d params from d loss / d hidden [B, F, H] bf16 (the unfrozen wav2vec2 of the SpeechBrain recipe)."""
+        if self._last is None or not isinstance(self._last[0], str):
+            raise RuntimeError("backward_hidden() needs a training-mode forward_hidden()")
+        assert dhidden.dtype == torch.bfloat16 and dhidden.is_contiguous()
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib.ssak_w2v2_backward_hidden(self._h, hip.ptr(dhidden), hip.ptr(self._ws), self._ws.numel(),
+                                                        hip.stream()))
+        self._last = None
+
     def backward(self, grad_scale: float = 1.0):
         """d loss / d params into ``self.grads`` (the counterpart of ``loss.backward()``)."""
-        if self._last is None or self._last[0] is None:
+        if self._last is None or self._last[0] is None or isinstance(self._last[0], str):
             raise RuntimeError("backward() needs a training-mode forward with labels")
         dlogits = self._last[0]
         if grad_scale != 1.0:

@@ -156,3 +156,21 @@ def test_align_host_mirror_matches_oracle(gold):
     d = {c: i for i, c in enumerate(labels)}
     assert align.loose_get_char_index(d, "A", 4) == 5 and align.loose_get_char_index(d, "é", 4) == 7
     assert align.loose_get_char_index(d, "z", 4) == 4 and align.loose_get_char_index(d, "z", None) is None
+
+
+def test_newbob_scheduler_mirror():
+    """ssak_amd.sb_head.NewBobScheduler (the recipe's lr_annealing_* objects, yaml :124-135) against the oracle's list form."""
+    from oracle import sb_head_ref as S
+    from ssak_amd.sb_head import NewBobScheduler
+    vals = [12.0, 11.0, 10.99, 10.98, 9.0, 9.5, 9.4, 0.0, 0.0]
+    for factor, patient in ((0.8, 0), (0.9, 0), (0.5, 2)):
+        sch = NewBobScheduler(1.0, factor, 0.0025, patient)
+        got = []
+        for v in vals:
+            old, new = sch(v)
+            assert old == (got[-1] if got else 1.0)
+            got.append(new)
+        assert got == pytest.approx(S.new_bob(vals, 1.0, factor, 0.0025, patient))
+    sch2 = NewBobScheduler(1.0, 0.8)
+    sch2.load_state_dict(sch.state_dict())
+    assert sch2.hyperparam_value == sch.hyperparam_value and sch2.metric_values == sch.metric_values

@@ -233,3 +233,60 @@ def test_resample_oracle_properties(orig, new):
     assert np.array_equal(resample_ref.resample(x, new, new), x)
     k, width, o, nn = resample_ref.sinc_resample_kernel(orig, new)
     assert k.shape == (nn, 1, 2 * width + o)
+
+
+# ------------------------------------------------------------------ SpeechBrain-recipe head
+def test_sb_head_oracle_vs_torch_modules():
+    """oracle/sb_head_ref.py against the torch modules speechbrain wraps (nn.Linear / nn.BatchNorm1d on [B, C, T] /
+    LeakyReLU), torch.optim.Adadelta and hand-computed NewBob values."""
+    from oracle import sb_head_ref as S
+    g = torch.Generator().manual_seed(0)
+    B, T, H, D, V = 3, 11, 16, 24, 7
+    sd = {}
+    for k, din in ((1, H), (2, D), (3, D)):
+        sd[f"0.linear{k}.w.weight"] = torch.randn(D, din, generator=g) * 0.3
+        sd[f"0.linear{k}.w.bias"] = torch.randn(D, generator=g) * 0.1
+        sd[f"0.bn{k}.norm.weight"] = torch.rand(D, generator=g) + 0.5
+        sd[f"0.bn{k}.norm.bias"] = torch.randn(D, generator=g) * 0.1
+    sd["1.w.weight"], sd["1.w.bias"] = torch.randn(V, D, generator=g), torch.randn(V, generator=g)
+    feats = torch.randn(B, T, H, generator=g)
+    mods, h = [], feats
+    run = [(torch.zeros(D), torch.ones(D)) for _ in range(3)]
+    for k in (1, 2, 3):
+        lin = torch.nn.Linear(h.shape[-1], D)
+        bn = torch.nn.BatchNorm1d(D)
+        lin.weight.data, lin.bias.data = sd[f"0.linear{k}.w.weight"].clone(), sd[f"0.linear{k}.w.bias"].clone()
+        bn.weight.data, bn.bias.data = sd[f"0.bn{k}.norm.weight"].clone(), sd[f"0.bn{k}.norm.bias"].clone()
+        h = torch.nn.functional.leaky_relu(bn(lin(h).transpose(1, 2)).transpose(1, 2), 0.01)
+        mods.append(bn)
+    want = torch.nn.functional.linear(h, sd["1.w.weight"], sd["1.w.bias"])
+    got = S.head_forward(sd, feats, None, True, dropouts=(0, 0, 0), running=run)
+    assert torch.allclose(got, want, atol=1e-6)
+    for i, bn in enumerate(mods):
+        assert torch.allclose(run[i][0], bn.running_mean) and torch.allclose(run[i][1], bn.running_var)
+    # utterance normalisation = layer_norm over everything but the batch axis
+    x = torch.randn(2, 5, 8, generator=g)
+    y = S.utt_norm(x)
+    assert torch.allclose(y[1], (x[1] - x[1].mean()) / torch.sqrt(x[1].var(unbiased=False) + 1e-5), atol=1e-6)
+    # CTC lengths: relative -> absolute by rounding; torch "mean" reduction
+    logits = torch.randn(2, 12, 6, generator=g)
+    tokens = torch.tensor([[1, 2, 3, 0], [4, 5, 0, 0]])
+    l = S.ctc_cost(logits, tokens, [1.0, 0.74], [0.75, 0.5])
+    lp = torch.log_softmax(logits, -1).transpose(0, 1)
+    per = torch.nn.functional.ctc_loss(lp, tokens, torch.tensor([12, 9]), torch.tensor([3, 2]), 0, reduction="none")
+    assert torch.allclose(l, (per / torch.tensor([3.0, 2.0])).mean())
+    # Adadelta
+    p = torch.randn(50, generator=g)
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.Adadelta([pt], lr=1.0, rho=0.95, eps=1e-8)
+    pn, sq, acc = p.numpy().copy(), np.zeros(50, np.float32), np.zeros(50, np.float32)
+    for _ in range(4):
+        gr = torch.randn(50, generator=g)
+        pt.grad = gr.clone()
+        opt.step()
+        S.adadelta_step(pn, gr.numpy(), sq, acc)
+    assert np.allclose(pn, pt.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert S.clip_coef([torch.full((4,), 5.0)], 5.0) == pytest.approx(0.5, rel=1e-6)
+    # NewBob: 10 -> 9 improves 10 %; 9 -> 8.99 improves 0.11 % < 0.25 %: anneal; 8.0 -> 8.0: anneal again
+    assert S.new_bob([10, 9, 8.99, 8.0, 8.0], 1.0, 0.8) == pytest.approx([1.0, 1.0, 0.8, 0.8, 0.64])
+    assert S.new_bob([5.0, 5.0, 5.0], 1e-4, 0.9, patient=1) == pytest.approx([1e-4, 1e-4, 0.9e-4])
