@@ -32,39 +32,108 @@ __device__ __forceinline__ void store8(bf16* p, const float* v) {
 }
 
 // ---------------------------------------------------------------- BatchNorm1d over rows
-// partial[rb][0][c] = sum x, partial[rb][1][c] = sum x^2 over the rows rb, rb + NB, ... (fp32: <= ~64 terms per partial)
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const bf16* __restrict__ x, long ld, int M, int C,
-                                                               float* __restrict__ partial) {
-  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
-  if (c0 >= C) return;
-  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int r = blockIdx.x; r < M; r += gridDim.x) {
-    float v[8];
-    load8(x + (long)r * ld + c0, v);
+// Thread mapping of the row-streaming kernels: a row is cpr = C / 8 chunks of 8 columns (16 B); a workgroup of NT threads
+// covers cpb = min(cpr, NT) chunks (grid.y column blocks when a row is wider) and `lanes` = NT / cpb rows at a time, so that
+// narrow and wide rows both keep every wave busy and each wave reads whole contiguous row segments.  Rows are taken four at
+// a time with the loads issued first (memory-level parallelism: these passes are pure HBM streaming).
+struct RowMap {
+  int cc, rl, lanes, tcc, cpb;
+  bool active;
+  __device__ __forceinline__ RowMap(int C, int NT) {
+    const int cpr = C >> 3;
+    cpb = cpr < NT ? cpr : NT;
+    lanes = NT / cpb;
+    tcc = threadIdx.x % cpb;
+    rl = threadIdx.x / cpb;
+    cc = blockIdx.y * cpb + tcc;
+    active = rl < lanes && cc < cpr;
+  }
+};
+constexpr int BN_STAT_THREADS = 1024;
+
+// sums of up to two per-column quantities over this workgroup's rows -> partial[blockIdx.x][0..1][c] (lanes reduced through LDS)
+__device__ __forceinline__ void bn_block_reduce_store(const RowMap& m, float (&s)[8], float (&q)[8], float* __restrict__ partial,
+                                                      int C, float* red) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s[k] += v[k];
-      q[k] = fmaf(v[k], v[k], q[k]);
+  for (int which = 0; which < 2; ++which) {
+    __syncthreads();
+    if (m.rl < m.lanes) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[(k * m.lanes + m.rl) * m.cpb + m.tcc] = which ? q[k] : s[k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < m.cpb * 8; t += blockDim.x) {
+      const int k = t / m.cpb, tc = t % m.cpb;
+      float v = 0.f;
+      for (int l = 0; l < m.lanes; ++l) v += red[(k * m.lanes + l) * m.cpb + tc];
+      const int c = (blockIdx.y * m.cpb + tc) * 8 + k;
+      if (c < C) partial[((long)blockIdx.x * 2 + which) * C + c] = v;
     }
   }
-  float* ps = partial + ((long)blockIdx.x * 2) * C + c0;
+}
+
+// partial[rb][0][c] = sum x, partial[rb][1][c] = sum x^2 over the rows of workgroup rb (fp32: a few dozen terms per partial)
+__global__ __launch_bounds__(BN_STAT_THREADS) void bn_stats_partial_kernel(const bf16* __restrict__ x, long ld, int M, int C,
+                                                                           float* __restrict__ partial) {
+  extern __shared__ float red[];
+  const RowMap m(C, BN_STAT_THREADS);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (m.active) {
+    const int stride = gridDim.x * m.lanes;
+    for (int r = blockIdx.x * m.lanes + m.rl; r < M; r += 4 * stride) {
+      bf16x8 v[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    ps[k] = s[k];
-    ps[C + k] = q[k];
+      for (int u = 0; u < 4; ++u) {
+        const int ru = r + u * stride;
+        v[u] = ru < M ? *reinterpret_cast<const bf16x8*>(x + (long)ru * ld + m.cc * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float f = (float)v[u][k];
+          s[k] += f;
+          q[k] = fmaf(f, f, q[k]);
+        }
+    }
+  }
+  bn_block_reduce_store(m, s, q, partial, C, red);
+}
+// Column totals of the two partial planes: workgroup = 64 columns x 16 slot groups, fixed-order sums in double.
+// (One thread per column walking all the partials serially was 150 us of dependent-latency loads.)
+__device__ __forceinline__ void bn_partial_totals(const float* __restrict__ partial, int nb, int C, double& s, double& q,
+                                                  double (*red)[16][64]) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  double ps = 0, pq = 0;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = ry; b < nb; b += 16) {
+      ps += (double)partial[((long)b * 2) * C + c];
+      pq += (double)partial[((long)b * 2 + 1) * C + c];
+    }
+  }
+  red[0][ry][cx] = ps;
+  red[1][ry][cx] = pq;
+  __syncthreads();
+  s = 0, q = 0;
+  if (ry == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s += red[0][r][cx];
+      q += red[1][r][cx];
+    }
   }
 }
 // mean / rstd of the batch (biased variance), running statistics updated with the unbiased one (torch.nn.BatchNorm1d)
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partial, int nb, int M, int C, float eps,
-                                                             float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                             float* __restrict__ run_mean, float* __restrict__ run_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0, q = 0;
-  for (int b = 0; b < nb; ++b) {
-    s += (double)partial[((long)b * 2) * C + c];
-    q += (double)partial[((long)b * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ partial, int nb, int M, int C, float eps,
+                                                              float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                              float* __restrict__ run_mean, float* __restrict__ run_var) {
+  __shared__ double red[2][16][64];
+  double s, q;
+  bn_partial_totals(partial, nb, C, s, q, red);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if ((threadIdx.x >> 6) != 0 || c >= C) return;
   const double mu = s / M;
   double var = q / M - mu * mu;
   var = var > 0 ? var : 0;
@@ -88,8 +157,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
                                                        int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                                        uint64_t seed, uint32_t stream, uint32_t thresh, float dscale) {
-  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
-  if (c0 >= C) return;
+  const RowMap m(C, 256);
+  if (!m.active) return;
+  const int c0 = m.cc * 8;
   float mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -98,70 +168,90 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
     gm[k] = gamma[c0 + k];
     bt[k] = beta[c0 + k];
   }
-  for (int r = blockIdx.x; r < M; r += gridDim.x) {
-    float v[8];
-    load8(x + (long)r * ldx + c0, v);
-    const uint64_t o = (uint64_t)r * C + c0;
+  const int stride = gridDim.x * m.lanes;
+  for (int r = blockIdx.x * m.lanes + m.rl; r < M; r += 4 * stride) {
+    bf16x8 in[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float z = fmaf((v[k] - mu[k]) * rs[k], gm[k], bt[k]);  // the expression the backward re-evaluates (same sign of z)
-      z = z > 0.f ? z : z * slope;
-      if (thresh) z = keep_bit(seed, stream, o + k, thresh) ? z * dscale : 0.f;
-      v[k] = z;
+    for (int u = 0; u < 4; ++u) {
+      const int ru = r + u * stride;
+      if (ru < M) in[u] = *reinterpret_cast<const bf16x8*>(x + (long)ru * ldx + c0);
     }
-    store8(y + (long)r * ldy + c0, v);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ru = r + u * stride;
+      if (ru >= M) break;
+      const uint64_t o = (uint64_t)ru * C + c0;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float z = fmaf(((float)in[u][k] - mu[k]) * rs[k], gm[k], bt[k]);  // the expression the backward re-evaluates (same sign of z)
+        z = z > 0.f ? z : z * slope;
+        if (thresh) z = keep_bit(seed, stream, o + k, thresh) ? z * dscale : 0.f;
+        v[k] = z;
+      }
+      store8(y + (long)ru * ldy + c0, v);
+    }
   }
 }
 // g = dy * mask * scale * leaky'(z);  partial[rb][0][c] = sum g, partial[rb][1][c] = sum g * xhat
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const bf16* __restrict__ dy, long ldy, const bf16* __restrict__ x,
-                                                             long ldx, int M, int C, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float slope, uint64_t seed,
-                                                             uint32_t stream, uint32_t thresh, float dscale,
-                                                             float* __restrict__ partial) {
-  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
-  if (c0 >= C) return;
-  float mu[8], rs[8], gm[8], bt[8], s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    mu[k] = mean[c0 + k];
-    rs[k] = rstd[c0 + k];
-    gm[k] = gamma[c0 + k];
-    bt[k] = beta[c0 + k];
-  }
-  for (int r = blockIdx.x; r < M; r += gridDim.x) {
-    float v[8], d[8];
-    load8(x + (long)r * ldx + c0, v);
-    load8(dy + (long)r * ldy + c0, d);
-    const uint64_t o = (uint64_t)r * C + c0;
+__global__ __launch_bounds__(BN_STAT_THREADS) void bn_bwd_partial_kernel(const bf16* __restrict__ dy, long ldy, const bf16* __restrict__ x,
+                                                                         long ldx, int M, int C, const float* __restrict__ mean,
+                                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                         const float* __restrict__ beta, float slope, uint64_t seed,
+                                                                         uint32_t stream, uint32_t thresh, float dscale,
+                                                                         float* __restrict__ partial) {
+  extern __shared__ float red[];
+  const RowMap m(C, BN_STAT_THREADS);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (m.active) {
+    const int c0 = m.cc * 8;
+    float mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float xh = (v[k] - mu[k]) * rs[k];
-      const float z = fmaf(xh, gm[k], bt[k]);
-      float g = z > 0.f ? d[k] : d[k] * slope;
-      if (thresh) g = keep_bit(seed, stream, o + k, thresh) ? g * dscale : 0.f;
-      s[k] += g;
-      q[k] = fmaf(g, xh, q[k]);
+      mu[k] = mean[c0 + k];
+      rs[k] = rstd[c0 + k];
+      gm[k] = gamma[c0 + k];
+      bt[k] = beta[c0 + k];
+    }
+    const int stride = gridDim.x * m.lanes;
+    for (int r = blockIdx.x * m.lanes + m.rl; r < M; r += 2 * stride) {
+      bf16x8 xv[2], dv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ru = r + u * stride;
+        if (ru < M) {
+          xv[u] = *reinterpret_cast<const bf16x8*>(x + (long)ru * ldx + c0);
+          dv[u] = *reinterpret_cast<const bf16x8*>(dy + (long)ru * ldy + c0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ru = r + u * stride;
+        if (ru >= M) break;
+        const uint64_t o = (uint64_t)ru * C + c0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float xh = ((float)xv[u][k] - mu[k]) * rs[k];
+          const float z = fmaf(xh, gm[k], bt[k]);
+          float g = z > 0.f ? (float)dv[u][k] : (float)dv[u][k] * slope;
+          if (thresh) g = keep_bit(seed, stream, o + k, thresh) ? g * dscale : 0.f;
+          s[k] += g;
+          q[k] = fmaf(g, xh, q[k]);
+        }
+      }
     }
   }
-  float* ps = partial + ((long)blockIdx.x * 2) * C + c0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    ps[k] = s[k];
-    ps[C + k] = q[k];
-  }
+  bn_block_reduce_store(m, s, q, partial, C, red);
 }
 // dbeta = sum g, dgamma = sum g xhat; coef[0][c] = dbeta / M, coef[1][c] = dgamma / M for the dx pass
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nb, int M, int C,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ coef) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0, q = 0;
-  for (int b = 0; b < nb; ++b) {
-    s += (double)partial[((long)b * 2) * C + c];
-    q += (double)partial[((long)b * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ partial, int nb, int M, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ coef) {
+  __shared__ double red[2][16][64];
+  double s, q;
+  bn_partial_totals(partial, nb, C, s, q, red);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if ((threadIdx.x >> 6) != 0 || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
   coef[c] = (float)(s / M);
@@ -174,8 +264,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ coef, float slope, uint64_t seed,
                                                            uint32_t stream, uint32_t thresh, float dscale) {
-  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
-  if (c0 >= C) return;
+  const RowMap m(C, 256);
+  if (!m.active) return;
+  const int c0 = m.cc * 8;
   float mu[8], rs[8], gm[8], bt[8], c1[8], c2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -186,20 +277,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
     c1[k] = coef[c0 + k];
     c2[k] = coef[C + c0 + k];
   }
-  for (int r = blockIdx.x; r < M; r += gridDim.x) {
-    float v[8], d[8];
-    load8(x + (long)r * ldx + c0, v);
-    load8(dy + (long)r * ldy + c0, d);
-    const uint64_t o = (uint64_t)r * C + c0;
+  const int stride = gridDim.x * m.lanes;
+  for (int r = blockIdx.x * m.lanes + m.rl; r < M; r += 2 * stride) {
+    bf16x8 xv[2], dv[2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float xh = (v[k] - mu[k]) * rs[k];
-      const float z = fmaf(xh, gm[k], bt[k]);
-      float g = z > 0.f ? d[k] : d[k] * slope;
-      if (thresh) g = keep_bit(seed, stream, o + k, thresh) ? g * dscale : 0.f;
-      v[k] = gm[k] * rs[k] * (g - c1[k] - xh * c2[k]);
+    for (int u = 0; u < 2; ++u) {
+      const int ru = r + u * stride;
+      if (ru < M) {
+        xv[u] = *reinterpret_cast<const bf16x8*>(x + (long)ru * ldx + c0);
+        dv[u] = *reinterpret_cast<const bf16x8*>(dy + (long)ru * ldy + c0);
+      }
     }
-    store8(dx + (long)r * lddx + c0, v);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ru = r + u * stride;
+      if (ru >= M) break;
+      const uint64_t o = (uint64_t)ru * C + c0;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = ((float)xv[u][k] - mu[k]) * rs[k];
+        const float z = fmaf(xh, gm[k], bt[k]);
+        float g = z > 0.f ? (float)dv[u][k] : (float)dv[u][k] * slope;
+        if (thresh) g = keep_bit(seed, stream, o + k, thresh) ? g * dscale : 0.f;
+        v[k] = gm[k] * rs[k] * (g - c1[k] - xh * c2[k]);
+      }
+      store8(dx + (long)ru * lddx + c0, v);
+    }
   }
 }
 
@@ -352,6 +456,23 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, co
   }
 }
 
+// launch geometry matching RowMap
+struct BnGrid {
+  int nb, cb_stat, ab, cb_apply;
+  size_t lds;
+  BnGrid(int M, int C) {
+    const int cpr = C / 8;
+    const int cpb_s = cpr < BN_STAT_THREADS ? cpr : BN_STAT_THREADS, lanes_s = BN_STAT_THREADS / cpb_s;
+    cb_stat = ssak_cdiv(cpr, cpb_s);
+    nb = ssak_cdiv(M, lanes_s) < BN_ROW_BLOCKS ? ssak_cdiv(M, lanes_s) : BN_ROW_BLOCKS;
+    lds = (size_t)8 * lanes_s * cpb_s * sizeof(float);
+    const int cpb_a = cpr < 256 ? cpr : 256, lanes_a = 256 / cpb_a;
+    cb_apply = ssak_cdiv(cpr, cpb_a);
+    const int want = ssak_cdiv(M, lanes_a * 4);
+    ab = want < 1 ? 1 : (want > 4096 ? 4096 : want);
+  }
+};
+
 template <typename T>
 int utt_norm_fwd(const T* x, T* y, int B, long n, float eps, float* stats, float* ws, hipStream_t st) {
   un_partial_kernel<T><<<dim3(UN_BLOCKS, B), 256, 0, st>>>(x, (const T*)nullptr, n, ws);
@@ -408,12 +529,13 @@ extern "C" int ssak_batchnorm_act_fwd(const void* x, void* y, int M, int C, cons
   SSAK_REQUIRE(training || (running_mean && running_var), "batchnorm_act_fwd: evaluation needs the running statistics");
   SSAK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_act_fwd: running_mean and running_var go together");
   hipStream_t st = (hipStream_t)stream;
-  const int nb = M < BN_ROW_BLOCKS ? M : BN_ROW_BLOCKS, cb = ssak_cdiv(C, 8 * 256);
+  const BnGrid gd(M, C);
+  const int nb = gd.nb;
   if (training) {
     SSAK_REQUIRE(workspace && workspace_bytes >= ssak_batchnorm_workspace_bytes(C), "batchnorm_act_fwd: workspace too small");
-    bn_stats_partial_kernel<<<dim3(nb, cb), 256, 0, st>>>((const bf16*)x, C, M, C, (float*)workspace);
+    bn_stats_partial_kernel<<<dim3(nb, gd.cb_stat), BN_STAT_THREADS, gd.lds, st>>>((const bf16*)x, C, M, C, (float*)workspace);
     SSAK_LAUNCH_CHECK();
-    bn_stats_final_kernel<<<ssak_cdiv(C, 256), 256, 0, st>>>((const float*)workspace, nb, M, C, eps, momentum, save_mean, save_rstd,
+    bn_stats_final_kernel<<<ssak_cdiv(C, 64), 1024, 0, st>>>((const float*)workspace, nb, M, C, eps, momentum, save_mean, save_rstd,
                                                               running_mean, running_var);
     SSAK_LAUNCH_CHECK();
   } else {
@@ -421,8 +543,7 @@ extern "C" int ssak_batchnorm_act_fwd(const void* x, void* y, int M, int C, cons
     SSAK_LAUNCH_CHECK();
   }
   const float p = training ? drop_p : 0.f;
-  const int ab = M < 2048 ? M : 2048;
-  bn_apply_kernel<<<dim3(ab, cb), 256, 0, st>>>((const bf16*)x, C, (bf16*)y, C, M, C, save_mean, save_rstd, gamma, beta, leaky_slope,
+  bn_apply_kernel<<<dim3(gd.ab, gd.cb_apply), 256, 0, st>>>((const bf16*)x, C, (bf16*)y, C, M, C, save_mean, save_rstd, gamma, beta, leaky_slope,
                                                seed, drop_stream, drop_thresh(p), drop_scale(p));
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -438,18 +559,18 @@ extern "C" int ssak_batchnorm_act_bwd(const void* dy, const void* x, void* dx, i
                "batchnorm_act_bwd: C must be a multiple of 8, rows 16-byte aligned");
   SSAK_REQUIRE(workspace && workspace_bytes >= ssak_batchnorm_workspace_bytes(C), "batchnorm_act_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int nb = M < BN_ROW_BLOCKS ? M : BN_ROW_BLOCKS, cb = ssak_cdiv(C, 8 * 256);
+  const BnGrid gd(M, C);
+  const int nb = gd.nb;
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)BN_ROW_BLOCKS * 2 * C;
   const uint32_t th = drop_thresh(drop_p);
   const float ds = drop_scale(drop_p);
-  bn_bwd_partial_kernel<<<dim3(nb, cb), 256, 0, st>>>((const bf16*)dy, C, (const bf16*)x, C, M, C, save_mean, save_rstd, gamma, beta,
+  bn_bwd_partial_kernel<<<dim3(nb, gd.cb_stat), BN_STAT_THREADS, gd.lds, st>>>((const bf16*)dy, C, (const bf16*)x, C, M, C, save_mean, save_rstd, gamma, beta,
                                                      leaky_slope, seed, drop_stream, th, ds, partial);
   SSAK_LAUNCH_CHECK();
-  bn_bwd_final_kernel<<<ssak_cdiv(C, 256), 256, 0, st>>>(partial, nb, M, C, dgamma, dbeta, coef);
+  bn_bwd_final_kernel<<<ssak_cdiv(C, 64), 1024, 0, st>>>(partial, nb, M, C, dgamma, dbeta, coef);
   SSAK_LAUNCH_CHECK();
-  const int ab = M < 2048 ? M : 2048;
-  bn_bwd_apply_kernel<<<dim3(ab, cb), 256, 0, st>>>((const bf16*)dy, C, (const bf16*)x, C, (bf16*)dx, C, M, C, save_mean, save_rstd,
+  bn_bwd_apply_kernel<<<dim3(gd.ab, gd.cb_apply), 256, 0, st>>>((const bf16*)dy, C, (const bf16*)x, C, (bf16*)dx, C, M, C, save_mean, save_rstd,
                                                    gamma, beta, coef, leaky_slope, seed, drop_stream, th, ds);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
