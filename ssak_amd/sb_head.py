@@ -335,6 +335,8 @@ class Brain:
         self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.dist else 1
         self._works = []
+        if self.dist:  # per-rank dropout streams (replicas start from identical seeds)
+            head._seed = (head._seed ^ (0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1))) % (1 << 64)
         if self.dist and not freeze_wav2vec:
             wav2vec2.set_grad_ready_callback(
                 lambda off, cnt: self._works.append(torch.distributed.all_reduce(wav2vec2.grads[off:off + cnt], async_op=True)))

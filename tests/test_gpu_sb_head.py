@@ -355,3 +355,47 @@ def test_recipe_frozen_steps_vs_oracle(tiny):
         ev = S.ctc_cost(S.head_forward({n: t.detach() for n, t in q.items()}, feats, None, False, dropouts=(0, 0, 0), running=run),
                         tokens, wav_lens, tok_lens).item()
     assert abs(v1 - ev) < 5e-2 * abs(ev)
+
+
+# ------------------------------------------------------------------ data parallelism of the recipe step
+def _sb_dp_worker(rank, world, port, out_dir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one card of the test box
+    import dataclasses
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.sb_head import Brain, CTCHead
+    oc = R.W2V2Config.tiny().deterministic()
+    d = dataclasses.asdict(oc)
+    d.pop("initializer_range")
+    model = Wav2Vec2ForCTC(Wav2Vec2Config(**d))
+    model.load_state_dict(R.init_params(oc, 5))
+    head = CTCHead(oc.hidden_size, 64, 13, dropouts=(0.15, 0.15, 0.0), seed=4)  # same seed: identical replicas at the start
+    brain = Brain(model, head, freeze_wav2vec=False)
+    g = torch.Generator().manual_seed(100 + rank)  # different data per rank
+    wavs = torch.randn(3, 7000, generator=g) * 0.1
+    tokens = torch.randint(1, 13, (3, 5), generator=g)
+    ones = torch.ones(3)
+    losses = [brain.fit_batch(wavs, ones, tokens, ones).item() for _ in range(3)]
+    torch.save({"enc": model.params[:model.num_trainable].cpu(), "head": head.params.cpu(), "losses": losses,
+                "run_mean": head.running_mean[0].cpu()}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_recipe_dp2_replicas_stay_identical(tmp_path):
+    """Two ranks, different utterances: after three unfrozen fit_batch steps (head gradients in one all-reduce, wav2vec2
+    gradients in the engine's bucketed ones, one joint clip coefficient from the reduced buffers) both replicas hold bitwise
+    the same parameters, while losses and BatchNorm running statistics are per rank (no SyncBatchNorm, as in the reference)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sb_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(a["enc"], b["enc"]) and torch.equal(a["head"], b["head"])
+    assert a["losses"] != b["losses"] and not torch.equal(a["run_mean"], b["run_mean"])
+    assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
