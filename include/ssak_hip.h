@@ -291,11 +291,22 @@ int ssak_utt_norm_bwd(const void* dy, const void* y, void* dx, int B, long n, in
 size_t ssak_batchnorm_workspace_bytes(int C);
 int ssak_batchnorm_act_fwd(const void* x, void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, int training, float leaky_slope, float drop_p,
-                           uint64_t seed, uint32_t drop_stream, float* save_mean, float* save_rstd, void* workspace,
-                           size_t workspace_bytes, void* stream);
+                           uint64_t seed, uint32_t drop_stream, float* save_mean, float* save_rstd, const double* global_sums,
+                           void* workspace, size_t workspace_bytes, void* stream);
 int ssak_batchnorm_act_bwd(const void* dy, const void* x, void* dx, int M, int C, const float* gamma, const float* beta,
                            const float* save_mean, const float* save_rstd, float leaky_slope, float drop_p, uint64_t seed,
-                           uint32_t drop_stream, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                           uint32_t drop_stream, float* dgamma, float* dbeta, double* local_sums_out, const double* global_sums,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* Synchronised statistics under data parallelism (the head's BatchNorm1d spans the global batch): the column
+ * totals travel as doubles through one all-reduce of 2 C + 1 values per normalisation and direction (the last one is the
+ * row count, so ranks may hold different numbers of rows and no host read is needed).
+ *   forward : ssak_batchnorm_stats(x) -> sums[2C+1] = (sum x [C], sum x^2 [C], M) of the local rows; all-reduce(sum);
+ *             ssak_batchnorm_act_fwd(..., global_sums = sums)
+ *   backward: ssak_batchnorm_act_bwd(dx = NULL, local_sums_out = sums) -> local dgamma / dbeta (the parameter all-reduce sums
+ *             them as usual) and sums[2C+1] = (sum g, sum g xhat, M); all-reduce(sum);
+ *             ssak_batchnorm_act_bwd(dx, global_sums = sums) -> dx; dgamma / dbeta untouched (may be NULL).
+ * With global_sums == NULL and local_sums_out == NULL both calls are the single-device form. */
+int ssak_batchnorm_stats(const void* x, int M, int C, double* sums, void* workspace, size_t workspace_bytes, void* stream);
 /* torch.optim.Adadelta (yaml :119-122: lr 1.0, rho 0.95, eps 1e-8): square_avg = rho sq + (1-rho) g^2;
  * delta = sqrt(acc_delta + eps) / sqrt(square_avg + eps) * g; acc_delta = rho acc + (1-rho) delta^2; p -= lr * delta.
  * g is first multiplied by grad_scale (1 / world size after a sum all-reduce) and by min(1, max_norm / (sqrt(*gnorm_sq) *

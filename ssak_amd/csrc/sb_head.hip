@@ -152,6 +152,43 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict
   mean[c] = run_mean[c];
   rstd[c] = (float)(1.0 / sqrt((double)run_var[c] + (double)eps));
 }
+// synchronised BatchNorm (data parallel): the two column totals leave as doubles, are summed over the ranks by the caller
+// (one all-reduce of 2 C doubles) and come back through the *_from_sums kernels with the global row count
+__global__ __launch_bounds__(1024) void bn_sums_final_kernel(const float* __restrict__ partial, int nb, int M, int C,
+                                                             double* __restrict__ sums) {
+  __shared__ double red[2][16][64];
+  double s, q;
+  bn_partial_totals(partial, nb, C, s, q, red);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if ((threadIdx.x >> 6) != 0 || c >= C) return;
+  sums[c] = s;
+  sums[C + c] = q;
+  if (c == 0) sums[2 * C] = (double)M;  // the row count rides in the same all-reduce
+}
+__global__ __launch_bounds__(256) void bn_stats_from_sums_kernel(const double* __restrict__ sums, int C, float eps, float momentum,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 float* __restrict__ run_mean, float* __restrict__ run_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double M = sums[2 * C];
+  const double mu = sums[c] / M;
+  double var = sums[C + c] / M - mu * mu;
+  var = var > 0 ? var : 0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unb = M > 1 ? var * (M / (M - 1)) : var;
+    run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+    run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+  }
+}
+__global__ __launch_bounds__(256) void bn_coef_from_sums_kernel(const double* __restrict__ sums, int C, float* __restrict__ coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double M = sums[2 * C];
+  coef[c] = (float)(sums[c] / M);
+  coef[C + c] = (float)(sums[C + c] / M);
+}
 // y = dropout(leaky_relu(gamma * (x - mean) * rstd + beta)); mask bit = keep_bit(seed, stream, r * C + c)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ x, long ldx, bf16* __restrict__ y, long ldy, int M,
                                                        int C, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -246,7 +283,7 @@ __global__ __launch_bounds__(BN_STAT_THREADS) void bn_bwd_partial_kernel(const b
 // dbeta = sum g, dgamma = sum g xhat; coef[0][c] = dbeta / M, coef[1][c] = dgamma / M for the dx pass
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ partial, int nb, int M, int C,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ coef) {
+                                                            float* __restrict__ coef, double* __restrict__ sums) {
   __shared__ double red[2][16][64];
   double s, q;
   bn_partial_totals(partial, nb, C, s, q, red);
@@ -254,8 +291,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restr
   if ((threadIdx.x >> 6) != 0 || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
-  coef[c] = (float)(s / M);
-  coef[C + c] = (float)(q / M);
+  if (coef) {
+    coef[c] = (float)(s / M);
+    coef[C + c] = (float)(q / M);
+  }
+  if (sums) {
+    sums[c] = s;
+    sums[C + c] = q;
+    if (c == 0) sums[2 * C] = (double)M;
+  }
 }
 // dx = gamma * rstd * (g - mean(g) - xhat * mean(g xhat))
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ dy, long ldy, const bf16* __restrict__ x, long ldx,
@@ -520,18 +564,36 @@ extern "C" int ssak_utt_norm_bwd(const void* dy, const void* y, void* dx, int B,
 
 extern "C" size_t ssak_batchnorm_workspace_bytes(int C) { return (size_t)(BN_ROW_BLOCKS * 2 + 2) * (C > 0 ? C : 0) * sizeof(float); }
 
+extern "C" int ssak_batchnorm_stats(const void* x, int M, int C, double* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(x && sums && M > 0 && C > 0 && C % 8 == 0 && ((uintptr_t)x & 15) == 0, "batchnorm_stats: bad arguments");
+  SSAK_REQUIRE(workspace && workspace_bytes >= ssak_batchnorm_workspace_bytes(C), "batchnorm_stats: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const BnGrid gd(M, C);
+  bn_stats_partial_kernel<<<dim3(gd.nb, gd.cb_stat), BN_STAT_THREADS, gd.lds, st>>>((const bf16*)x, C, M, C, (float*)workspace);
+  SSAK_LAUNCH_CHECK();
+  bn_sums_final_kernel<<<ssak_cdiv(C, 64), 1024, 0, st>>>((const float*)workspace, gd.nb, M, C, sums);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
 extern "C" int ssak_batchnorm_act_fwd(const void* x, void* y, int M, int C, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, float momentum, float eps, int training,
                                       float leaky_slope, float drop_p, uint64_t seed, uint32_t drop_stream, float* save_mean,
-                                      float* save_rstd, void* workspace, size_t workspace_bytes, void* stream) {
+                                      float* save_rstd, const double* global_sums, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
   SSAK_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && M > 0 && C > 0, "batchnorm_act_fwd: bad arguments");
   SSAK_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "batchnorm_act_fwd: C must be a multiple of 8, rows 16-byte aligned");
   SSAK_REQUIRE(training || (running_mean && running_var), "batchnorm_act_fwd: evaluation needs the running statistics");
   SSAK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_act_fwd: running_mean and running_var go together");
+  SSAK_REQUIRE(!global_sums || training, "batchnorm_act_fwd: global sums are a training-mode input");
   hipStream_t st = (hipStream_t)stream;
   const BnGrid gd(M, C);
   const int nb = gd.nb;
-  if (training) {
+  if (training && global_sums) {
+    bn_stats_from_sums_kernel<<<ssak_cdiv(C, 256), 256, 0, st>>>(global_sums, C, eps, momentum, save_mean, save_rstd,
+                                                                 running_mean, running_var);
+    SSAK_LAUNCH_CHECK();
+  } else if (training) {
     SSAK_REQUIRE(workspace && workspace_bytes >= ssak_batchnorm_workspace_bytes(C), "batchnorm_act_fwd: workspace too small");
     bn_stats_partial_kernel<<<dim3(nb, gd.cb_stat), BN_STAT_THREADS, gd.lds, st>>>((const bf16*)x, C, M, C, (float*)workspace);
     SSAK_LAUNCH_CHECK();
@@ -549,12 +611,17 @@ extern "C" int ssak_batchnorm_act_fwd(const void* x, void* y, int M, int C, cons
   return SSAK_OK;
 }
 
+// Backward in one call (global_sums == NULL, local_sums_out == NULL), or in two around the caller's all-reduce:
+//   call 1: dx == NULL, local_sums_out != NULL  -> dgamma / dbeta (local) and the two local totals as doubles
+//   call 2: global_sums != NULL                 -> dx from the global totals / global row count; dgamma / dbeta are not touched
 extern "C" int ssak_batchnorm_act_bwd(const void* dy, const void* x, void* dx, int M, int C, const float* gamma, const float* beta,
                                       const float* save_mean, const float* save_rstd, float leaky_slope, float drop_p, uint64_t seed,
-                                      uint32_t drop_stream, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
-  SSAK_REQUIRE(dy && x && dx && gamma && beta && save_mean && save_rstd && dgamma && dbeta && M > 0 && C > 0,
-               "batchnorm_act_bwd: bad arguments");
+                                      uint32_t drop_stream, float* dgamma, float* dbeta, double* local_sums_out,
+                                      const double* global_sums, void* workspace, size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(dy && x && gamma && beta && save_mean && save_rstd && M > 0 && C > 0, "batchnorm_act_bwd: bad arguments");
+  SSAK_REQUIRE(dx || local_sums_out, "batchnorm_act_bwd: nothing to compute");
+  SSAK_REQUIRE(global_sums || (dgamma && dbeta), "batchnorm_act_bwd: dgamma / dbeta needed");
+  SSAK_REQUIRE(!global_sums || dx, "batchnorm_act_bwd: global sums come with dx");
   SSAK_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0,
                "batchnorm_act_bwd: C must be a multiple of 8, rows 16-byte aligned");
   SSAK_REQUIRE(workspace && workspace_bytes >= ssak_batchnorm_workspace_bytes(C), "batchnorm_act_bwd: workspace too small");
@@ -565,14 +632,21 @@ extern "C" int ssak_batchnorm_act_bwd(const void* dy, const void* x, void* dx, i
   float* coef = partial + (size_t)BN_ROW_BLOCKS * 2 * C;
   const uint32_t th = drop_thresh(drop_p);
   const float ds = drop_scale(drop_p);
-  bn_bwd_partial_kernel<<<dim3(nb, gd.cb_stat), BN_STAT_THREADS, gd.lds, st>>>((const bf16*)dy, C, (const bf16*)x, C, M, C, save_mean, save_rstd, gamma, beta,
-                                                     leaky_slope, seed, drop_stream, th, ds, partial);
-  SSAK_LAUNCH_CHECK();
-  bn_bwd_final_kernel<<<ssak_cdiv(C, 64), 1024, 0, st>>>(partial, nb, M, C, dgamma, dbeta, coef);
-  SSAK_LAUNCH_CHECK();
-  bn_bwd_apply_kernel<<<dim3(gd.ab, gd.cb_apply), 256, 0, st>>>((const bf16*)dy, C, (const bf16*)x, C, (bf16*)dx, C, M, C, save_mean, save_rstd,
-                                                   gamma, beta, coef, leaky_slope, seed, drop_stream, th, ds);
-  SSAK_LAUNCH_CHECK();
+  if (global_sums) {
+    bn_coef_from_sums_kernel<<<ssak_cdiv(C, 256), 256, 0, st>>>(global_sums, C, coef);
+    SSAK_LAUNCH_CHECK();
+  } else {
+    bn_bwd_partial_kernel<<<dim3(nb, gd.cb_stat), BN_STAT_THREADS, gd.lds, st>>>((const bf16*)dy, C, (const bf16*)x, C, M, C, save_mean, save_rstd, gamma, beta,
+                                                       leaky_slope, seed, drop_stream, th, ds, partial);
+    SSAK_LAUNCH_CHECK();
+    bn_bwd_final_kernel<<<ssak_cdiv(C, 64), 1024, 0, st>>>(partial, nb, M, C, dgamma, dbeta, dx ? coef : nullptr, local_sums_out);
+    SSAK_LAUNCH_CHECK();
+  }
+  if (dx) {
+    bn_bwd_apply_kernel<<<dim3(gd.ab, gd.cb_apply), 256, 0, st>>>((const bf16*)dy, C, (const bf16*)x, C, (bf16*)dx, C, M, C, save_mean, save_rstd,
+                                                     gamma, beta, coef, leaky_slope, seed, drop_stream, th, ds);
+    SSAK_LAUNCH_CHECK();
+  }
   return SSAK_OK;
 }
 

@@ -98,8 +98,10 @@ def _load():
         "ssak_utt_norm_bwd": (i32, [vp, vp, vp, i32, C.c_long, i32, vp, vp, sz, vp]),
         "ssak_batchnorm_workspace_bytes": (sz, [i32]),
         "ssak_batchnorm_act_fwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, f32, f32, C.c_uint64, C.c_uint32, vp, vp,
+                                         vp, vp, sz, vp]),
+        "ssak_batchnorm_act_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, C.c_uint64, C.c_uint32, vp, vp, vp, vp,
                                          vp, sz, vp]),
-        "ssak_batchnorm_act_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, C.c_uint64, C.c_uint32, vp, vp, vp, sz, vp]),
+        "ssak_batchnorm_stats": (i32, [vp, i32, i32, vp, vp, sz, vp]),
         "ssak_adadelta_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, vp]),
         "ssak_cast_f32_bf16": (i32, [vp, vp, C.c_long, vp]),
         "ssak_colsum_workspace_bytes": (sz, [i32]),

@@ -95,6 +95,7 @@ class CTCHead:
         self.nblk = len(self.dropouts)
         self.slope, self.bn_eps, self.bn_momentum = leaky_slope, bn_eps, bn_momentum
         self.training = True
+        self.sync_bn = False  # set by Brain under data parallelism: BatchNorm statistics over the global batch
         self.layout: Dict[str, tuple] = {}
         cur = 0
 
@@ -221,11 +222,16 @@ class CTCHead:
                 y = torch.empty_like(a)
                 mean = torch.empty(D, dtype=torch.float32, device=self.device)
                 rstd = torch.empty(D, dtype=torch.float32, device=self.device)
+                gs = None
+                if tr and self.sync_bn:
+                    gs = torch.empty(2 * D + 1, dtype=torch.float64, device=self.device)
+                    hip.check(hip.lib.ssak_batchnorm_stats(hip.ptr(a), M, D, hip.ptr(gs), hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
+                    torch.distributed.all_reduce(gs)
                 hip.check(hip.lib.ssak_batchnorm_act_fwd(
                     hip.ptr(a), hip.ptr(y), M, D, hip.ptr(self.param(f"0.bn{i + 1}.norm.weight")),
                     hip.ptr(self.param(f"0.bn{i + 1}.norm.bias")), hip.ptr(self.running_mean[i]), hip.ptr(self.running_var[i]),
                     self.bn_momentum, self.bn_eps, int(tr), self.slope, self.dropouts[i], hip.C.c_uint64(self._seed), i,
-                    hip.ptr(mean), hip.ptr(rstd), hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
+                    hip.ptr(mean), hip.ptr(rstd), hip.ptr(gs), hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
                 saved.append((h, a, mean, rstd))
                 h = y
             logits = torch.empty((B, F, self.Vp), dtype=torch.float32, device=self.device)
@@ -263,11 +269,19 @@ class CTCHead:
                 h_in, a, mean, rstd = saved[i]
                 din = h_in.shape[1]
                 da = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
-                hip.check(hip.lib.ssak_batchnorm_act_bwd(
-                    hip.ptr(dh), hip.ptr(a), hip.ptr(da), M, D, hip.ptr(self.param(f"0.bn{i + 1}.norm.weight")),
-                    hip.ptr(self.param(f"0.bn{i + 1}.norm.bias")), hip.ptr(mean), hip.ptr(rstd), self.slope, self.dropouts[i],
-                    hip.C.c_uint64(seed), i, hip.ptr(self.grad(f"0.bn{i + 1}.norm.weight")),
-                    hip.ptr(self.grad(f"0.bn{i + 1}.norm.bias")), hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
+                bn_args = (M, D, hip.ptr(self.param(f"0.bn{i + 1}.norm.weight")), hip.ptr(self.param(f"0.bn{i + 1}.norm.bias")),
+                           hip.ptr(mean), hip.ptr(rstd), self.slope, self.dropouts[i], hip.C.c_uint64(seed), i,
+                           hip.ptr(self.grad(f"0.bn{i + 1}.norm.weight")), hip.ptr(self.grad(f"0.bn{i + 1}.norm.bias")))
+                if self.sync_bn:  # local parameter gradients + local totals, all-reduce, then dx from the global totals
+                    gs = torch.empty(2 * D + 1, dtype=torch.float64, device=dev)
+                    hip.check(hip.lib.ssak_batchnorm_act_bwd(hip.ptr(dh), hip.ptr(a), None, *bn_args, hip.ptr(gs), None,
+                                                             hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
+                    torch.distributed.all_reduce(gs)
+                    hip.check(hip.lib.ssak_batchnorm_act_bwd(hip.ptr(dh), hip.ptr(a), hip.ptr(da), *bn_args, None, hip.ptr(gs),
+                                                             hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
+                else:
+                    hip.check(hip.lib.ssak_batchnorm_act_bwd(hip.ptr(dh), hip.ptr(a), hip.ptr(da), *bn_args, None, None,
+                                                             hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
                 hip.gemm(da, h_in, self.grad(f"0.linear{i + 1}.w.weight"), D, din, M, a_kmajor=True, b_kmajor=True, lda=D, ldb=din,
                          ldc=din, split_k=0)
                 colsum(da, D, self.grad(f"0.linear{i + 1}.w.bias"))
@@ -314,7 +328,8 @@ class Brain:
 
     def __init__(self, wav2vec2: Wav2Vec2ForCTC, head: CTCHead, freeze_wav2vec: bool = True, normalize_wav: bool = True,
                  output_norm: bool = True, lr: float = 1.0, lr_wav2vec: float = 1e-4, max_grad_norm: float = 5.0,
-                 blank_index: int = 0, annealing=(0.8, 0.9), improvement_threshold: float = 0.0025, vocab=None):
+                 blank_index: int = 0, annealing=(0.8, 0.9), improvement_threshold: float = 0.0025, vocab=None,
+                 sync_batchnorm: bool = True):
         self.wav2vec2, self.head = wav2vec2, head
         self.device = head.device
         self.freeze = freeze_wav2vec
@@ -335,6 +350,9 @@ class Brain:
         self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.dist else 1
         self._works = []
+        # BatchNorm over the global batch under data parallelism; False = per-rank statistics, what the
+        # reference's nn.DataParallel / DDP without SyncBatchNorm computes
+        head.sync_bn = bool(self.dist and sync_batchnorm)
         if self.dist:  # per-rank dropout streams (replicas start from identical seeds)
             head._seed = (head._seed ^ (0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1))) % (1 << 64)
         if self.dist and not freeze_wav2vec:

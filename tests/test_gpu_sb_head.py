@@ -61,7 +61,7 @@ def _bn_fwd(hip, a, gamma, beta, rm, rv, training, p, seed, stream_id):
     ws = _ws(hip.lib.ssak_batchnorm_workspace_bytes(Cc))
     hip.check(hip.lib.ssak_batchnorm_act_fwd(hip.ptr(a), hip.ptr(y), M, Cc, hip.ptr(gamma), hip.ptr(beta), hip.ptr(rm), hip.ptr(rv),
                                              0.1, 1e-5, int(training), 0.01, p, C.c_uint64(seed), stream_id, hip.ptr(mean),
-                                             hip.ptr(rstd), hip.ptr(ws), ws.numel(), hip.stream()))
+                                             hip.ptr(rstd), None, hip.ptr(ws), ws.numel(), hip.stream()))
     return y, mean, rstd
 
 
@@ -102,8 +102,8 @@ def test_batchnorm_act_fwd_bwd(hip, M, Cc, p):
     dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
     ws = _ws(hip.lib.ssak_batchnorm_workspace_bytes(Cc))
     hip.check(hip.lib.ssak_batchnorm_act_bwd(hip.ptr(dy.cuda()), hip.ptr(ad), hip.ptr(da), M, Cc, hip.ptr(gd), hip.ptr(bd), hip.ptr(mean),
-                                             hip.ptr(rstd), 0.01, p, C.c_uint64(77), 3, hip.ptr(dg), hip.ptr(db), hip.ptr(ws), ws.numel(),
-                                             hip.stream()))
+                                             hip.ptr(rstd), 0.01, p, C.c_uint64(77), 3, hip.ptr(dg), hip.ptr(db), None, None, hip.ptr(ws),
+                                             ws.numel(), hip.stream()))
     assert rel_l2(da.float().cpu(), ar.grad) < 8e-3
     assert rel_l2(dg.cpu(), gr.grad) < 2e-3 and rel_l2(db.cpu(), br.grad) < 2e-3
     # evaluation mode: running statistics, no dropout
@@ -373,7 +373,7 @@ def _sb_dp_worker(rank, world, port, out_dir):
     model = Wav2Vec2ForCTC(Wav2Vec2Config(**d))
     model.load_state_dict(R.init_params(oc, 5))
     head = CTCHead(oc.hidden_size, 64, 13, dropouts=(0.15, 0.15, 0.0), seed=4)  # same seed: identical replicas at the start
-    brain = Brain(model, head, freeze_wav2vec=False)
+    brain = Brain(model, head, freeze_wav2vec=False, sync_batchnorm=False)  # per-rank statistics, as the reference's DDP
     g = torch.Generator().manual_seed(100 + rank)  # different data per rank
     wavs = torch.randn(3, 7000, generator=g) * 0.1
     tokens = torch.randint(1, 13, (3, 5), generator=g)
@@ -388,7 +388,8 @@ def _sb_dp_worker(rank, world, port, out_dir):
 def test_recipe_dp2_replicas_stay_identical(tmp_path):
     """Two ranks, different utterances: after three unfrozen fit_batch steps (head gradients in one all-reduce, wav2vec2
     gradients in the engine's bucketed ones, one joint clip coefficient from the reduced buffers) both replicas hold bitwise
-    the same parameters, while losses and BatchNorm running statistics are per rank (no SyncBatchNorm, as in the reference)."""
+    the same parameters, while losses and -- with sync_batchnorm=False, the reference's behaviour -- BatchNorm running statistics
+    are per rank."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -399,3 +400,69 @@ def test_recipe_dp2_replicas_stay_identical(tmp_path):
     assert torch.equal(a["enc"], b["enc"]) and torch.equal(a["head"], b["head"])
     assert a["losses"] != b["losses"] and not torch.equal(a["run_mean"], b["run_mean"])
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+
+
+def _sb_problem():
+    import dataclasses
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    oc = R.W2V2Config.tiny().deterministic()
+    d = dataclasses.asdict(oc)
+    d.pop("initializer_range")
+    g = torch.Generator().manual_seed(77)
+    wavs = torch.randn(6, 7000, generator=g) * 0.1
+    tokens = torch.randint(1, 13, (6, 5), generator=g)  # equal target lengths: shard means average exactly
+    return oc, Wav2Vec2Config(**d), R.init_params(oc, 5), wavs, tokens
+
+
+def _sb_syncbn_worker(rank, world, port, out_dir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.sb_head import Brain, CTCHead
+    oc, cfg, p0, wavs, tokens = _sb_problem()
+    model = Wav2Vec2ForCTC(cfg)
+    model.load_state_dict(p0)
+    head = CTCHead(cfg.hidden_size, 64, 13, dropouts=(0.0, 0.0, 0.0), seed=4)
+    brain = Brain(model, head, freeze_wav2vec=False, sync_batchnorm=True)
+    assert head.sync_bn
+    mine = slice(rank * 3, rank * 3 + 3)
+    ones = torch.ones(3)
+    loss = brain.fit_batch(wavs[mine], ones, tokens[mine], ones).item()
+    torch.save({"head_grads": head.grads.cpu() / world, "enc_grads": model.grads[:model.num_trainable].cpu() / world, "loss": loss,
+                "run_mean": head.running_mean[0].cpu(), "run_var": head.running_var[0].cpu(), "head": head.params.cpu()},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_recipe_dp2_sync_batchnorm_equals_single_process(tmp_path):
+    """Synchronised BatchNorm: two ranks holding half the batch each, statistics and backward totals exchanged
+    as 2 C + 1 doubles per normalisation, reproduce the single-process step on the whole batch -- same running statistics,
+    same averaged gradients for the head and for wav2vec2 (up to the summation order of the bf16 GEMMs), same update."""
+    import socket
+    import torch.multiprocessing as mp
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.sb_head import Brain, CTCHead
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sb_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    oc, cfg, p0, wavs, tokens = _sb_problem()
+    model = Wav2Vec2ForCTC(cfg)
+    model.load_state_dict(p0)
+    head = CTCHead(cfg.hidden_size, 64, 13, dropouts=(0.0, 0.0, 0.0), seed=4)
+    brain = Brain(model, head, freeze_wav2vec=False)
+    ones = torch.ones(6)
+    loss = brain.fit_batch(wavs, ones, tokens, ones).item()
+    assert abs(0.5 * (a["loss"] + b["loss"]) - loss) < 1e-3 * abs(loss)
+    for r in (a, b):
+        assert torch.allclose(r["run_mean"], head.running_mean[0].cpu(), atol=1e-5)
+        assert torch.allclose(r["run_var"], head.running_var[0].cpu(), rtol=1e-4, atol=1e-6)
+        assert rel_l2(r["head_grads"], head.grads.cpu()) < 1e-2
+        assert rel_l2(r["enc_grads"], model.grads[:model.num_trainable].cpu()) < 1e-2
+    assert torch.equal(a["head"], b["head"])
+    # and per-rank statistics (sync_batchnorm=False) do differ from the global ones: the switch is live
+    assert not torch.allclose(a["run_mean"], torch.zeros_like(a["run_mean"]))

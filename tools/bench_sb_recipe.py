@@ -99,10 +99,10 @@ ws = torch.empty(hip.lib.ssak_batchnorm_workspace_bytes(1024), dtype=torch.uint8
 bytes_el = M * 1024 * 2
 t_fwd = timed(lambda: hip.check(hip.lib.ssak_batchnorm_act_fwd(hip.ptr(a), hip.ptr(y), M, 1024, hip.ptr(gam), hip.ptr(bet), hip.ptr(rm),
                                                               hip.ptr(rv), 0.1, 1e-5, 1, 0.01, 0.15, C.c_uint64(5), 0, hip.ptr(mean),
-                                                              hip.ptr(rstd), hip.ptr(ws), ws.numel(), hip.stream())))
+                                                              hip.ptr(rstd), None, hip.ptr(ws), ws.numel(), hip.stream())))
 t_bwd = timed(lambda: hip.check(hip.lib.ssak_batchnorm_act_bwd(hip.ptr(y), hip.ptr(a), hip.ptr(dx), M, 1024, hip.ptr(gam), hip.ptr(bet),
                                                               hip.ptr(mean), hip.ptr(rstd), 0.01, 0.15, C.c_uint64(5), 0, hip.ptr(dgm),
-                                                              hip.ptr(dbt), hip.ptr(ws), ws.numel(), hip.stream())))
+                                                              hip.ptr(dbt), None, None, hip.ptr(ws), ws.numel(), hip.stream())))
 uws = torch.empty(hip.lib.ssak_utt_norm_workspace_bytes(B), dtype=torch.uint8, device="cuda")
 stats = torch.empty(B, 2, device="cuda")
 t_un = timed(lambda: hip.check(hip.lib.ssak_utt_norm_fwd(hip.ptr(feats), hip.ptr(y), B, F * 1024, 1, 1e-5, hip.ptr(stats), hip.ptr(uws),
