@@ -1,3 +1,5 @@
+# (-amdgpu-atomic-optimizer-strategy=None: the persistent GEMM keeps one returning atomic in flight per workgroup; the
+# optimizer's wave reduction + readfirstlane would make the wave wait for it where it is issued.)
 # (-amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs; the default put them in AccVGPRs and paid ~7 v_accvgpr moves
 # per attention score element.)
 # Builds libssak_hip.so (hand-written HIP kernels for gfx950 + the C ABI of include/ssak_hip.h).
@@ -7,7 +9,7 @@ ARCH ?= gfx950
 CSRC := ssak_amd/csrc
 OBJ := build/obj
 LIB := ssak_amd/lib/libssak_hip.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-atomic-optimizer-strategy=None
 SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%,$(OBJ)/%.o,$(SRCS))
 

@@ -164,6 +164,12 @@ int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const voi
 int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs /*host*/, int n, const void* const* A, const void* const* B, void* const* C,
                            void* stream);
 
+/* Tile order of the persistent GEMM kernels, process-wide.  0 (default): static stride over the workgroups; 1: every tile is
+ * drawn from per-XCD ticket counters, so that workgroups whose CU is held by another stream's kernel for a while -- the RCCL
+ * all-reduce of a data-parallel step -- take fewer tiles instead of finishing last.  The data-parallel trainers switch it on;
+ * alone on the chip the static order is a few percent faster (no ticket round trip at the start of a launch). */
+int ssak_gemm_tile_order(int dynamic);
+
 /* Per-launch GEMM timing for the roofline report (measurement aid, not on the reference's path): while
  * enabled, every GEMM launch is bracketed by HIP events on its own stream; ssak_prof_collect waits for them and
  * returns, per kernel instantiation (named as rocprofv3 prints it), launches / summed ms / algorithmic FLOPs. */

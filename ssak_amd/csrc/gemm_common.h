@@ -29,6 +29,7 @@ struct GemmParams {
   long bias_s2;
   uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
   float* colsum;          // [wave-tile rows][N] column sums of the stored values (bias gradient of the producing Linear) or null
+  int* tile_ctr;          // persistent kernels: [0] = tickets handed out past the first round, [1] = workgroups done (or null: static)
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {

@@ -27,6 +27,9 @@
 // c ^ ((r >> 1) & 7) (ds_read_b128, conflict-free); K-major [64 k-rows][256 B], chunk ch of k-row kr at slot
 // ch ^ km_swz(kr) (ds_read_b64_tr_b16).  The DMA writes linearly, so the swizzles are applied to the source address.
 #include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 #include "gemm_common.h"
@@ -38,7 +41,7 @@ constexpr int P8_THREADS = 512;
 constexpr int P8_PIECE = 16384;          // bytes per piece
 constexpr int P8_BUF = 4 * P8_PIECE;     // AT, AB, BL, BR
 constexpr int P8_PIPE = 2 * P8_BUF;      // 128 KiB of operand pieces
-constexpr int P8_LDS = P8_PIPE + 8 * 1024;  // + 1 KiB per wave: the tile's bias slice, staged by DMA with the operands
+constexpr int P8_LDS = P8_PIPE + 8 * 1024 + 64;  // + 1 KiB per wave: the tile's bias slice, staged by DMA with the operands; + the next tile's ticket
 
 // Staging state of one operand (two pieces: half 0 = AT / BL, half 1 = AB / BR).  SEG = rows of a piece taken from one
 // wave row / column (16 * MH for A, 32 for B), SPAN = that wave row's / column's extent in the tile (2 * SEG), NSEG = wave
@@ -284,9 +287,30 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
   // (phase 4 of K tile 1).  Measured on K = 768 tiles (tools/probes/p8_probe.hip): every CU reaches its epilogue at the
   // same moment, the 32 MB burst of a round takes 2.7 us (bf16) to 8 us (GELU + saved pre-activation) to drain at HBM
   // speed, and the pipeline fill of a fresh workgroup costs another 2 us -- all of it used to be exposed.
+  // Tile order.  Static (tile_ctr == null, the single-GPU default): workgroup b takes logical ids b, b + grid, ...
+  // Dynamic (data-parallel runs): a workgroup draws every tile from a ticket counter, so that one which starts late -- its
+  // CU held by another stream's kernel, e.g. the RCCL all-reduce of the previous layer's gradients -- simply takes fewer
+  // tiles.  With the static stride such a workgroup ran its whole share after everyone else had finished
+  // (tools/probes/hog_probe.hip: 32 busy CUs made these GEMMs 1.8x slower, not 1.14x).  There is one counter per XCD
+  // (x = blockIdx.x & 7, ticket k -> logical id 8 k + x), which keeps xcd_remap's property that an XCD works through a
+  // contiguous run of tiles (a single counter scattered the panels over all eight L2s: 16 % slower with nobody else on the
+  // chip).  The ticket of the next tile is requested at the top of the current one (one lane, a returning atomic that
+  // retires under the main loop, well away from the epilogue's store burst) and its value is only touched after the loop's
+  // vmcnt(0), where it is published through LDS; only the very first ticket of a launch is waited for.  (Built with -amdgpu-atomic-optimizer-strategy=None: the optimizer's
+  // readfirstlane broadcast would wait on the spot.)
+  int* const tile_ctr = p.tile_ctr ? p.tile_ctr + (blockIdx.x & 7) : nullptr;
+  int* const ticket_lds = reinterpret_cast<int*>(smem + P8_PIPE + 8 * 1024);  // written by one lane, read after the barrier
+  int ticket = 0;  // lane 0 of wave 0: the ticket in flight (for the tile after the current one)
+  int t_first = blockIdx.x;
+  if (tile_ctr) {
+    if (threadIdx.x == 0) *ticket_lds = atomicAdd(tile_ctr, 1);
+    __syncthreads();
+    t_first = 8 * __builtin_amdgcn_readfirstlane(*ticket_lds) + (int)(blockIdx.x & 7);
+    __syncthreads();
+  }
   bool primed = false;
-  P8Tile cur_t = decode(blockIdx.x);
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  P8Tile cur_t = decode(min(t_first, ntiles - 1));
+  for (int t = t_first; t < ntiles;) {
     const P8Tile c = cur_t;
     P8_STAMP(0);
     const bool was_primed = primed;
@@ -301,6 +325,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     P8_BARRIER();     // ... everyone's
     if (wr == 1) P8_BARRIER();  // wave row 1 runs one barrier behind wave row 0
     P8_STAMP(1);
+    if (tile_ctr && threadIdx.x == 0) ticket = atomicAdd(tile_ctr, 1);  // next tile's ticket: retires under the main loop
 
     f32x4 acc[2 * MH][4];
 #pragma unroll
@@ -354,8 +379,10 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     if (wr == 0) P8_BARRIER();
     wait_vmcnt<0>();  // drain the trailing dummies before LDS is released
     P8_STAMP(2);
+    if (tile_ctr && threadIdx.x == 0) *ticket_lds = ticket;
 
     __syncthreads();  // DMA drained in every wave, all fragment reads done: LDS is free
+    const int t_next = tile_ctr ? 8 * __builtin_amdgcn_readfirstlane(*ticket_lds) + (int)(blockIdx.x & 7) : t + (int)gridDim.x;
     BiasRegs<4> bias_regs;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -376,8 +403,8 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     // "interior" = every wave can take the LDS-free epilogue (whole 256 columns; rows beyond M are masked per lane there)
     const bool interior = c.bn0 + 256 <= pe.N && epilogue_direct_ok(pe, c.bm0, c.bn0, 0, 0, BM, c.z1 * p.sc1 + c.z2 * p.sc2);
     primed = false;
-    if (t + (int)gridDim.x < ntiles) {
-      cur_t = decode(t + gridDim.x);
+    if (t_next < ntiles) {
+      cur_t = decode(t_next);
       // early priming counts on the epilogue issuing exactly epi_vm stores per wave: only for tiles with all their rows
       if (interior && epi_early && c.bm0 + BM <= pe.M) {
         prime(cur_t);
@@ -401,7 +428,50 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     P8_STAMP(5);  // ... and its stores have drained
     p8_round = min(p8_round + 1, 3);
 #endif
+    t = t_next;
   }
+  // the last workgroup out leaves the counters at zero for the next launch on this stream
+  if (p.tile_ctr && threadIdx.x == 0) {
+    // (agent-scope atomics only, no __threadfence(): a release fence here writes back the XCD's whole L2 -- the tiles just
+    // stored -- once per workgroup, which cost 13 us per launch; the kernel boundary orders the reset before the next launch)
+    if (atomicAdd(p.tile_ctr + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicExch(p.tile_ctr + i, 0);
+    }
+  }
+}
+
+// Ticket counters (eight per-XCD counters + the count of finished workgroups): one 64-byte slot per (device, stream).  Launches on a stream run in order and every launch leaves its slot
+// at zero, so a slot is reused without a reset; different streams never share one.
+int p8_ticket_slot(hipStream_t st, int** out) {
+  struct Key {
+    int dev;
+    hipStream_t st;
+    bool operator<(const Key& o) const { return dev != o.dev ? dev < o.dev : st < o.st; }
+  };
+  static std::mutex mu;
+  static std::map<Key, int*> slots;
+  static std::map<int, std::pair<char*, int>> pools;  // device -> (zeroed pool, slots used)
+  constexpr int POOL_SLOTS = 1024;
+  int dev = 0;
+  SSAK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = slots.find(Key{dev, st});
+  if (it == slots.end()) {
+    auto& pool = pools[dev];
+    if (!pool.first) {
+      SSAK_HIP(hipMalloc((void**)&pool.first, POOL_SLOTS * 64));
+      SSAK_HIP(hipMemset(pool.first, 0, POOL_SLOTS * 64));
+      pool.second = 0;
+    }
+    if (pool.second >= POOL_SLOTS) {  // more streams than slots: fall back to the static order on the extra ones
+      *out = nullptr;
+      return SSAK_OK;
+    }
+    it = slots.emplace(Key{dev, st}, reinterpret_cast<int*>(pool.first + 64 * pool.second++)).first;
+  }
+  *out = it->second;
+  return SSAK_OK;
 }
 
 int p8_num_cu(int* out) {
@@ -413,6 +483,15 @@ int p8_num_cu(int* out) {
   }
   *out = n_cu;
   return SSAK_OK;
+}
+
+int g_p8_dynamic = -1;  // -1: not set (environment SSAK_GEMM_DYNAMIC_TILES decides, default static)
+bool p8_dynamic() {
+  if (g_p8_dynamic < 0) {
+    const char* e = getenv("SSAK_GEMM_DYNAMIC_TILES");
+    g_p8_dynamic = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_p8_dynamic == 1;
 }
 
 template <int MH, bool A_KM, bool B_KM>
@@ -429,7 +508,11 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
   P8Group none;
   none.n = 0;
   none.total_tiles = 0;
-  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(p, none);  // one persistent workgroup per CU
+  GemmParams q = p;
+  q.tile_ctr = nullptr;
+  if (ntiles > n_cu && n_cu % 8 == 0 && p8_dynamic())
+    if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
+  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q, none);  // one persistent workgroup per CU
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -452,12 +535,21 @@ int launch_p8_grouped(const GemmParams& p, const P8Group& grp, hipStream_t st) {
   }
   int n_cu = 0;
   if (int rc = p8_num_cu(&n_cu)) return rc;
-  kern<<<dim3((unsigned)std::min(grp.total_tiles, n_cu)), P8_THREADS, P8_LDS, st>>>(p, grp);
+  GemmParams q = p;
+  q.tile_ctr = nullptr;
+  if (grp.total_tiles > n_cu && n_cu % 8 == 0 && p8_dynamic())
+    if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
+  kern<<<dim3((unsigned)std::min(grp.total_tiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q, grp);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
 }  // namespace
+
+extern "C" int ssak_gemm_tile_order(int dynamic) {
+  g_p8_dynamic = dynamic ? 1 : 0;
+  return SSAK_OK;
+}
 
 int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);

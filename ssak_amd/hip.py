@@ -70,6 +70,7 @@ def _load():
         "ssak_ctc_forced_align": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
+        "ssak_gemm_tile_order": (i32, [i32]),
         "ssak_prof_enable": (i32, [i32]),
         "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),

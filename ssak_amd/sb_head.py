@@ -350,6 +350,8 @@ class Brain:
         self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.dist else 1
         self._works = []
+        if self.dist and self.world > 1:
+            hip.check(hip.lib.ssak_gemm_tile_order(1))  # collectives share the chip with the persistent GEMMs
         # BatchNorm over the global batch under data parallelism; False = per-rank statistics, what the
         # reference's nn.DataParallel / DDP without SyncBatchNorm computes
         head.sync_bn = bool(self.dist and sync_batchnorm)

@@ -81,6 +81,9 @@ class Trainer:
         # group-norm ("base") models run without attention mask, layer-norm (XLSR) models with it
         self.use_mask = model.config.feat_extract_norm == "layer"
         self._works = []
+        if self.dist and self.world > 1:
+            # RCCL's kernels take CUs away from the persistent GEMMs for a while: draw tiles from tickets (include/ssak_hip.h)
+            hip.check(hip.lib.ssak_gemm_tile_order(1))
         if self.dist:
             # bucketed exchange: one async sum all-reduce per announced gradient range (a layer's matrices = 28 MB
             # for base), issued while the rest of the backward is still running; RCCL runs them on its own stream

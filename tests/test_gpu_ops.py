@@ -450,3 +450,54 @@ def test_gemm_fused_column_sums(hip, M, N):
     want = C2.float().sum(0) + 3.0
     tol = 2e-3 * C2.float().abs().sum(0) + 1e-3  # C2 is the bf16 rounding of what was summed in fp32
     assert bool(((cs - want).abs() <= tol).all()), float((cs - want).abs().max())
+
+
+def test_gemm_dynamic_tile_order(hip):
+    """The ticket-drawn tile order of the persistent kernels (what the data-parallel trainers switch on) gives exactly the
+    static order's results: multi-round shapes, integer operands (bit-exact), repeated launches on one stream (every launch
+    leaves its counters at zero), two streams at once (separate counter slots), and a grouped launch."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(4096, 2304, 512, False, False), (5000, 1024, 256, False, True), (3072, 3072, 384, True, True)]
+    data = []
+    for M, N, K, a_km, b_km in shapes:
+        A = torch.randint(-3, 4, (K, M) if a_km else (M, K), generator=g).to(torch.bfloat16).cuda()
+        B = torch.randint(-3, 4, (K, N) if b_km else (N, K), generator=g).to(torch.bfloat16).cuda()
+        data.append((A, B, M, N, K, a_km, b_km))
+
+    def run(stream=None):
+        outs = []
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            for A, B, M, N, K, a_km, b_km in data:
+                Cc = torch.empty(M, N, dtype=torch.float32, device="cuda")
+                hip.gemm(A, B, Cc, M, N, K, a_kmajor=a_km, b_kmajor=b_km, lda=A.shape[1], ldb=B.shape[1], ldc=N)
+                outs.append(Cc)
+        return outs
+
+    ref = run()
+    torch.cuda.synchronize()
+    hip.check(hip.lib.ssak_gemm_tile_order(1))
+    try:
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(3):
+            o0 = run()
+            o1, o2 = run(s1), run(s2)
+            torch.cuda.synchronize()
+            for o in (o0, o1, o2):
+                for got, want in zip(o, ref):
+                    assert torch.equal(got, want)
+        # grouped (weight-gradient form): 2 x (768 x 3072) + (2304 x 768) at 256 x 256 tiles = 99 tiles ... make it > 256
+        K = 512
+        probs, wants = [], []
+        for M, N in [(3072, 3072), (3072, 2304), (2304, 3072)]:
+            A = torch.randint(-3, 4, (K, M), generator=g).to(torch.bfloat16).cuda()
+            B = torch.randint(-3, 4, (K, N), generator=g).to(torch.bfloat16).cuda()
+            Cc = torch.empty(M, N, dtype=torch.float32, device="cuda")
+            probs.append((A, B, Cc, M, N, K, M, N, N, True, True))
+            wants.append(A.float().T @ B.float())
+        for _ in range(2):
+            hip.gemm_grouped(probs)
+        torch.cuda.synchronize()
+        for (A, B, Cc, *_), w in zip(probs, wants):
+            assert torch.equal(Cc, w)
+    finally:
+        hip.check(hip.lib.ssak_gemm_tile_order(0))
