@@ -120,11 +120,37 @@ __device__ __forceinline__ bf16x8 load_row_frag(const bf16* base, long ld, int r
   return *reinterpret_cast<const bf16x8*>(base + (long)row * ld + 32 * kk + 8 * (lane >> 4));
 }
 
+// Workgroup -> (batch, head, block) with the blocks of one (batch, head) on ONE XCD.  The hardware deals consecutive
+// workgroup ids round-robin over the 8 XCDs, each with its own L2: with the plain (block, head, batch) grid order the 4
+// query blocks of a head landed on 4 different XCDs and each fetched that head's K and V from HBM again (rocprofv3
+// FETCH_SIZE: 221 MB per forward launch for 98 MB of operands).  Here XCD x takes the heads bh = x (mod 8) and walks their
+// blocks back to back, so the first block's fetches serve the others from L2.  Identity when batch * heads is not a
+// multiple of 8.
+struct AttnBlock {
+  int b, h, blk;
+};
+__device__ __forceinline__ AttnBlock attn_block() {
+  const int nblk = gridDim.x, nh = gridDim.y, nbh = gridDim.y * gridDim.z;
+  AttnBlock r;
+  if ((nbh & 7) != 0) {
+    r.b = blockIdx.z, r.h = blockIdx.y, r.blk = blockIdx.x;
+    return r;
+  }
+  const int L = blockIdx.x + nblk * (blockIdx.y + nh * blockIdx.z);
+  const int xcd = L & 7, j = L >> 3;
+  const int bh = (j / nblk) * 8 + xcd;
+  r.blk = j % nblk;
+  r.b = bh / nh;
+  r.h = bh % nh;
+  return r;
+}
+
 // ================================================================================================ forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K | V)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+  const AttnBlock ab = attn_block();
+  const int b = ab.b, h = ab.h, q0 = ab.blk * QB;
   const int F = p.F, H = p.H;
   const long ld = 3L * H;
   const bf16* base = p.qkv + (long)b * F * ld;
@@ -282,7 +308,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K rows | K transpose | V rows)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+  const AttnBlock ab = attn_block();
+  const int b = ab.b, h = ab.h, q0 = ab.blk * QB;
   const int F = p.F, H = p.H;
   const long ld = 3L * H;
   const bf16* base = p.qkv + (long)b * F * ld;
@@ -420,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q rows|Q tr|dO rows|dO tr), then lse|delta per stage
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * QB;
+  const AttnBlock ab = attn_block();
+  const int b = ab.b, h = ab.h, key0 = ab.blk * QB;
   const int F = p.F, H = p.H;
   const long ld = 3L * H;
   const bf16* base = p.qkv + (long)b * F * ld;
