@@ -14,6 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-12))
+
+
 def _cfg(Wav2Vec2Config, oc):
     d = dataclasses.asdict(oc)
     d.pop("initializer_range")
@@ -312,3 +318,56 @@ def test_dp2_ranks_stay_identical_with_per_rank_layerdrop(tmp_path):
     mp.spawn(_dp_layerdrop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.equal(a, b)
+
+
+def test_torch_autograd_loop_matches_native_trainer():
+    """The reference's loop shape -- loss.backward(), clip_grad_norm_, torch.optim.AdamW.step(), zero_grad() on a torch host
+    loop (ssak_amd.autograd) -- against the fused native trainer from the same start: same losses, same parameters after three
+    steps (both clip at 1.0; Adam's sign-like first steps are compared on the update as a whole).  And the CTC autograd
+    function against torch's own F.ctc_loss gradient."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.autograd import TorchWav2Vec2ForCTC, ctc_loss
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    oc = R.W2V2Config.tiny().deterministic()
+    p0 = R.init_params(oc, 3)
+    rng = np.random.default_rng(1)
+    x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(9000).astype(np.float32) for _ in range(4)])).cuda()
+    labels = torch.tensor(R.pad_labels([list(rng.integers(1, 32, n)) for n in (6, 4, 7, 5)])).cuda()
+    native = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
+    native.load_state_dict(p0)
+    tr = Trainer(native, AdamW(native, lr=1e-3, warmup_steps=0, total_steps=1 << 40, max_grad_norm=1.0))
+    tm = TorchWav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
+    tm.load_state_dict(p0)
+    opt = torch.optim.AdamW(tm.parameters(), lr=1e-3, weight_decay=0.0)
+    p_init = native.params.clone()
+    for _ in range(3):
+        l_native = tr.train_step(x, None, labels, raw=False).item()
+        out = tm(x, labels=labels)
+        out.loss.backward()
+        assert float(tm.params.grad[tm.num_trainable:].abs().max()) == 0.0  # frozen feature encoder
+        torch.nn.utils.clip_grad_norm_(tm.parameters(), 1.0)
+        opt.step()
+        tm.zero_grad()
+        assert abs(out.loss.item() - l_native) < 2e-3 * abs(l_native)
+    n = native.num_trainable
+    du_n, du_t = (native.params - p_init)[:n], (tm.params.detach() - p_init)[:n]
+    assert float(du_n.abs().max()) > 1e-3 and float((du_t - du_n).norm() / du_n.norm()) < 0.05
+    # evaluation through the torch-visible model uses the updated weights (shadow refreshed on the version change)
+    tm.eval()
+    native.eval()
+    assert rel_l2(tm(x).logits.cpu(), native(x).logits.cpu()) < 2e-2
+    # CTC as an autograd function on logits with history
+    lg = torch.randn(3, 40, 16, device="cuda", requires_grad=True)
+    w = torch.randn(16, 16, device="cuda", requires_grad=True)
+    tl = torch.tensor([[1, 2, 3, -1], [4, 5, -1, -1], [6, 7, 8, 9]], device="cuda")
+    loss, nll = ctc_loss(lg @ w, None, tl)
+    (loss * 2.0).backward()
+    lg2, w2 = lg.detach().cpu().requires_grad_(True), w.detach().cpu().requires_grad_(True)
+    lp = torch.log_softmax(lg2 @ w2, -1).transpose(0, 1)
+    ref = torch.nn.functional.ctc_loss(lp, torch.tensor([1, 2, 3, 4, 5, 6, 7, 8, 9]), torch.full((3,), 40), torch.tensor([3, 2, 4]),
+                                       blank=0, reduction="mean", zero_infinity=True)
+    (ref * 2.0).backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert rel_l2(lg.grad.cpu(), lg2.grad) < 1e-3 and rel_l2(w.grad.cpu(), w2.grad) < 1e-3
