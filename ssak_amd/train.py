@@ -10,6 +10,7 @@ import argparse
 import hashlib
 import json
 import os
+import shutil
 import time
 
 import numpy as np
@@ -173,9 +174,30 @@ def main(argv=None):
     rng = np.random.RandomState(args.seed)
     use_mask = model.config.feat_extract_norm == "layer"
     step, t0, run_loss = 0, time.time(), []
+    # resume from the last checkpoint of this output folder (wav2vec_train.py:245 get_last_checkpoint -> :415
+    # trainer.train(resume_from_checkpoint=...)): weights, optimizer moments and step, the dropout / SpecAugment streams; the
+    # batch order is replayed from the seed up to the checkpoint's step
+    resume_step = 0
+    last = last_checkpoint(out_dir)
+    if last is not None:
+        from .checkpoint import load_state_dict_file
+        model.load_state_dict(load_state_dict_file(last))
+        opt.load_state_dict(torch.load(os.path.join(last, "optimizer.pt")))
+        with open(os.path.join(last, "trainer_state.json")) as f:
+            state = json.load(f)
+        extra = torch.load(os.path.join(last, "rng.pt"), weights_only=False)
+        model._step_seed, _ = extra["step_seed"], model._host_rng.set_state(extra["host_rng"])
+        resume_step = int(state["global_step"])
+        if rank == 0:
+            print(f"resuming from {last} (step {resume_step} of {total})")
     while step < total:
         plan = [shard_batch(idx, rank, world) if world > 1 else idx for idx in length_grouped_batches(train_len, args.batch_size, rng)]
         plan = [m for m in plan if m][:total - step]
+        if step < resume_step:  # batches the checkpointed run already consumed
+            skip = min(len(plan), resume_step - step)
+            plan, step = plan[skip:], step + skip
+            if not plan:
+                continue
         if args.online:
             feed = BatchPrefetcher(ingest, [[(train_u[i].path, train_u[i].start or None, train_u[i].end or None) for i in m] for m in plan])
         else:
@@ -200,13 +222,29 @@ def main(argv=None):
                     ck = os.path.join(out_dir, f"checkpoint-{step}")
                     save_pretrained(model, tok, ck)
                     torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
+                    torch.save({"step_seed": int(model._step_seed), "host_rng": model._host_rng.get_state()}, os.path.join(ck, "rng.pt"))
                     with open(os.path.join(ck, "trainer_state.json"), "w") as f:
                         json.dump(state, f, indent=1)
+                    for old in sorted_checkpoints(out_dir)[:-2]:  # save_total_limit=2 (wav2vec_train.py:370)
+                        shutil.rmtree(old, ignore_errors=True)
     if rank == 0:
         save_pretrained(model, tok, os.path.join(out_dir, "final"))
         print(f"trained {step} steps in {time.time() - t0:.1f} s -> {out_dir}")
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def sorted_checkpoints(out_dir: str):
+    if not os.path.isdir(out_dir):
+        return []
+    cks = [d for d in os.listdir(out_dir) if d.startswith("checkpoint-") and d[11:].isdigit()
+           and os.path.exists(os.path.join(out_dir, d, "trainer_state.json"))]
+    return [os.path.join(out_dir, d) for d in sorted(cks, key=lambda d: int(d[11:]))]
+
+
+def last_checkpoint(out_dir: str):
+    cks = sorted_checkpoints(out_dir)
+    return cks[-1] if cks else None
 
 
 def tok_pad(folder: str) -> int:

@@ -130,6 +130,24 @@ def test_train_and_infer_cli_on_kaldi_folder(tmp_path):
     evals = [e["eval_loss"] for e in st["log_history"] if "eval_loss" in e]
     assert st["global_step"] == 40 and len(train_losses) == 2 and train_losses[1] < train_losses[0]
     assert evals[-1] < json.load(open(run / "init_eval.json"))["eval_loss"]
+    # resume (wav2vec_train.py:245,415): an interrupted copy of the run -- checkpoint-20 only -- continues to the same end:
+    # same batches from the seed, same optimizer moments and step, same second-interval loss
+    import shutil
+    shutil.copytree(tmp_path / "out", tmp_path / "out_resume")
+    run_r = tmp_path / "out_resume" / outs[0]
+    shutil.rmtree(run_r / "checkpoint-40")
+    shutil.rmtree(run_r / "final")
+    r = subprocess.run([sys.executable, "-m", "ssak_amd.train", str(kd), str(kd), "--base_model", str(tmp_path / "base"),
+                        "--batch_size", "4", "--num_epochs", "20", "--eval_steps", "20", "--learning_rate", "3e-3",
+                        "--min_duration", "0", "--output_dir", str(tmp_path / "out_resume")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "resuming from" in r.stdout and "checkpoint-20" in r.stdout
+    st_r = json.load(open(run_r / "checkpoint-40" / "trainer_state.json"))
+    losses_r = [e["loss"] for e in st_r["log_history"] if "loss" in e]
+    assert st_r["global_step"] == 40 and len(losses_r) == 2 and losses_r[0] == train_losses[0]
+    assert abs(losses_r[1] - train_losses[1]) < 1e-3 * abs(train_losses[1])
+    assert (run_r / "final" / "model.safetensors").exists()
     # --online: the same training with audio read on the fly and decoded / normalised on the device (ssak_amd.ingest)
     # must follow the same loss trajectory (same seed, same batches; dropout is off in this config)
     r = subprocess.run([sys.executable, "-m", "ssak_amd.train", str(kd), str(kd), "--base_model", str(tmp_path / "base"),
