@@ -148,17 +148,35 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Roofline leg: HIP events around GEMM launches, recorded by the library on the launch stream.  Bracketing EVERY GEMM of
+    # a step costs ~3 % of it (an event pair keeps consecutive kernels from overlapping head to tail), so the survey of all
+    # GEMM instantiations runs inside the last warm-up steps and the timed region brackets only the dominant instantiation.
+    n_survey = min(2, args.warmup)
+    for _ in range(args.warmup - n_survey):
         trainer.train_step(waves, None, labels)
     sync()
-    hip.prof_enable(True)
+    survey, dom = None, -1
+    if n_survey:
+        hip.prof_enable(1)
+        hip.prof_collect()
+        ts = time.perf_counter()
+        for _ in range(n_survey):
+            trainer.train_step(waves, None, labels)
+        sync()
+        survey_dt = time.perf_counter() - ts
+        hip.prof_enable(0)
+        survey = hip.prof_collect()
+        dom = max(range(len(survey)), key=lambda i: survey[i][2])
+    hip.prof_enable(2 + dom if dom >= 0 else 1)
+    if os.environ.get("SSAK_BENCH_NO_PROF") == "1":  # development switch: cost of the events
+        hip.prof_enable(0)
     hip.prof_collect()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.train_step(waves, None, labels)
     sync()
     dt = time.perf_counter() - t0
-    hip.prof_enable(False)
+    hip.prof_enable(0)
     prof = hip.prof_collect()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -176,7 +194,6 @@ def main():
         if prof:
             name, launches, ms, flops = prof[0]
             ach = flops / (ms * 1e-3) / 1e12
-            gemm_ms = sum(p[2] for p in prof)
             traffic, traffic_src = None, None
             try:  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes of the same command
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
@@ -187,9 +204,14 @@ def main():
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": launches // args.steps, "avg_launch_us": round(ms * 1e3 / launches, 2),
-                    "all_gemm_tflops": round(sum(p[3] for p in prof) / (gemm_ms * 1e-3) / 1e12, 1),
-                    "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 3),
+                    "timed_with": "HIP events around every launch of this instantiation inside the timed region",
                     "whole_step_tflops": round(GF_PER_UTT_TRAIN * 1e9 * B * args.steps / dt / 1e12, 1)}
+            if survey:  # all GEMM instantiations, from the last warm-up steps
+                sv = [p for p in survey if p[1] > 0]
+                sv_ms = sum(p[2] for p in sv)
+                roof["survey"] = {"source": f"last {n_survey} warm-up steps, every GEMM launch bracketed",
+                                  "all_gemm_tflops": round(sum(p[3] for p in sv) / (sv_ms * 1e-3) / 1e12, 1),
+                                  "gemm_share_of_step": round(sv_ms * 1e-3 / survey_dt, 3)}
         out = {"metric": "utterances/sec (16 kHz, 10 s) Wav2Vec2-base CTC train step", "value": round(value, 2),
                "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

@@ -171,8 +171,11 @@ int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs /*host*/, int n, const vo
 int ssak_gemm_tile_order(int dynamic);
 
 /* Per-launch GEMM timing for the roofline report (measurement aid, not on the reference's path): while
- * enabled, every GEMM launch is bracketed by HIP events on its own stream; ssak_prof_collect waits for them and
- * returns, per kernel instantiation (named as rocprofv3 prints it), launches / summed ms / algorithmic FLOPs. */
+ * enabled, GEMM launches are bracketed by HIP events on their own stream; ssak_prof_collect waits for them and
+ * returns, per kernel instantiation (named as rocprofv3 prints it), launches / summed ms / algorithmic FLOPs.
+ * ssak_prof_enable(0) = off, (1) = every launch, (2 + i) = only the instantiation at index i of ssak_prof_collect's
+ * table: an event pair keeps consecutive kernels from overlapping head to tail, and bracketing all ~100 GEMMs of a train
+ * step costs 3 % of it, so a benchmark times only the instantiation it reports on inside its timed region. */
 typedef struct {
   char name[80];
   long launches;

@@ -632,7 +632,8 @@ struct ProfRec {
   int variant;
   double flops;
 };
-bool g_prof_on = false;
+int g_prof_mode = 0;  // 0 = off, 1 = every GEMM launch, 2 + v = only kernel slot v (the events cost ~3 % of a step when all are on)
+inline bool prof_wanted(int variant) { return g_prof_mode == 1 || g_prof_mode == variant + 2; }
 bool g_no_big_tile = false;  // development switch (SSAK_GEMM_NO_BIG=1): keep the 128x128 kernels
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_event_pool;
@@ -663,16 +664,17 @@ int launch(const GemmParams& p, bool dma, hipStream_t st) {
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
   ProfRec rec;
-  if (g_prof_on) {
+  rec.variant = (dma ? 0 : 8) + (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
+  const bool prof = prof_wanted(rec.variant);
+  if (prof) {
     rec.e0 = prof_event();
     rec.e1 = prof_event();
-    rec.variant = (dma ? 0 : 8) + (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
     (void)hipEventRecord(rec.e0, st);
   }
   kern<<<dim3((unsigned)nblk), NTHREADS, lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
-  if (g_prof_on) {
+  if (prof) {
     (void)hipEventRecord(rec.e1, st);
     g_prof.push_back(rec);
   }
@@ -690,16 +692,17 @@ int launch_big(const GemmParams& p, hipStream_t st) {
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
   ProfRec rec;
-  if (g_prof_on) {
+  rec.variant = 16 + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
+  const bool prof = prof_wanted(rec.variant);
+  if (prof) {
     rec.e0 = prof_event();
     rec.e1 = prof_event();
-    rec.variant = 16 + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
     (void)hipEventRecord(rec.e0, st);
   }
   kern<<<dim3((unsigned)nblk), 512, lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
-  if (g_prof_on) {
+  if (prof) {
     (void)hipEventRecord(rec.e1, st);
     g_prof.push_back(rec);
   }
@@ -898,15 +901,16 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
     ProfRec rec;
-    if (g_prof_on) {
+    rec.variant = 20 + (p8_bm / 64 - 2) * 4 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
+    const bool prof = prof_wanted(rec.variant);
+    if (prof) {
       rec.e0 = prof_event();
       rec.e1 = prof_event();
-      rec.variant = 20 + (p8_bm / 64 - 2) * 4 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
       rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
       (void)hipEventRecord(rec.e0, st);
     }
     rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
-    if (g_prof_on) {
+    if (prof) {
       (void)hipEventRecord(rec.e1, st);
       g_prof.push_back(rec);
     }
@@ -997,15 +1001,16 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
   p.kt_per_split = ssak_cdiv(d0.K, BK);
   hipStream_t st = (hipStream_t)stream;
   ProfRec rec;
-  if (g_prof_on) {
+  rec.variant = 32;
+  const bool prof = prof_wanted(rec.variant);
+  if (prof) {
     rec.e0 = prof_event();
     rec.e1 = prof_event();
-    rec.variant = 32;
     rec.flops = flops;
     (void)hipEventRecord(rec.e0, st);
   }
   const int rc = ssak_gemm_p8_launch_grouped(&p, n, A, B, C, Ms, Ns, lda, ldb, ldc, ea, eb, d0.a_kmajor, d0.b_kmajor, st);
-  if (g_prof_on) {
+  if (prof) {
     (void)hipEventRecord(rec.e1, st);
     g_prof.push_back(rec);
   }
@@ -1013,7 +1018,7 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
 }
 
 extern "C" int ssak_prof_enable(int on) {
-  g_prof_on = on != 0;
+  g_prof_mode = on < 0 ? 0 : on;
 
   return SSAK_OK;
 }

@@ -261,8 +261,9 @@ def gemm_grouped(problems, stream_=None):
     check(lib.ssak_gemm_bf16_grouped(descs, n, pa, pb, pc, stream()))
 
 
-def prof_enable(on: bool):
-    check(lib.ssak_prof_enable(int(on)))
+def prof_enable(mode: int):
+    """0 = off, 1 = every GEMM launch, 2 + i = only the instantiation at index i of :func:`prof_collect`'s list."""
+    check(lib.ssak_prof_enable(int(mode)))
 
 
 def prof_collect():
