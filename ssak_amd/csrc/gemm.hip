@@ -937,6 +937,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   if (colsum_out) {
     if (colsum_fused) {
       const int slots = 2 * ssak_cdiv(d->M, p8_bm);  // (tile row, wave row) pairs, wave tiles of p8_bm / 2 rows
+      if (g_reduce_sink && g_reduce_sink->push((const float*)workspace, d->N, slots, d->N, colsum_out)) return SSAK_OK;
       colsum_slots_kernel<<<ssak_cdiv(d->N, 64), 1024, 0, st>>>((const float*)workspace, slots, d->N, colsum_out);
       SSAK_LAUNCH_CHECK();
     } else {

@@ -8,6 +8,30 @@ struct DropSpec {
   float p = 0.f;
 };
 
+// Deferred second stages of the two-stage column reductions (LayerNorm dgamma / dbeta / bias sums, column sums of bf16
+// matrices, the GEMM epilogue's per-tile-row sums): out[n] += sum_k partial[k * stride + n].  Each used to be its own 4 us
+// launch -- 50 per train step, a fifth of all launches.  While a sink is installed (the engine's backward does, per pair of
+// encoder layers) the producers queue the job instead and k_reduce_flush runs all of them as ONE launch; the partial buffers
+// must stay untouched until then.
+struct ReduceJob {
+  const float* partial;
+  float* out;
+  long stride;
+  int slots, ncols;
+};
+struct ReduceSink {
+  static constexpr int CAP = 32;
+  ReduceJob jobs[CAP];
+  int n = 0;
+  bool push(const float* partial, long stride, int slots, int ncols, float* out) {
+    if (n >= CAP) return false;
+    jobs[n++] = ReduceJob{partial, out, stride, slots, ncols};
+    return true;
+  }
+};
+extern thread_local ReduceSink* g_reduce_sink;
+int k_reduce_flush(ReduceSink& sink, hipStream_t st);
+
 // norm_act.hip
 int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
                     float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,

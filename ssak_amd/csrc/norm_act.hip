@@ -332,6 +332,34 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
   }
 }
 
+// All queued second stages in one launch.  Workgroup = 64 columns x 16 slot groups of one job (fixed summation order).
+struct ReduceTable {
+  ReduceJob jobs[ReduceSink::CAP];
+  int first_block[ReduceSink::CAP + 1];
+  int n;
+};
+__global__ __launch_bounds__(1024) void reduce_jobs_kernel(const ReduceTable t) {
+  __shared__ float red[16][65];
+  int j = 0;
+  for (int k = 1; k < t.n; ++k) j = (int)blockIdx.x >= t.first_block[k] ? k : j;
+  const ReduceJob& q = t.jobs[j];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = ((int)blockIdx.x - t.first_block[j]) * 64 + cx;
+  float s = 0.f;
+  if (n < q.ncols) {
+#pragma unroll 4
+    for (int k = ry; k < q.slots; k += 16) s += q.partial[(long)k * q.stride + n];
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < q.ncols) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += red[r][cx];
+    q.out[n] += v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- softmax
 // Scores arrive in bf16 (what the bf16 QK^T GEMM produces); statistics are fp32.  One wave per row; a lane owns
 // 16-byte chunks (8 consecutive keys) so every access is a full-width vector load/store.
@@ -612,6 +640,12 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   else
     ln_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
+  if (g_reduce_sink && g_reduce_sink->n + 3 <= ReduceSink::CAP) {  // second stage queued: one launch for many (kernels.h)
+    g_reduce_sink->push(partial, 3L * C, grid, C, dgamma);
+    g_reduce_sink->push(partial + C, 3L * C, grid, C, dbeta);
+    if (dy_colsum) g_reduce_sink->push(partial + 2 * C, 3L * C, grid, C, dy_colsum);
+    return SSAK_OK;
+  }
   ln_bwd_finalize_kernel<<<ssak_cdiv((dy_colsum ? 3 : 2) * C, 64), 1024, 0, st>>>(partial, grid, C, dgamma, dbeta, dy_colsum);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -659,9 +693,36 @@ int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, f
   colsum_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, out, det ? scratch : nullptr, rowmask, flens, F > 0 ? F : 1);
   SSAK_LAUNCH_CHECK();
   if (det) {
+    if (g_reduce_sink && g_reduce_sink->push(scratch, N, (int)grid.y, N, out)) return SSAK_OK;
     colsum_rows_kernel<<<ssak_cdiv(N, 64), 1024, 0, st>>>(scratch, (int)grid.y, N, out);
     SSAK_LAUNCH_CHECK();
   }
+  return SSAK_OK;
+}
+
+thread_local ReduceSink* g_reduce_sink = nullptr;
+
+int k_reduce_flush(ReduceSink& sink, hipStream_t st) {
+  int done = 0;
+  while (done < sink.n) {
+    // jobs that add into the same vector must not share a launch (plain +=): cut the batch at the first repeat
+    ReduceTable t;
+    t.n = 0;
+    int blocks = 0;
+    for (int i = done; i < sink.n; ++i) {
+      bool repeat = false;
+      for (int k = 0; k < t.n; ++k) repeat |= t.jobs[k].out == sink.jobs[i].out;
+      if (repeat) break;
+      t.first_block[t.n] = blocks;
+      t.jobs[t.n++] = sink.jobs[i];
+      blocks += ssak_cdiv(sink.jobs[i].ncols, 64);
+    }
+    t.first_block[t.n] = blocks;
+    reduce_jobs_kernel<<<blocks, 1024, 0, st>>>(t);
+    SSAK_LAUNCH_CHECK();
+    done += t.n;
+  }
+  sink.n = 0;
   return SSAK_OK;
 }
 

@@ -59,7 +59,7 @@ struct Plan {
   std::vector<size_t> x;       // L+1 layer inputs/outputs
   std::vector<LayerBuf> lb;
   // backward temporaries
-  size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH, lnpart;
+  size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH, lnpart, redring, redring_floats;
   // second set of the buffers the weight-gradient products read (dy of both LayerNorms, dI, dqkv): those products are
   // queued and launched two layers at a time, so a layer's set must survive the next layer's backward
   size_t dY1 = 0, dYb[2] = {0, 0}, dIb[2] = {0, 0}, dqkvb[2] = {0, 0}, dY1b[2] = {0, 0};
@@ -399,6 +399,10 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.dwf = cv.take((size_t)H * K * (H / G) * sizeof(float));
     p.dln0 = cv.take((size_t)M * C * b2);
     p.lnpart = cv.take((size_t)LN_BWD_BLOCKS * 3 * std::max(H, C) * sizeof(float));
+    // partial sums of the reductions whose second stage is deferred to one launch per pair of encoder layers (kernels.h:
+    // ReduceSink): per layer two LayerNorm backward slabs, the FFN bias sums of the dX epilogue and the qkv bias sums
+    p.redring_floats = 3 * ((size_t)2 * LN_BWD_BLOCKS * 3 * H + (size_t)ssak_cdiv(M, 64) * I + (size_t)64 * 3 * H);
+    p.redring = cv.take(p.redring_floats * sizeof(float));
     // split-K slabs: the largest weight-gradient product is [I,H] (or [3H,H]); at most 32 slices
     const size_t big = (size_t)std::max(std::max(I * H, 3 * H * H), std::max(H * C, V * H));
     p.slab_bytes = big * 32 * sizeof(float);
@@ -985,20 +989,54 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     return (bf16*)nullptr;
   };
   WgradQueue wq;
+  // second stages of the layers' column reductions: queued, launched together at every weight-gradient flush
+  ReduceSink sink;
+  struct SinkGuard {
+    SinkGuard(ReduceSink* s) { g_reduce_sink = s; }
+    ~SinkGuard() { g_reduce_sink = nullptr; }
+  };
+  size_t red_used = 0;
+  auto red_take = [&](size_t nfloats) -> float* {  // a partial-sum region that stays untouched until the next flush
+    nfloats = (nfloats + 63) & ~(size_t)63;
+    if (red_used + nfloats > p.redring_floats) return nullptr;
+    float* r = FP(p.redring) + red_used;
+    red_used += nfloats;
+    return r;
+  };
+  auto red_get = [&](size_t nfloats, float** out) -> int {
+    float* r = red_take(nfloats);
+    if (!r) {  // ring full (cannot happen with the flush cadence of two layers; kept for safety): run what is queued
+      TRY(k_reduce_flush(sink, st));
+      red_used = 0;
+      r = red_take(nfloats);
+    }
+    if (!r) {
+      ssak_set_error("w2v2_backward: reduction ring too small");
+      return SSAK_ERR_STATE;
+    }
+    *out = r;
+    return SSAK_OK;
+  };
+  const size_t ln_part_floats = (size_t)LN_BWD_BLOCKS * 3 * H;
   int kept = 0;  // layers that ran so far: selects the buffer set their weight-gradient operands live in
   const int layer_tiles = ssak_cdiv(3 * H, 256) * ssak_cdiv(H, 256) + ssak_cdiv(H, 256) * ssak_cdiv(H, 256) +
                           2 * ssak_cdiv(I, 256) * ssak_cdiv(H, 256);
   auto flush_wgrads = [&]() -> int {
+    TRY(k_reduce_flush(sink, st));
+    red_used = 0;
     TRY(wq.flush(st, slab, p.slab_bytes));
     for (int i = 0; i < wq.n_ann; ++i) announce(wq.ann_off[i], layer_span);
     wq.n_ann = 0;
     wq.layers = 0;
     return SSAK_OK;
   };
+  SinkGuard sink_guard(&sink);
   for (int l = c.num_layers - 1; l >= 0; --l) {
     const LayerP& L = e->lp[l];
     const LayerBuf& lb = p.lb[l];
     float* stl = FP(lb.st);
+    float *ln_part = nullptr, *ln_part2 = nullptr, *ffn_part = nullptr, *qkv_part = nullptr;
+    TRY(red_get(ln_part_floats, &ln_part));
     const long nxt_w = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1w : e->p_eln_w;
     const long nxt_b = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1b : e->p_eln_b;
     if (!e->keep[l]) {
@@ -1011,13 +1049,16 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       // x[l+1] = LN_next(r): its gradient joins the residual-stream gradient; nothing consumed x[l]
       bf16* dr = free_buf(gA, gB, Gres);
       TRY(k_layernorm_bwd(gA, gB, BF(e->hres[l]), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dr, nullptr, Gd + nxt_w, Gd + nxt_b,
-                          FP(p.lnpart), M, H, none, none, st));
+                          ln_part, M, H, none, none, st));
       Gres = dr;
       gA = BF(p.dB);
       gB = nullptr;
       SSAK_HIP(hipMemsetAsync(gA, 0, (size_t)M * H * sizeof(bf16), st));
       continue;
     }
+    TRY(red_get(ln_part_floats, &ln_part2));
+    TRY(red_get((size_t)ssak_cdiv(M, 64) * I, &ffn_part));
+    TRY(red_get((size_t)64 * 3 * H, &qkv_part));
     bf16* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
     const int set = kept & 1;
     ++kept;
@@ -1027,11 +1068,11 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     if (!stable) {
       // final_layer_norm backward: r2 = x1 + drop(ffn)
       TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, dY,
-                          Gd + L.ln2w, Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
+                          Gd + L.ln2w, Gd + L.ln2b, ln_part, M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
     } else {
       // (next LN) backward: x[l+1] = LN_next(r2), r2 = r1 + drop(ffn); the residual-stream gradient is added after it
       TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dR, dY, Gd + nxt_w,
-                          Gd + nxt_b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
+                          Gd + nxt_b, ln_part, M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
     }
     // (the dy output is written even without hidden dropout -- a plain copy then -- so that the queued weight-gradient
     // products always read buffers of this layer's set, never the rotating residual-stream buffers)
@@ -1039,7 +1080,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     wq.push(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
     TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
             .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed)
-            .colsum(Gd + L.b1).run(st, slab, p.slab_bytes));  // b1's gradient = column sums of dI, taken in the epilogue
+            .colsum(Gd + L.b1).run(st, ffn_part, (size_t)ssak_cdiv(M, 64) * I * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
     wq.push(Gemm(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
     bf16* dX = BF(p.dB);
     TRY(Gemm(M, H, I).a(dI, I).b(W + L.w1, H, true).c(dX, H).run(st));
@@ -1048,12 +1089,12 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
       dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
       TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, dY1, Gd + L.ln1w,
-                          Gd + L.ln1b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
+                          Gd + L.ln1b, ln_part2, M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
     } else {
       // final_layer_norm backward: x1 = LN(r1), r1 = r + drop(attn_out); residual gradient dR is added after it
       dR1 = free_buf(dR, dX, nullptr);
       TRY(k_layernorm_bwd(dX, nullptr, BF(lb.r1), stl, stl + M, P + L.ln2w, dR, dR1, dY1, Gd + L.ln2w,
-                          Gd + L.ln2b, FP(p.lnpart), M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
+                          Gd + L.ln2b, ln_part2, M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
     }
     const bf16* dy1 = dY1;
     wq.push(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));  // (bo's gradient: summed by the LN backward)
@@ -1078,7 +1119,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
     }
     wq.push(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
-    TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, FP(p.lnpart), cs_floats));
+    TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
     TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
     wq.ann_off[wq.n_ann++] = L.wqkv;
     ++wq.layers;
@@ -1095,6 +1136,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     }
   }
   TRY(flush_wgrads());
+  g_reduce_sink = nullptr;  // the rest of the backward launches its second stages directly
   // ---- encoder input
   bf16* dh1 = free_buf(gA, gB, Gres);
   if (!stable) {
