@@ -3,6 +3,8 @@
 // One wave per SIMD: fragment reads of K step t+1 are interleaved with the MFMAs of step t inside the wave; 32-deep K
 // steps, four LDS stages of 32 KB, LDS-DMA issued three steps ahead, one barrier per step.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Issak_amd/csrc tools/probes/p4_probe.hip -o tools/probes/p4_probe.bin
+// -DP4_FLAGS: no workgroup barrier in the loop -- per-stage LDS counters instead ("my share of stage s has landed" / "I have
+// read stage s"), so the four waves drift within the slack of the four-stage pipeline instead of meeting every K step.
 #include "../../ssak_amd/csrc/common.h"
 #include "../../ssak_amd/csrc/gemm_common.h"
 
@@ -77,6 +79,12 @@ __global__ __launch_bounds__(256) void gemm_p4_probe(const bf16* A, const bf16* 
     fo_a[i] = ra * 64 + ((lq ^ ((ra >> 2) & 3)) << 4);
     fo_b[i] = 16384 + rb * 64 + ((lq ^ ((rb >> 2) & 3)) << 4);
   }
+#ifdef P4_FLAGS
+  typedef __attribute__((address_space(3))) int lds_int;
+  int* const flags = reinterpret_cast<int*>(smem + P4_NS * P4_STAGE);  // [0..3] landed counters, [4..7] read counters
+  if (threadIdx.x < 8) flags[threadIdx.x] = 0;
+  __syncthreads();
+#endif
   // prologue: stages 0..3 in flight
 #pragma unroll
   for (int s = 0; s < P4_NS; ++s) {
@@ -85,6 +93,11 @@ __global__ __launch_bounds__(256) void gemm_p4_probe(const bf16* A, const bf16* 
   }
   wait_vmcnt<24>();  // stage 0 landed (this wave's share)
   __syncthreads();
+#ifdef P4_FLAGS
+  // stage 0's landing was settled by the barrier above: start its counter at 4 (one generation complete)
+  if (threadIdx.x == 0) flags[0] = 4;
+  __syncthreads();
+#endif
   bf16x8 fa[2][8], fb[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -99,7 +112,24 @@ __global__ __launch_bounds__(256) void gemm_p4_probe(const bf16* A, const bf16* 
 #ifndef P4_NO_WAIT
       wait_vmcnt<16>();
 #endif
-#ifndef P4_NO_BARRIER
+#ifdef P4_FLAGS
+      {
+        // this wave's share of stage tt+1 has landed; this wave finished reading stage tt one step ago (fragments in registers)
+        const int s1 = (tt + 1) & 3, s0 = tt & 3;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the fragment reads of stage tt are in registers
+        if (lane == 0) {
+          __hip_atomic_fetch_add(flags + s1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(flags + 4 + s0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const int want_landed = 4 * (((tt + 1) >> 2) + 1), want_read = 4 * ((tt >> 2) + 1);
+        int guard = 0;  // (a probe must terminate even if the protocol is wrong)
+        while ((__hip_atomic_load(flags + s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want_landed ||
+                __hip_atomic_load(flags + 4 + s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want_read) &&
+               ++guard < 200000)
+          __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#elif !defined(P4_NO_BARRIER)
       __syncthreads();
 #endif
       char* const nxt = smem + ((tt + 1) & 3) * P4_STAGE;
@@ -168,7 +198,7 @@ int main(int argc, char** argv) {
   for (auto& v : hb) v = tobf((float)(rand() % 7 - 3));
   hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
-  hipFuncSetAttribute((const void*)gemm_p4_probe, hipFuncAttributeMaxDynamicSharedMemorySize, P4_NS * P4_STAGE);
+  hipFuncSetAttribute((const void*)gemm_p4_probe, hipFuncAttributeMaxDynamicSharedMemorySize, P4_NS * P4_STAGE + 64);
   const int grid = (M / 256) * (N / 256);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -176,7 +206,7 @@ int main(int argc, char** argv) {
   float best = 1e9;
   for (int it = 0; it < 6; ++it) {
     hipEventRecord(e0);
-    gemm_p4_probe<<<grid, 256, P4_NS * P4_STAGE>>>(A, B, C, M, N, K);
+    gemm_p4_probe<<<grid, 256, P4_NS * P4_STAGE + 64>>>(A, B, C, M, N, K);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms;
