@@ -466,3 +466,40 @@ def test_recipe_dp2_sync_batchnorm_equals_single_process(tmp_path):
     assert torch.equal(a["head"], b["head"])
     # and per-rank statistics (sync_batchnorm=False) do differ from the global ones: the switch is live
     assert not torch.allclose(a["run_mean"], torch.zeros_like(a["run_mean"]))
+
+
+def test_head_kernels_reject_bad_arguments(hip):
+    """Argument errors come back as ValueError through the C ABI's status (never a launch with mismatched shapes)."""
+    x = torch.zeros(4, 24, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty_like(x)
+    f = torch.zeros(24, device="cuda")
+    ws = _ws(hip.lib.ssak_batchnorm_workspace_bytes(24))
+    args = (hip.ptr(x), hip.ptr(y), 4, 24, hip.ptr(f), hip.ptr(f))
+    with pytest.raises(ValueError):  # evaluation mode without running statistics
+        hip.check(hip.lib.ssak_batchnorm_act_fwd(*args, None, None, 0.1, 1e-5, 0, 0.01, 0.0, C.c_uint64(0), 0, hip.ptr(f), hip.ptr(f), None,
+                                                 hip.ptr(ws), ws.numel(), hip.stream()))
+    with pytest.raises(ValueError):  # workspace too small
+        hip.check(hip.lib.ssak_batchnorm_act_fwd(*args, None, None, 0.1, 1e-5, 1, 0.01, 0.0, C.c_uint64(0), 0, hip.ptr(f), hip.ptr(f), None,
+                                                 hip.ptr(ws), 16, hip.stream()))
+    x7 = torch.zeros(4, 28, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):  # C not a multiple of 8
+        hip.check(hip.lib.ssak_batchnorm_act_fwd(hip.ptr(x7), hip.ptr(x7), 4, 28, hip.ptr(f), hip.ptr(f), None, None, 0.1, 1e-5, 1, 0.01, 0.0,
+                                                 C.c_uint64(0), 0, hip.ptr(f), hip.ptr(f), None, hip.ptr(ws), ws.numel(), hip.stream()))
+    uws = _ws(hip.lib.ssak_utt_norm_workspace_bytes(2))
+    w = torch.zeros(2, 1001, device="cuda")
+    with pytest.raises(ValueError):  # fp32 rows must be multiples of 4 samples
+        hip.check(hip.lib.ssak_utt_norm_fwd(hip.ptr(w), hip.ptr(w), 2, 1001, 0, 1e-5, None, hip.ptr(uws), uws.numel(), hip.stream()))
+    with pytest.raises(ValueError):
+        hip.check(hip.lib.ssak_adadelta_step(None, hip.ptr(f), hip.ptr(f), hip.ptr(f), None, 24, None, 0.0, 1.0, 1.0, 0.95, 1e-8, 0.0,
+                                             hip.stream()))
+    from ssak_amd.sb_head import CTCHead
+    with pytest.raises(ValueError):
+        CTCHead(100, 64, 13)  # input_dim must be a multiple of 8
+    head = CTCHead(64, 64, 13, dropouts=(0.0, 0.0, 0.0))
+    with pytest.raises(RuntimeError):
+        head.backward(torch.zeros(1, 2, head.Vp, device="cuda"))  # no training-mode forward
+    # a single row / a single utterance still normalise (variance 0 -> rstd = 1 / sqrt(eps))
+    one = torch.full((1, 64), 3.0, dtype=torch.bfloat16, device="cuda")
+    y1, mean, rstd = _bn_fwd(hip, one, torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda"),
+                             torch.ones(64, device="cuda"), True, 0.0, 1, 0)
+    assert torch.all(y1 == 0) and torch.allclose(mean, torch.full_like(mean, 3.0)) and torch.allclose(rstd, torch.full_like(rstd, 1e5 ** 0.5), rtol=1e-3)
