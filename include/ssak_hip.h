@@ -324,6 +324,9 @@ int ssak_adadelta_step(float* params, const float* grads, float* square_avg, flo
                        const float* gnorm_sq, float max_norm, float grad_scale, float lr, float rho, float eps, float weight_decay,
                        void* stream);
 int ssak_cast_f32_bf16(const float* src, void* dst_bf16, long n, void* stream);
+/* the way back (the optional bf16 gradient exchange of the data-parallel trainer: 180 MB instead of 361 MB per step,
+ * SURVEY.md 8e); 16-byte aligned buffers */
+int ssak_cast_bf16_f32(const void* src_bf16, float* dst, long n, void* stream);
 /* out[N] = column sums of X [M, N] bf16 (row stride ld): the bias gradient of a Linear from its output gradient.  Two-stage,
  * fixed-order; N and ld multiples of 8. */
 size_t ssak_colsum_workspace_bytes(int N);

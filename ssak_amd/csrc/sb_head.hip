@@ -660,6 +660,26 @@ extern "C" int ssak_adadelta_step(float* params, const float* grads, float* squa
   return SSAK_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restrict__ in, float* __restrict__ out, long n) {
+  const long n8 = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const bf16x8 q = reinterpret_cast<const bf16x8*>(in)[i];
+    reinterpret_cast<float4*>(out)[2 * i] = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+    reinterpret_cast<float4*>(out)[2 * i + 1] = make_float4((float)q[4], (float)q[5], (float)q[6], (float)q[7]);
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) out[i] = (float)in[i];
+}
+}  // namespace
+
+extern "C" int ssak_cast_bf16_f32(const void* src_bf16, float* dst, long n, void* stream) {
+  SSAK_REQUIRE(src_bf16 && dst && n > 0 && (((uintptr_t)src_bf16 | (uintptr_t)dst) & 15) == 0, "cast_bf16_f32: bad arguments");
+  cast_bf16_f32_kernel<<<(int)fmin(4096.0, (double)ssak_cdiv(n, 2048)), 256, 0, (hipStream_t)stream>>>((const bf16*)src_bf16, dst, n);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
 extern "C" int ssak_cast_f32_bf16(const float* src, void* dst_bf16, long n, void* stream) {
   SSAK_REQUIRE(src && dst_bf16 && n > 0, "cast_f32_bf16: bad arguments");
   return k_cast_f32_bf16(src, (bf16*)dst_bf16, n, (hipStream_t)stream);

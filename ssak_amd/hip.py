@@ -105,6 +105,7 @@ def _load():
         "ssak_batchnorm_stats": (i32, [vp, i32, i32, vp, vp, sz, vp]),
         "ssak_adadelta_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, vp]),
         "ssak_cast_f32_bf16": (i32, [vp, vp, C.c_long, vp]),
+        "ssak_cast_bf16_f32": (i32, [vp, vp, C.c_long, vp]),
         "ssak_colsum_workspace_bytes": (sz, [i32]),
         "ssak_colsum_bf16": (i32, [vp, C.c_long, i32, i32, vp, vp, sz, vp]),
     }

@@ -13,6 +13,8 @@ latency of many small collectives.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip
@@ -73,8 +75,16 @@ class AdamW:
 class Trainer:
     """One optimizer step per call; data-parallel when a process group is initialised."""
 
-    def __init__(self, model: Wav2Vec2ForCTC, optimizer: AdamW, normalize_on_device: bool = True):
+    def __init__(self, model: Wav2Vec2ForCTC, optimizer: AdamW, normalize_on_device: bool = True,
+                 grad_exchange_dtype: str | None = None):
+        """``grad_exchange_dtype``: "fp32" (default; or environment SSAK_DP_GRAD_DTYPE) or "bf16" -- the gradient buckets are
+        rounded to bf16 for the all-reduce and widened again before the clip + update: half the bytes over xGMI (180 MB
+        instead of 361 MB per step for the base model) at bf16 rounding of the exchanged sums."""
         self.model, self.opt = model, optimizer
+        self.grad_exchange_dtype = grad_exchange_dtype or os.environ.get("SSAK_DP_GRAD_DTYPE", "fp32")
+        if self.grad_exchange_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_exchange_dtype must be 'fp32' or 'bf16'")
+        self._g16 = None
         self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.dist else 1
         self.normalize_on_device = normalize_on_device
@@ -90,7 +100,16 @@ class Trainer:
             model.set_grad_ready_callback(self._on_grads_ready)
 
     def _on_grads_ready(self, offset: int, count: int):
-        self._works.append(torch.distributed.all_reduce(self.model.grads[offset:offset + count], async_op=True))
+        m = self.model
+        if self.grad_exchange_dtype == "bf16":
+            if self._g16 is None:
+                self._g16 = torch.empty(m.num_trainable, dtype=torch.bfloat16, device=m.device)
+            # ranges start at multiples of 8 elements for every supported topology; the cast runs on the compute stream,
+            # behind the kernels that produced the range
+            hip.check(hip.lib.ssak_cast_f32_bf16(hip.ptr(m.grads[offset:]), hip.ptr(self._g16[offset:]), count, hip.stream()))
+            self._works.append(torch.distributed.all_reduce(self._g16[offset:offset + count], async_op=True))
+            return
+        self._works.append(torch.distributed.all_reduce(m.grads[offset:offset + count], async_op=True))
 
     def broadcast_parameters(self):
         if self.dist:
@@ -106,6 +125,8 @@ class Trainer:
         m.backward()  # with a process group: announces finished gradient ranges -> bucketed all-reduces overlap it
         for w in self._works:
             w.wait()  # the compute stream waits for the reduced buckets; mean over ranks is folded into the optimizer
+        if self._works and self.grad_exchange_dtype == "bf16":
+            hip.check(hip.lib.ssak_cast_bf16_f32(hip.ptr(self._g16), hip.ptr(m.grads), m.num_trainable, hip.stream()))
         self._works.clear()
         self.opt.step(grad_scale=1.0 / self.world)
         return out.loss

@@ -223,8 +223,8 @@ def _dp_problem():
     return oc, R.init_params(oc, 21), x, labels
 
 
-def _dp_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _dp_worker(rank, world, port, out, exchange="fp32"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SSAK_DP_GRAD_DTYPE=exchange)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one card of the test box
     from ssak_amd.config import Wav2Vec2Config
     from ssak_amd.data import shard_batch
@@ -244,8 +244,10 @@ def _dp_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_dp2_trainer_equals_single_process(tmp_path):
-    """Two ranks of the REAL trainer (engine grad-ready callbacks -> bucketed async all-reduce -> fused clip + AdamW with the
+@pytest.mark.parametrize("exchange", ["fp32", "bf16"])
+def test_dp2_trainer_equals_single_process(tmp_path, exchange):
+    """(exchange = "bf16": the optional half-width gradient exchange -- buckets rounded to bf16 for the all-reduce.)
+    Two ranks of the REAL trainer (engine grad-ready callbacks -> bucketed async all-reduce -> fused clip + AdamW with the
     1/world scale) on half the batch each reproduce the single-process run on the whole batch: same parameters after 4
     steps within bf16-engine noise.  gloo stands in for RCCL so that both ranks fit on the one GPU of the test box."""
     import socket
@@ -257,7 +259,7 @@ def test_dp2_trainer_equals_single_process(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, out, exchange), nprocs=2, join=True)
     got = torch.load(out)
     oc, p0, x, labels = _dp_problem()
     model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
