@@ -501,3 +501,27 @@ def test_gemm_dynamic_tile_order(hip):
             assert torch.equal(Cc, w)
     finally:
         hip.check(hip.lib.ssak_gemm_tile_order(0))
+
+
+def test_cast_and_colsum_helpers(hip):
+    """ssak_cast_f32_bf16 / ssak_cast_bf16_f32 (round to nearest even and exact widening, odd lengths) and ssak_colsum_bf16
+    against torch, on sizes that exercise the vector bodies and the scalar tails."""
+    g = torch.Generator().manual_seed(2)
+    for n in (8, 1003, 4096 + 13):
+        x = torch.randn(n, generator=g).cuda()
+        b = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        hip.check(hip.lib.ssak_cast_f32_bf16(hip.ptr(x), hip.ptr(b), n, hip.stream()))
+        assert torch.equal(b, x.to(torch.bfloat16))
+        y = torch.empty(n, device="cuda")
+        hip.check(hip.lib.ssak_cast_bf16_f32(hip.ptr(b), hip.ptr(y), n, hip.stream()))
+        assert torch.equal(y, b.float())
+    for M, N in ((1, 8), (700, 64), (4999, 2304)):
+        X = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+        out = torch.full((N,), 7.0, device="cuda")  # overwritten, not accumulated
+        ws = torch.empty(hip.lib.ssak_colsum_workspace_bytes(N), dtype=torch.uint8, device="cuda")
+        hip.check(hip.lib.ssak_colsum_bf16(hip.ptr(X), N, M, N, hip.ptr(out), hip.ptr(ws), ws.numel(), hip.stream()))
+        ref = X.double().sum(0)
+        assert float((out.double() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+        out2 = torch.empty_like(out)
+        hip.check(hip.lib.ssak_colsum_bf16(hip.ptr(X), N, M, N, hip.ptr(out2), hip.ptr(ws), ws.numel(), hip.stream()))
+        assert torch.equal(out, out2)  # fixed summation order
