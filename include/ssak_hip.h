@@ -285,7 +285,8 @@ int ssak_w2v2_backward_hidden(ssak_w2v2* h, const void* dhidden_bf16, void* work
  *
  * ssak_utt_norm_*: F.layer_norm(x, x.shape[1:]) without affine parameters -- the wrapper's waveform normalisation (fp32,
  * is_bf16 = 0) and its output_norm over (frames x features) (bf16, is_bf16 = 1).  x, y [B, n]; stats [B][2] = (mean, rstd) out
- * (may be NULL in the forward when no backward follows); the backward takes y, the forward's OUTPUT.  n a multiple of 8 / 4. */
+ * (may be NULL in the forward when no backward follows); the backward takes y, the forward's OUTPUT.  Any n (rows whose length
+ * is a multiple of 8 bf16 / 4 fp32 elements take the 16-byte vector path). */
 size_t ssak_utt_norm_workspace_bytes(int B);
 int ssak_utt_norm_fwd(const void* x, void* y, int B, long n, int is_bf16, float eps, float* stats, void* workspace,
                       size_t workspace_bytes, void* stream);

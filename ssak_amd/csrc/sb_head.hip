@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void un_partial_kernel(const T* __restrict__ A
   __shared__ float red[16];
   constexpr int N = Chunk<T>::N;
   const long base = (long)blockIdx.y * n;
-  const long nch = n / N;
+  const long nch = (n % N == 0) ? n / N : 0;  // rows of other lengths are not 16-byte aligned: element by element
   float s = 0.f, q = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long)gridDim.x * 256) {
     float a[8], b[8];
@@ -395,12 +395,11 @@ __global__ __launch_bounds__(256) void un_partial_kernel(const T* __restrict__ A
       q = fmaf(a[k], B2 ? b[k] : a[k], q);
     }
   }
-  if (blockIdx.x == 0)
-    for (long i = nch * N + threadIdx.x; i < n; i += 256) {
-      const float a = (float)A[base + i], b = B2 ? (float)B2[base + i] : a;
-      s += a;
-      q = fmaf(a, b, q);
-    }
+  for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float a = (float)A[base + i], b = B2 ? (float)B2[base + i] : a;
+    s += a;
+    q = fmaf(a, b, q);
+  }
   s = block_sum(s, red);
   q = block_sum(q, red);
   if (threadIdx.x == 0) {
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(256) void un_fwd_apply_kernel(const T* __restrict__
   __syncthreads();
   const float mu = mr[0], rs = mr[1];
   const long base = (long)blockIdx.y * n;
-  const long nch = n / N;
+  const long nch = (n % N == 0) ? n / N : 0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long)gridDim.x * 256) {
     float a[8];
     loadv<T>(x + base, i, a);
@@ -442,8 +441,8 @@ __global__ __launch_bounds__(256) void un_fwd_apply_kernel(const T* __restrict__
     for (int k = 0; k < N; ++k) a[k] = (a[k] - mu) * rs;
     storev<T>(y + base, i, a);
   }
-  if (blockIdx.x == 0)
-    for (long i = nch * N + threadIdx.x; i < n; i += 256) y[base + i] = (T)(((float)x[base + i] - mu) * rs);
+  for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[base + i] = (T)(((float)x[base + i] - mu) * rs);
 }
 // backward: dx = rstd * (dy - mean(dy) - y * mean(dy * y))   (y is the forward's output = xhat)
 template <typename T>
@@ -464,7 +463,7 @@ __global__ __launch_bounds__(256) void un_bwd_apply_kernel(const T* __restrict__
   __syncthreads();
   const float c1 = cc[0], c2 = cc[1], rs = stats[blockIdx.y * 2 + 1];
   const long base = (long)blockIdx.y * n;
-  const long nch = n / N;
+  const long nch = (n % N == 0) ? n / N : 0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long)gridDim.x * 256) {
     float d[8], h[8];
     loadv<T>(dy + base, i, d);
@@ -473,9 +472,8 @@ __global__ __launch_bounds__(256) void un_bwd_apply_kernel(const T* __restrict__
     for (int k = 0; k < N; ++k) d[k] = rs * (d[k] - c1 - h[k] * c2);
     storev<T>(dx + base, i, d);
   }
-  if (blockIdx.x == 0)
-    for (long i = nch * N + threadIdx.x; i < n; i += 256)
-      dx[base + i] = (T)(rs * ((float)dy[base + i] - c1 - (float)y[base + i] * c2));
+  for (long i = nch * N + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    dx[base + i] = (T)(rs * ((float)dy[base + i] - c1 - (float)y[base + i] * c2));
 }
 
 // ---------------------------------------------------------------- Adadelta
@@ -544,8 +542,7 @@ extern "C" int ssak_utt_norm_fwd(const void* x, void* y, int B, long n, int is_b
                                  size_t workspace_bytes, void* stream) {
   SSAK_REQUIRE(x && y && workspace && B > 0 && n > 0, "utt_norm_fwd: bad arguments");
   SSAK_REQUIRE(workspace_bytes >= ssak_utt_norm_workspace_bytes(B), "utt_norm_fwd: workspace too small");
-  SSAK_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && n % (is_bf16 ? 8 : 4) == 0,
-               "utt_norm_fwd: rows must be 16-byte aligned (n a multiple of %d)", is_bf16 ? 8 : 4);
+  SSAK_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "utt_norm_fwd: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   return is_bf16 ? utt_norm_fwd<bf16>((const bf16*)x, (bf16*)y, B, n, eps, stats, (float*)workspace, st)
                  : utt_norm_fwd<float>((const float*)x, (float*)y, B, n, eps, stats, (float*)workspace, st);
@@ -555,8 +552,7 @@ extern "C" int ssak_utt_norm_bwd(const void* dy, const void* y, void* dx, int B,
                                  void* workspace, size_t workspace_bytes, void* stream) {
   SSAK_REQUIRE(dy && y && dx && stats && workspace && B > 0 && n > 0, "utt_norm_bwd: bad arguments");
   SSAK_REQUIRE(workspace_bytes >= ssak_utt_norm_workspace_bytes(B), "utt_norm_bwd: workspace too small");
-  SSAK_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15) == 0 && n % (is_bf16 ? 8 : 4) == 0,
-               "utt_norm_bwd: rows must be 16-byte aligned (n a multiple of %d)", is_bf16 ? 8 : 4);
+  SSAK_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15) == 0, "utt_norm_bwd: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   return is_bf16 ? utt_norm_bwd<bf16>((const bf16*)dy, (const bf16*)y, (bf16*)dx, B, n, stats, (float*)workspace, st)
                  : utt_norm_bwd<float>((const float*)dy, (const float*)y, (float*)dx, B, n, stats, (float*)workspace, st);

@@ -30,7 +30,7 @@ def _ws(n):
 
 
 @pytest.mark.parametrize("dtype,B,n", [(torch.float32, 3, 16000), (torch.float32, 2, 4004), (torch.bfloat16, 4, 49 * 64),
-                                       (torch.bfloat16, 2, 499 * 1024)])
+                                       (torch.bfloat16, 2, 499 * 1024), (torch.float32, 3, 23457), (torch.bfloat16, 2, 1003)])
 def test_utt_norm_fwd_bwd(hip, dtype, B, n):
     g = torch.Generator().manual_seed(n)
     x = (torch.randn(B, n, generator=g) * 0.3 + 0.1).to(dtype)
@@ -487,8 +487,8 @@ def test_head_kernels_reject_bad_arguments(hip):
                                                  C.c_uint64(0), 0, hip.ptr(f), hip.ptr(f), None, hip.ptr(ws), ws.numel(), hip.stream()))
     uws = _ws(hip.lib.ssak_utt_norm_workspace_bytes(2))
     w = torch.zeros(2, 1001, device="cuda")
-    with pytest.raises(ValueError):  # fp32 rows must be multiples of 4 samples
-        hip.check(hip.lib.ssak_utt_norm_fwd(hip.ptr(w), hip.ptr(w), 2, 1001, 0, 1e-5, None, hip.ptr(uws), uws.numel(), hip.stream()))
+    with pytest.raises(ValueError):  # workspace too small
+        hip.check(hip.lib.ssak_utt_norm_fwd(hip.ptr(w), hip.ptr(w), 2, 1001, 0, 1e-5, None, hip.ptr(uws), 8, hip.stream()))
     with pytest.raises(ValueError):
         hip.check(hip.lib.ssak_adadelta_step(None, hip.ptr(f), hip.ptr(f), hip.ptr(f), None, 24, None, 0.0, 1.0, 1.0, 0.95, 1e-8, 0.0,
                                              hip.stream()))
@@ -503,3 +503,104 @@ def test_head_kernels_reject_bad_arguments(hip):
     y1, mean, rstd = _bn_fwd(hip, one, torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda"),
                              torch.ones(64, device="cuda"), True, 0.0, 1, 0)
     assert torch.all(y1 == 0) and torch.allclose(mean, torch.full_like(mean, 3.0)) and torch.allclose(rstd, torch.full_like(rstd, 1e5 ** 0.5), rtol=1e-3)
+
+
+_HPARAMS = """# written by the test: the recipe's keys with hyperpyyaml tags, small sizes
+num_epochs: 6
+lr: 1.0
+lr_wav2vec: 0.0001
+sorting: random
+batch_size: 4
+test_batch_size: 4
+min_duration: 0
+max_duration: 15
+freeze_wav2vec: True
+eval_steps: 4
+debug: False
+seed: 1234
+__set_seed: !apply:torch.manual_seed [!ref <seed>]
+train: !PLACEHOLDER
+valid: !PLACEHOLDER
+output_folder_prefix: ''
+base_model: !PLACEHOLDER
+dnn_neurons: 64
+output_neurons: 30
+blank_index: 0
+model_opt_class: !name:torch.optim.Adadelta
+    lr: !ref <lr>
+    rho: 0.95
+    eps: 1.e-8
+lr_annealing_model: !new:speechbrain.nnet.schedulers.NewBobScheduler
+    initial_value: !ref <lr>
+    improvement_threshold: 0.0025
+    annealing_factor: 0.8
+    patient: 0
+lr_annealing_wav2vec: !new:speechbrain.nnet.schedulers.NewBobScheduler
+    initial_value: !ref <lr_wav2vec>
+    improvement_threshold: 0.0025
+    annealing_factor: 0.9
+    patient: 0
+"""
+
+
+@pytest.mark.timeout(900)
+def test_speechbrain_recipe_cli_on_kaldi_folder(tmp_path):
+    """`python -m ssak_amd.train_speechbrain HPARAMS.yaml --train=... --valid=... --base_model=...` on a synthetic Kaldi
+    corpus: the yaml's hyperpyyaml tags are read, the validation loss goes down over the epochs (frozen wav2vec2, Adadelta on
+    the head), train_log.txt has the recipe's fields, the best checkpoint becomes final/, a rerun resumes and has nothing left
+    to do, and --freeze_wav2vec=False trains the encoder too."""
+    import dataclasses
+    import json
+    import os
+    import subprocess
+    import sys
+    from ssak_amd import data as D
+    from ssak_amd.checkpoint import save_pretrained
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.synth import VOCAB, synth_text, synth_wave
+    from oracle import w2v2_ref as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    kd = tmp_path / "kaldi"
+    (kd / "audio").mkdir(parents=True)
+    with open(kd / "wav.scp", "w") as fw, open(kd / "text", "w") as ft, open(kd / "utt2dur", "w") as fd:
+        for i in range(12):
+            n = int(rng.integers(16000, 24000))
+            D.write_wav(str(kd / "audio" / f"u{i}.wav"), synth_wave(rng, n))
+            fw.write(f"utt{i} {kd}/audio/u{i}.wav\n")
+            ft.write(f"utt{i} {synth_text(rng, 3, 6)}\n")
+            fd.write(f"utt{i} {n / 16000:.3f}\n")
+    oc = dataclasses.replace(R.W2V2Config.tiny(), layerdrop=0.0)
+    d = dataclasses.asdict(oc)
+    d.pop("initializer_range")
+    base = Wav2Vec2ForCTC(Wav2Vec2Config(**d))
+    base.load_state_dict(R.init_params(oc, 1))
+    save_pretrained(base, D.CharTokenizer(VOCAB), str(tmp_path / "base"))
+    del base
+    hp = tmp_path / "hparams.yaml"
+    hp.write_text(_HPARAMS)
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "ssak_amd.train_speechbrain", str(hp), f"--train={kd}", f"--valid={kd}", f"--base_model={tmp_path / 'base'}",
+           f"--output_folder_prefix={tmp_path}/out_"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    runs = [p for p in os.listdir(tmp_path) if p.startswith("out_sb_")]
+    assert len(runs) == 1 and "_frTrue_lr1.0-0.0001_bs4_s1234_random" in runs[0]
+    run = tmp_path / runs[0]
+    lines = open(run / "train_log.txt").read().strip().split("\n")
+    assert len(lines) >= 6  # 3 batches per epoch: one validation at each epoch end, plus every 4th step
+    assert all(k in lines[0] for k in ("epoch: 1", "total_samples:", "total_audio_h:", "lr_model: 1", "lr_wav2vec:", "valid loss:", "valid WER:"))
+    vloss = [float(l.split("valid loss: ")[1].split(",")[0]) for l in lines]
+    assert vloss[-1] < vloss[0]
+    assert (run / "final" / "model.ckpt").exists() and (run / "final" / "vocab.json").exists()
+    assert 1 <= len([c for c in os.listdir(run / "save") if c.startswith("CKPT-")]) <= 2
+    best = json.load(open(run / "final" / "meta.json"))
+    assert best["WER"] == min(float(l.split("valid WER: ")[1]) for l in lines) or best["WER"] <= float(lines[-1].split("valid WER: ")[1])
+    r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "resuming from" in r2.stdout
+    assert open(run / "train_log.txt").read().strip().split("\n") == lines  # nothing left to train
+    r3 = subprocess.run(cmd + ["--freeze_wav2vec=False", "--num_epochs=1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    run3 = [p for p in os.listdir(tmp_path) if p.startswith("out_sb_") and "_frFalse_" in p]
+    assert len(run3) == 1 and (tmp_path / run3[0] / "final" / "wav2vec2.ckpt").exists()
