@@ -174,3 +174,49 @@ def test_newbob_scheduler_mirror():
     sch2 = NewBobScheduler(1.0, 0.8)
     sch2.load_state_dict(sch.state_dict())
     assert sch2.hyperparam_value == sch.hyperparam_value and sch2.metric_values == sch.metric_values
+
+
+_SB_YAML = """lr: 1.0
+lr_wav2vec: 0.0001
+batch_size: 32
+freeze_wav2vec: True
+seed: 1234
+__set_seed: !apply:torch.manual_seed [!ref <seed>]
+train: !PLACEHOLDER
+valid: !PLACEHOLDER
+output_folder_prefix: ''
+output_folder: !ref <output_folder_prefix>run_lr<lr>_bs<batch_size>
+save_folder: !ref <output_folder>/save
+model_opt_class: !name:torch.optim.Adadelta
+    lr: !ref <lr>
+    rho: 0.95
+    eps: 1.e-8
+lr_annealing_model: !new:speechbrain.nnet.schedulers.NewBobScheduler
+    initial_value: !ref <lr>
+    annealing_factor: 0.8
+    patient: 0
+"""
+
+
+def test_speechbrain_cli_yaml_and_overrides(tmp_path):
+    """ssak_amd.train_speechbrain reads the recipe's yaml without hyperpyyaml: tagged nodes as plain mappings, `!ref <key>`
+    resolved (typed when alone, interpolated inside strings), `!PLACEHOLDER` filled from --key=value / --key value, types of
+    overridden entries kept, --gpus dropped (ssak/train/speechbrain/wav2vec_train.py:499-529)."""
+    from ssak_amd.train_speechbrain import CharVocab, load_hparams, pad_tokens, parse_argv
+    y = tmp_path / "h.yaml"
+    y.write_text(_SB_YAML)
+    f, o = parse_argv([str(y), "--train=/a", "--valid", "/b", "--lr=0.5", "--freeze_wav2vec=False", "--gpus", "0", "--debug"])
+    assert f == str(y) and o == {"train": "/a", "valid": "/b", "lr": "0.5", "freeze_wav2vec": "False", "debug": "true"}
+    hp = load_hparams(f, o)
+    assert hp["lr"] == 0.5 and hp["freeze_wav2vec"] is False and hp["batch_size"] == 32 and hp["train"] == "/a"
+    assert hp["output_folder"] == "run_lr0.5_bs32" and hp["save_folder"] == "run_lr0.5_bs32/save"
+    assert hp["model_opt_class"] == {"lr": 0.5, "rho": 0.95, "eps": 1e-8}
+    assert hp["lr_annealing_model"]["initial_value"] == 0.5 and hp["lr_annealing_model"]["annealing_factor"] == 0.8
+    with pytest.raises(SystemExit):
+        load_hparams(f, {})  # train / valid are mandatory
+    with pytest.raises(SystemExit):
+        parse_argv(["--train=/a"])  # no yaml file
+    v = CharVocab.from_texts(["ab c", "ca"])
+    assert v.symbols == ["<blank>", " ", "a", "b", "c"] and v.encode("a cz") == [2, 1, 4]
+    t, tl = pad_tokens([[2, 3, 4, 2], [3]])
+    assert t.tolist() == [[2, 3, 4, 2], [3, 0, 0, 0]] and tl.tolist() == [1.0, 0.25]
