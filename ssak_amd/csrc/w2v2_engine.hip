@@ -955,7 +955,23 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   const float scale = 1.f / sqrtf((float)hd);
 
   const long n_grad = (e->cfg.arch == 1 || e->cfg.freeze_feature_encoder) ? e->n_train : e->n_total;
-  SSAK_HIP(hipMemsetAsync(Gd, 0, (size_t)n_grad * sizeof(float), st));
+  {
+    // Zero what is ACCUMULATED into (bias / LayerNorm / embedding gradients: everything outside the layers' weight matrices)
+    // and the matrices of dropped layers; the four matrices of a kept layer are written whole by its weight-gradient products
+    // (94 % of the buffer: 40 us of memset per step).  Falls back to the whole buffer if the layers are not laid out back to back.
+    const long span = (e->lp[0].w2 + (long)c.hidden_size * c.intermediate_size) - e->lp[0].wqkv;
+    bool packed = true;
+    for (int l = 1; l < c.num_layers; ++l) packed &= e->lp[l].wqkv == e->lp[l - 1].wqkv + span;
+    const long w0 = e->lp[0].wqkv, w1 = e->lp[c.num_layers - 1].wqkv + span;
+    if (!packed || w1 > n_grad) {
+      SSAK_HIP(hipMemsetAsync(Gd, 0, (size_t)n_grad * sizeof(float), st));
+    } else {
+      if (w0 > 0) SSAK_HIP(hipMemsetAsync(Gd, 0, (size_t)w0 * sizeof(float), st));
+      for (int l = 0; l < c.num_layers; ++l)
+        if (!e->keep[l]) SSAK_HIP(hipMemsetAsync(Gd + e->lp[l].wqkv, 0, (size_t)span * sizeof(float), st));
+      if (n_grad > w1) SSAK_HIP(hipMemsetAsync(Gd + w1, 0, (size_t)(n_grad - w1) * sizeof(float), st));
+    }
+  }
   // ---- lm_head (its gradient stays zero when the backward starts from the hidden state)
   bf16* dlog = BF(p.dlog);
   if (dlogits) {

@@ -59,6 +59,7 @@ def test_tiny_forward_backward_vs_hf(mods, gold):
     out = model(torch.tensor(z["x"]), labels=torch.tensor(z["labels"]), mask_time_indices=z["mask"])
     assert rel_l2(out.logits.cpu().numpy(), z["logits"]) < 2e-2
     assert abs(out.loss.item() - float(z["loss"])) < 2e-2 * float(z["loss"])
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     grads = {k[5:]: z[k] for k in z.files if k.startswith("grad/")}
     worst = _check_grads(model, grads, 6e-2)
@@ -87,6 +88,7 @@ def test_tiny_ragged_lengths_vs_oracle(mods):
     for b in range(4):  # only valid frames are defined by the reference
         assert rel_l2(out.logits[b, :fl[b]].cpu().numpy(), logits[b, :fl[b]].numpy()) < 2e-2
     assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     _check_grads(model, {n: g.numpy() for n, g in grads.items()}, 6e-2)
 
@@ -105,6 +107,7 @@ def test_tiny_xlsr_topology_vs_hf(mods, gold):
     for b in range(len(lens)):
         assert rel_l2(out.logits[b, :fl[b]].cpu().numpy(), z["logits"][b, :fl[b]]) < 2e-2
     assert abs(out.loss.item() - float(z["loss"])) < 2e-2 * float(z["loss"])
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     worst = _check_grads(model, {k[5:]: z[k] for k in z.files if k.startswith("grad/")}, 6e-2)
     print("tiny xlsr worst grad", worst)
@@ -127,6 +130,7 @@ def test_xlsr_layerdrop_and_dropout_vs_oracle(mods):
     model.load_state_dict(p)
     out = model(torch.tensor(x), labels=torch.tensor(labels), mask_time_indices=mask, layer_keep=keep)
     assert rel_l2(out.logits.cpu().numpy(), logits.numpy()) < 2e-2
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     g = {n: v.numpy() for n, v in grads.items()}
     _check_grads(model, g, 6e-2)
@@ -162,6 +166,7 @@ def test_base_vs_hf_golden(mods, gold):
     print("base logits rel l2", e, "loss", out.loss.item(), float(z["loss"]))
     assert e < 2e-2
     assert abs(out.loss.item() - float(z["loss"])) < 2e-2 * float(z["loss"])
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     worst = 0.0
     gmax = float(z["grad_norms"].max())
@@ -189,6 +194,7 @@ def test_dropout_replay_and_layerdrop(mods):
         model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc), seed=11).train()
         model.load_state_dict(p)
         out = model(torch.tensor(x), labels=torch.tensor(labels), layer_keep=[True, False])
+        model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
         model.backward()
         outs.append((out.loss.item(), model.grads.clone()))
         assert np.isfinite(out.loss.item())
@@ -263,6 +269,7 @@ def test_whisper_encoder_ctc_vs_hf(gold):
     assert out.logits.shape == (2, 50, 32)
     assert rel_l2(out.logits.cpu().numpy(), z["logits"]) < 2e-2
     assert abs(out.loss.item() - float(z["loss"])) < 2e-2 * float(z["loss"])
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     grads = {k[5:]: z[k] for k in z.files if k.startswith("grad/")}
     worst = _check_grads(model, grads, 6e-2)
@@ -285,6 +292,7 @@ def test_no_freeze_feature_encoder_gradients(mods):
     assert model.num_trainable == model.num_params
     out = model(torch.tensor(x), labels=torch.tensor(labels))
     assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     fe = {n: g.numpy() for n, g in grads.items() if n.startswith("wav2vec2.feature_extractor.")}
     assert len(fe) == 9
@@ -315,6 +323,7 @@ def test_no_freeze_layer_norm_feature_encoder_gradients(mods):
     assert model.num_trainable == model.num_params
     out = model(torch.tensor(x), lengths=torch.tensor(lens), labels=torch.tensor(labels))
     assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
+    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
     model.backward()
     fe = {n: g.numpy() for n, g in grads.items() if n.startswith("wav2vec2.feature_extractor.")}
     assert len(fe) == 7 * 4  # conv weight + bias, LayerNorm weight + bias per layer
