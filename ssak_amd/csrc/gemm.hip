@@ -941,7 +941,9 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
       colsum_slots_kernel<<<ssak_cdiv(d->N, 64), 1024, 0, st>>>((const float*)workspace, slots, d->N, colsum_out);
       SSAK_LAUNCH_CHECK();
     } else {
-      return k_colsum((const bf16*)C, d->ldc, d->M, d->N, colsum_out, st);
+      // separate pass over the stored C; two-stage and fixed-order when the workspace can hold its partial rows
+      // (min(64, ceil(M / 32)) * N floats), float atomics otherwise
+      return k_colsum((const bf16*)C, d->ldc, d->M, d->N, colsum_out, st, (float*)workspace, workspace_bytes / sizeof(float));
     }
   }
   return SSAK_OK;

@@ -401,7 +401,7 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.lnpart = cv.take((size_t)LN_BWD_BLOCKS * 3 * std::max(H, C) * sizeof(float));
     // partial sums of the reductions whose second stage is deferred to one launch per pair of encoder layers (kernels.h:
     // ReduceSink): per layer two LayerNorm backward slabs, the FFN bias sums of the dX epilogue and the qkv bias sums
-    p.redring_floats = 3 * ((size_t)2 * LN_BWD_BLOCKS * 3 * H + (size_t)ssak_cdiv(M, 64) * I + (size_t)64 * 3 * H);
+    p.redring_floats = 3 * ((size_t)2 * LN_BWD_BLOCKS * 3 * H + (size_t)std::max(ssak_cdiv(M, 64), 64) * I + (size_t)64 * 3 * H);
     p.redring = cv.take(p.redring_floats * sizeof(float));
     // split-K slabs: the largest weight-gradient product is [I,H] (or [3H,H]); at most 32 slices
     const size_t big = (size_t)std::max(std::max(I * H, 3 * H * H), std::max(H * C, V * H));
@@ -1073,7 +1073,8 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       continue;
     }
     TRY(red_get(ln_part_floats, &ln_part2));
-    TRY(red_get((size_t)ssak_cdiv(M, 64) * I, &ffn_part));
+    const size_t ffn_part_floats = (size_t)std::max(ssak_cdiv(M, 64), 64) * I;  // (>= 64 rows: the non-fused fallback's partials)
+    TRY(red_get(ffn_part_floats, &ffn_part));
     TRY(red_get((size_t)64 * 3 * H, &qkv_part));
     bf16* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
     const int set = kept & 1;
@@ -1096,7 +1097,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     wq.push(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
     TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
             .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed)
-            .colsum(Gd + L.b1).run(st, ffn_part, (size_t)ssak_cdiv(M, 64) * I * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
+            .colsum(Gd + L.b1).run(st, ffn_part, ffn_part_floats * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
     wq.push(Gemm(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
     bf16* dX = BF(p.dB);
     TRY(Gemm(M, H, I).a(dI, I).b(W + L.w1, H, true).c(dX, H).run(st));
