@@ -407,8 +407,11 @@ __global__ void posconv_colnorm_kernel(const float* __restrict__ v, const float*
   const float* vp = v + ((long)(g * cg) * cg + c) * K + k;  // + n * cg * K
   if (dwf) {
     const float* dp = dwf + (((long)g * K + k) * cg + c) * cg;  // + n
+    // (unrolled: the loads of eight rows in flight per thread; one at a time this kernel ran at HBM latency, 34 us for 19 MB)
+#pragma unroll 8
     for (int n = 0; n < cg; ++n) s = fmaf(vp[(long)n * cg * K], dp[n], s);
   } else {
+#pragma unroll 8
     for (int n = 0; n < cg; ++n) {
       const float a = vp[(long)n * cg * K];
       s = fmaf(a, a, s);
@@ -434,35 +437,62 @@ __global__ __launch_bounds__(1024) void posconv_colnorm_finalize_kernel(const fl
   }
 }
 
-__global__ void posconv_materialize_kernel(const float* __restrict__ g, const float* __restrict__ v,
-                                           const float* __restrict__ nsq, bf16* __restrict__ wf, bf16* __restrict__ wb,
-                                           int H, int cg, int K) {
-  const long n = (long)H * cg * K;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e % K);
-    const int c = (int)((e / K) % cg);
-    const int o = (int)(e / ((long)K * cg));
-    const float wv = g[k] * v[e] * rsqrtf(nsq[k]);
-    wf[((long)o * K + k) * cg + c] = (bf16)wv;
-    const int grp = o / cg, nn = o % cg;
-    wb[(((long)grp * cg + c) * K + (K - 1 - k)) * cg + nn] = (bf16)wv;
+// w = g[k] v / ||v_k|| in the two bf16 layouts the GEMMs read: wf[o][k][c] (forward / dX operand) and
+// wb[group][c][K-1-k][n] (o = group * cg + n).  Both are (c, k) <-> (k, c|n) transposes of v[o][c][k]: a workgroup stages
+// one [cg][K] slab through LDS -- slab o for wf (blocks [0, H)), the slab of (group, c) over its cg output channels for wb
+// (blocks [H, 2H)) -- so that global reads and writes are both contiguous (the element-wise version scattered 2-byte
+// stores: 48 us for 38 MB).
+__global__ __launch_bounds__(256) void posconv_materialize_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                                  const float* __restrict__ nsq, bf16* __restrict__ wf,
+                                                                  bf16* __restrict__ wb, int H, int cg, int K) {
+  extern __shared__ float slab[];  // [cg][K + 1]
+  const int KP = K + 1;
+  const bool back = (int)blockIdx.x >= H;
+  const int id = back ? blockIdx.x - H : blockIdx.x;
+  if (!back) {
+    const float* src = v + (long)id * cg * K;  // v[o = id][c][k]
+    for (int j = threadIdx.x; j < cg * K; j += 256) {
+      const int c = j / K, k = j % K;
+      slab[c * KP + k] = g[k] * src[j] * rsqrtf(nsq[k]);
+    }
+    __syncthreads();
+    bf16* dst = wf + (long)id * K * cg;  // wf[o][k][c]
+    for (int j = threadIdx.x; j < K * cg; j += 256) dst[j] = (bf16)slab[(j % cg) * KP + j / cg];
+  } else {
+    const int grp = id / cg, c = id % cg;
+    for (int j = threadIdx.x; j < cg * K; j += 256) {
+      const int nn = j / K, k = j % K;
+      slab[nn * KP + k] = g[k] * v[(((long)grp * cg + nn) * cg + c) * K + k] * rsqrtf(nsq[k]);
+    }
+    __syncthreads();
+    bf16* dst = wb + (long)id * K * cg;  // wb[group][c][kk][n], kk = K - 1 - k
+    for (int j = threadIdx.x; j < K * cg; j += 256) dst[j] = (bf16)slab[(j % cg) * KP + (K - 1 - j / cg)];
   }
 }
 
-__global__ void posconv_wbwd_kernel(const float* __restrict__ dwf, const float* __restrict__ g,
-                                    const float* __restrict__ v, const float* __restrict__ nsq,
-                                    const float* __restrict__ dot, float* __restrict__ dg, float* __restrict__ dv, int H,
-                                    int cg, int K) {
-  const long n = (long)H * cg * K;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e % K);
-    const int c = (int)((e / K) % cg);
-    const int o = (int)(e / ((long)K * cg));
-    const float inv = rsqrtf(nsq[k]);
-    const float d = dwf[((((long)(o / cg)) * K + k) * cg + c) * cg + (o % cg)];  // dwf[group][tap][c][n]
-    dv[e] += g[k] * inv * (d - v[e] * dot[k] * inv * inv);
-    if (e < K) dg[e] += dot[e] * rsqrtf(nsq[e]);
+// weight-norm backward: dv[o][c][k] += g[k] / ||v_k|| (d - v dot[k] / ||v_k||^2), dg[k] += dot[k] / ||v_k||, with
+// d = dwf[group][k][c][n].  One workgroup per (group, c): the dwf rows (contiguous over n) go through LDS and leave
+// as rows contiguous over k.
+__global__ __launch_bounds__(256) void posconv_wbwd_kernel(const float* __restrict__ dwf, const float* __restrict__ g,
+                                                           const float* __restrict__ v, const float* __restrict__ nsq,
+                                                           const float* __restrict__ dot, float* __restrict__ dg,
+                                                           float* __restrict__ dv, int H, int cg, int K) {
+  extern __shared__ float slab[];  // [K][cg + 1]
+  const int CP = cg + 1;
+  const int grp = blockIdx.x / cg, c = blockIdx.x % cg;
+  for (int j = threadIdx.x; j < K * cg; j += 256) {
+    const int k = j / cg, nn = j % cg;
+    slab[k * CP + nn] = dwf[(((long)grp * K + k) * cg + c) * cg + nn];
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < cg * K; j += 256) {
+    const int nn = j / K, k = j % K;
+    const long e = (((long)grp * cg + nn) * cg + c) * K + k;
+    const float inv = rsqrtf(nsq[k]);
+    dv[e] += g[k] * inv * (slab[k * CP + nn] - v[e] * dot[k] * inv * inv);
+  }
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < K; k += 256) dg[k] += dot[k] * rsqrtf(nsq[k]);
 }
 
 __global__ void posconv_pack_kernel(const bf16* __restrict__ h, bf16* __restrict__ pg, int B, int F, int H, int G,
@@ -613,7 +643,8 @@ int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, 
   SSAK_LAUNCH_CHECK();
   posconv_colnorm_finalize_kernel<<<ssak_cdiv(K, 64), 1024, 0, st>>>(partial, H, K, norms);
   SSAK_LAUNCH_CHECK();
-  posconv_materialize_kernel<<<min(2048, ssak_cdiv((long)H * cg * K, 256)), 256, 0, st>>>(g, v, norms, w_fwd, w_bwd, H, cg, K);
+  SSAK_REQUIRE((size_t)cg * (K + 1) * sizeof(float) <= 64 * 1024, "posconv: (H/G) x K slab does not fit in LDS");
+  posconv_materialize_kernel<<<2 * H, 256, (size_t)cg * (K + 1) * sizeof(float), st>>>(g, v, norms, w_fwd, w_bwd, H, cg, K);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -628,7 +659,8 @@ int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const 
   SSAK_LAUNCH_CHECK();
   posconv_colnorm_finalize_kernel<<<ssak_cdiv(K, 64), 1024, 0, st>>>(partial, H, K, dot);
   SSAK_LAUNCH_CHECK();
-  posconv_wbwd_kernel<<<min(2048, ssak_cdiv((long)H * cg * K, 256)), 256, 0, st>>>(dw, g, v, norms, dot, dg, dv, H, cg, K);
+  SSAK_REQUIRE((size_t)K * (cg + 1) * sizeof(float) <= 64 * 1024, "posconv: K x (H/G) slab does not fit in LDS");
+  posconv_wbwd_kernel<<<H, 256, (size_t)K * (cg + 1) * sizeof(float), st>>>(dw, g, v, norms, dot, dg, dv, H, cg, K);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
