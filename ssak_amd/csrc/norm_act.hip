@@ -7,6 +7,7 @@
 // One wave owns one row; 16-byte vector accesses; statistics in fp32; two-pass variance as torch does.
 // Dropout masks are recomputed from (seed, stream, element index) in the backward kernels.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -31,6 +32,31 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     w[i] = __builtin_bit_cast(uint32_t, t);
   }
   return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int VEC>
+__device__ __forceinline__ void unpackv(const uint4& q, float* f) {
+  unpack8(q, f);
+}
+template <int VEC>
+__device__ __forceinline__ void unpackv(const uint2& q, float* f) {
+  const uint32_t w[2] = {q.x, q.y};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <int VEC>
+__device__ __forceinline__ typename std::conditional<VEC == 8, uint4, uint2>::type packv(const float* f);
+template <>
+__device__ __forceinline__ uint4 packv<8>(const float* f) {
+  return pack8(f);
+}
+template <>
+__device__ __forceinline__ uint2 packv<4>(const float* f) {
+  const bf16x2 t0 = {(bf16)f[0], (bf16)f[1]}, t1 = {(bf16)f[2], (bf16)f[3]};
+  return make_uint2(__builtin_bit_cast(uint32_t, t0), __builtin_bit_cast(uint32_t, t1));
 }
 
 struct LnFwdParams {
@@ -159,29 +185,33 @@ struct LnBwdParams {
   float mid_scale;
 };
 
-template <int NCH>
+// VEC = elements per lane chunk: 8 (16-byte accesses) in general; 4 (8-byte accesses) when that divides the row evenly over
+// the 64 lanes -- C = 768 is 96 chunks of 8, i.e. 64 + 32 lanes (a quarter of the lane slots and of the registers idle), but
+// exactly 3 chunks of 4 per lane.
+template <int NCH, int VEC>
 __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p) {
-  __shared__ float red[3][ROW_THREADS / 64][NCH * 64 * 8 / 64][64];  // [dgamma|dbeta|dy sum][wave][slot][lane]
+  using VecT = typename std::conditional<VEC == 8, uint4, uint2>::type;
+  __shared__ float red[3][ROW_THREADS / 64][NCH * VEC][64];  // [dgamma|dbeta|dy sum][wave][slot][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nch = p.C >> 3;
+  const int nch = p.C / VEC;
   const int wid = blockIdx.x * (ROW_THREADS / 64) + wave;
-  float ag[NCH][8], ab[NCH][8], gm[NCH][8], ay[NCH][8], bt[NCH][8];
+  float ag[NCH][VEC], ab[NCH][VEC], gm[NCH][VEC], ay[NCH][VEC], bt[NCH][VEC];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < VEC; ++k) {
       ag[i][k] = 0.f;
       ab[i][k] = 0.f;
       ay[i][k] = 0.f;
-      gm[i][k] = (ch < nch) ? p.gamma[ch * 8 + k] : 0.f;
-      bt[i][k] = (ch < nch && p.beta) ? p.beta[ch * 8 + k] : 0.f;
+      gm[i][k] = (ch < nch) ? p.gamma[ch * VEC + k] : 0.f;
+      bt[i][k] = (ch < nch && p.beta) ? p.beta[ch * VEC + k] : 0.f;
     }
   }
   // raw operands of the row a wave works on are fetched one row ahead: a wave owns ~8 rows and every row is a dependent
   // chain load -> two wave reductions -> store, so without the prefetch the kernel ran at HBM latency, not bandwidth
   const int rstep = gridDim.x * (ROW_THREADS / 64);
-  uint4 ra[NCH], rb[NCH], rx[NCH];
+  VecT ra[NCH], rb[NCH], rx[NCH];
   float mean_n = 0.f, rstd_n = 0.f;
   auto fetch = [&](int row) {
     mean_n = p.mean[row];
@@ -190,20 +220,20 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
     for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
-        const size_t o = (size_t)row * p.C + ch * 8;
-        __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
-        ra[i] = *reinterpret_cast<const uint4*>(p.g1 + o);
-        if (p.g2) rb[i] = *reinterpret_cast<const uint4*>(p.g2 + o);
-        rx[i] = *reinterpret_cast<const uint4*>(p.r + o);
+        const size_t o = (size_t)row * p.C + ch * VEC;
+        __builtin_assume((o & (VEC - 1)) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
+        ra[i] = *reinterpret_cast<const VecT*>(p.g1 + o);
+        if (p.g2) rb[i] = *reinterpret_cast<const VecT*>(p.g2 + o);
+        rx[i] = *reinterpret_cast<const VecT*>(p.r + o);
       }
     }
   };
   if (wid < p.M) fetch(wid);
   for (int row = wid; row < p.M; row += rstep) {
     const float mean = mean_n, rstd = rstd_n;
-    float dyv[NCH][8], xh[NCH][8];
+    float dyv[NCH][VEC], xh[NCH][VEC];
     float s1 = 0.f, s2 = 0.f;
-    uint4 ca[NCH], cb[NCH], cx[NCH];
+    VecT ca[NCH], cb[NCH], cx[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       ca[i] = ra[i];
@@ -215,24 +245,24 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
     for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < VEC; ++k) {
         dyv[i][k] = 0.f;
         xh[i][k] = 0.f;
       }
       if (ch < nch) {
-        const size_t o = (size_t)row * p.C + ch * 8;
-        __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
-        float a[8], x[8];
-        unpack8(ca[i], a);
+        const size_t o = (size_t)row * p.C + ch * VEC;
+        __builtin_assume((o & (VEC - 1)) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
+        float a[VEC], x[VEC];
+        unpackv<VEC>(ca[i], a);
         if (p.g2) {
-          float b2[8];
-          unpack8(cb[i], b2);
+          float b2[VEC];
+          unpackv<VEC>(cb[i], b2);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) a[k] += b2[k];
+          for (int k = 0; k < VEC; ++k) a[k] += b2[k];
         }
-        unpack8(cx[i], x);
+        unpackv<VEC>(cx[i], x);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < VEC; ++k) {
           if (p.post_thresh) a[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? a[k] * p.post_scale : 0.f;
           xh[i][k] = (x[k] - mean) * rstd;
           if (p.beta) a[k] *= gelu_grad_f(fmaf(xh[i][k], gm[i][k], bt[i][k]));
@@ -250,29 +280,29 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
     for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
-        const size_t o = (size_t)row * p.C + ch * 8;
-        __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
-        float d[8];
+        const size_t o = (size_t)row * p.C + ch * VEC;
+        __builtin_assume((o & (VEC - 1)) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
+        float d[VEC];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = rstd * (dyv[i][k] - s1 - xh[i][k] * s2);
+        for (int k = 0; k < VEC; ++k) d[k] = rstd * (dyv[i][k] - s1 - xh[i][k] * s2);
         if (p.g_res) {
-          float e[8];
-          unpack8(*reinterpret_cast<const uint4*>(p.g_res + o), e);
+          float e[VEC];
+          unpackv<VEC>(*reinterpret_cast<const VecT*>(p.g_res + o), e);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) d[k] += e[k];
+          for (int k = 0; k < VEC; ++k) d[k] += e[k];
         }
         if (p.mid_thresh) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) d[k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? d[k] * p.mid_scale : 0.f;
+          for (int k = 0; k < VEC; ++k) d[k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? d[k] * p.mid_scale : 0.f;
         }
-        *reinterpret_cast<uint4*>(p.dr + o) = pack8(d);
+        *reinterpret_cast<VecT*>(p.dr + o) = packv<VEC>(d);
         if (p.dy) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
+          for (int k = 0; k < VEC; ++k) {
             d[k] = (!p.pre_thresh || keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh)) ? d[k] * p.pre_scale : 0.f;
             ay[i][k] += d[k];  // fp32 values, before the bf16 rounding of the store
           }
-          *reinterpret_cast<uint4*>(p.dy + o) = pack8(d);
+          *reinterpret_cast<VecT*>(p.dy + o) = packv<VEC>(d);
         }
       }
     }
@@ -281,16 +311,16 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      red[0][wave][i * 8 + k][lane] = ag[i][k];
-      red[1][wave][i * 8 + k][lane] = ab[i][k];
-      red[2][wave][i * 8 + k][lane] = ay[i][k];
+    for (int k = 0; k < VEC; ++k) {
+      red[0][wave][i * VEC + k][lane] = ag[i][k];
+      red[1][wave][i * VEC + k][lane] = ab[i][k];
+      red[2][wave][i * VEC + k][lane] = ay[i][k];
     }
   __syncthreads();
-  for (int e = threadIdx.x; e < NCH * 8 * 64; e += ROW_THREADS) {
+  for (int e = threadIdx.x; e < NCH * VEC * 64; e += ROW_THREADS) {
     const int slot = e >> 6, ln = e & 63;
-    const int i = slot >> 3, k = slot & 7;
-    const int col = (ln + 64 * i) * 8 + k;
+    const int i = slot / VEC, k = slot % VEC;
+    const int col = (ln + 64 * i) * VEC + k;
     if (col < p.C) {
       float sg = 0.f, sb = 0.f, sy = 0.f;
 #pragma unroll
@@ -633,12 +663,14 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   p.rows_per_wave = 0;
   const int grid = std::min(LN_BWD_BLOCKS, ssak_cdiv(M, ROW_THREADS / 64));
   const int nch = ssak_cdiv(C / 8, 64);
-  if (nch == 1)
-    ln_bwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+  if (C % 256 == 0 && C / 256 == 3 && (C / 8) % 64 != 0)  // (768: three chunks of 4 per lane, every lane busy)
+    ln_bwd_kernel<3, 4><<<grid, ROW_THREADS, 0, st>>>(p);
+  else if (nch == 1)
+    ln_bwd_kernel<1, 8><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
-    ln_bwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_bwd_kernel<2, 8><<<grid, ROW_THREADS, 0, st>>>(p);
   else
-    ln_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_bwd_kernel<3, 8><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
   if (g_reduce_sink && g_reduce_sink->n + 3 <= ReduceSink::CAP) {  // second stage queued: one launch for many (kernels.h)
     g_reduce_sink->push(partial, 3L * C, grid, C, dgamma);
