@@ -170,20 +170,26 @@ int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs /*host*/, int n, const vo
  * alone on the chip the static order is a few percent faster (no ticket round trip at the start of a launch). */
 int ssak_gemm_tile_order(int dynamic);
 
-/* Per-launch GEMM timing for the roofline report (measurement aid, not on the reference's path): while
- * enabled, GEMM launches are bracketed by HIP events on their own stream; ssak_prof_collect waits for them and
- * returns, per kernel instantiation (named as rocprofv3 prints it), launches / summed ms / algorithmic FLOPs.
- * ssak_prof_enable(0) = off, (1) = every launch, (2 + i) = only the instantiation at index i of ssak_prof_collect's
- * table: an event pair keeps consecutive kernels from overlapping head to tail, and bracketing all ~100 GEMMs of a train
- * step costs 3 % of it, so a benchmark times only the instantiation it reports on inside its timed region. */
+/* Per-launch timing for the roofline report (measurement aid, not on the reference's path): while enabled, launches are
+ * bracketed by HIP events on their own stream; ssak_prof_collect waits for them and returns one entry per slot: the GEMM
+ * instantiations (slots 0..32, named as rocprofv3 prints them) and the other kernel classes of the train step (attention,
+ * LayerNorm, conv0, AdamW, CTC, ...), each with launches / summed ms / ALGORITHMIC work -- flops for SSAK_BOUND_MFMA slots,
+ * bytes for SSAK_BOUND_HBM / SSAK_BOUND_LATENCY slots.  ssak_prof_enable(0) = off, (1) = every launch, (2 + i) = only slot i:
+ * an event pair keeps consecutive kernels from overlapping head to tail, and bracketing all launches of a train step costs
+ * a few per cent of it, so a benchmark surveys all slots in warm-up steps and times only the slot it reports on inside its
+ * timed region. */
+#define SSAK_BOUND_MFMA 0
+#define SSAK_BOUND_HBM 1
+#define SSAK_BOUND_LATENCY 2
 typedef struct {
-  char name[80];
+  char name[112];
   long launches;
   double total_ms;
-  double total_flops;
+  double total_flops; /* flops, or bytes for the HBM / latency-bound slots */
+  int bound;
 } ssak_prof_entry;
 int ssak_prof_enable(int on);
-int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 33; returns the number of entries (33) */
+int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 64; returns the number of entries */
 
 /* ---- a7 (part): fused self-attention, head_dim 64 --------------------------------------------
  * Replaces Wav2Vec2Attention's softmax(QK^T d^-0.5 + key mask) -> dropout -> .V and its autograd
@@ -267,6 +273,20 @@ int ssak_w2v2_forward(ssak_w2v2* h, const float* input_values, const int32_t* le
  * (the reference's nn.DataParallel reduces after backward, docker/transformers_modified/trainer.py:1345-1346). */
 typedef void (*ssak_grad_ready_fn)(long offset, long count, void* user);
 int ssak_w2v2_set_grad_ready_callback(ssak_w2v2* h, ssak_grad_ready_fn fn, void* user);
+/* Optimizer on a side stream (north_star: "all-reduce ... overlapped with the optimizer on a side HIP stream"; the reference's
+ * HF Trainer runs optimizer.step() in line, docker/transformers_modified/trainer.py:1827-1855): `params_ready` is a hipEvent_t the
+ * caller records on its optimizer stream after the update of params / shadow (and ssak_w2v2_sync_weights(full = 0)) has been
+ * enqueued there.  Every forward then waits for it on ITS stream at the first kernel that reads a trainable parameter -- with
+ * a frozen feature encoder that is the feature projection, so the whole conv stack of step n+1 runs under the exchange tail and
+ * the AdamW sweep of step n.  stall_begin / stall_end (hipEvent_t or NULL) are recorded around that wait: their distance is the
+ * exposed part of the tail.  NULL params_ready removes the wait. */
+int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begin, void* stall_end);
+/* The gradient ranges ssak_w2v2_backward announces, in announcement order, from the configuration alone (host arithmetic, no
+ * device): head matrix, one range per encoder layer from the last to the first (a layer's q|k|v|out|ffn matrices are
+ * contiguous), the leading small matrices, then the vector region (biases, LayerNorm affines) [+ the feature encoder when it
+ * is trained].  They are disjoint, start at multiples of 8 elements and cover [0, num_trainable): the buckets of the
+ * data-parallel exchange.  Returns the number of ranges (<= cap written), negative on a bad configuration. */
+int ssak_w2v2_grad_ranges(const ssak_w2v2_config* cfg /*host*/, long* offsets /*host*/, long* counts /*host*/, int cap);
 /* dlogits [B,F,V] fp32 (e.g. from ssak_ctc_loss_fwd_bwd); overwrites grads[0, num_trainable). */
 int ssak_w2v2_backward(ssak_w2v2* h, const float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
 /* The same model stopped at the encoder's last hidden state -- `self.modules.wav2vec2(wavs)` of the SpeechBrain recipe

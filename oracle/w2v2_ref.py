@@ -291,7 +291,8 @@ def encoder_layer(p, cfg: W2V2Config, l: int, h: torch.Tensor, key_mask, train: 
 
 def forward(p: Dict[str, torch.Tensor], cfg: W2V2Config, input_values: torch.Tensor,
             lengths=None, labels: Optional[torch.Tensor] = None, train: bool = False,
-            mask_time_indices: Optional[torch.Tensor] = None, layer_keep=None, stages: Optional[dict] = None):
+            mask_time_indices: Optional[torch.Tensor] = None, layer_keep=None, stages: Optional[dict] = None,
+            gradient_checkpointing: bool = False):
     """``Wav2Vec2ForCTC.forward`` (:1667-1742) through ``Wav2Vec2Model.forward`` (:1319-1380) and
     ``Wav2Vec2Encoder.forward`` (:667-726).
 
@@ -328,7 +329,14 @@ def forward(p: Dict[str, torch.Tensor], cfg: W2V2Config, input_values: torch.Ten
     for l in range(cfg.num_hidden_layers):
         if layer_keep is not None and not layer_keep[l]:
             continue
-        h = encoder_layer(p, cfg, l, h, key_mask, train)
+        if gradient_checkpointing and torch.is_grad_enabled():
+            # model.gradient_checkpointing_enable() of the train script (wav2vec_train.py:329): each encoder layer's
+            # activations are recomputed in the backward (modeling_wav2vec2.py: GradientCheckpointingLayer)
+            from torch.utils.checkpoint import checkpoint
+            h = checkpoint(lambda t, l=l: encoder_layer(p, cfg, l, t, key_mask, train), h, use_reentrant=False,
+                           preserve_rng_state=train)
+        else:
+            h = encoder_layer(p, cfg, l, h, key_mask, train)
         if stages is not None:
             stages[f"layer{l}"] = h
     if cfg.do_stable_layer_norm:

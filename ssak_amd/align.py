@@ -30,15 +30,12 @@ class Segment:
     end: int
     score: float
 
-    def __repr__(self):
-        return f"{self.label}\t({self.score:4.2f}): [{self.start:5d}, {self.end:5d})"
+    def __repr__(self):  # same text as the reference prints (:147)
+        return "%s\t(%4.2f): [%5d, %5d)" % (self.label, self.score, self.start, self.end)
 
     @property
     def length(self):
         return self.end - self.start
-
-
-_last = {}  # trellis data_ptr -> path of the launch that produced it (get_trellis and backtrack are one kernel)
 
 
 def forced_align(emission: torch.Tensor, tokens: Sequence[int], blank_id: int = 0, first_as_garbage: bool = False):
@@ -81,49 +78,64 @@ def forced_align(emission: torch.Tensor, tokens: Sequence[int], blank_id: int = 
 
 
 def get_trellis(emission, tokens, blank_id=0, first_as_garbage=False):
+    """The Viterbi trellis [F+1, L+1] (:27-70).  The kernel walks the best path in the same launch; it travels WITH the
+    returned tensor (attribute ``ssak_alignment``: the token sequence, the blank id and the path) so that :func:`backtrack` on
+    this very object needs no second launch.  Tensors derived from it (slices, copies) do not carry the attribute."""
     trellis, path = forced_align(emission, tokens, blank_id, first_as_garbage)
-    _last.clear()
-    _last[(trellis.data_ptr(), tuple(tokens), int(blank_id))] = path
+    trellis.ssak_alignment = (tuple(int(t) for t in tokens), int(blank_id), path)
     return trellis
 
 
 def backtrack(trellis, emission, tokens, blank_id=0):
-    key = (trellis.data_ptr(), tuple(tokens), int(blank_id))
-    if key in _last:
-        path = _last[key]
-    else:  # a trellis that did not come from get_trellis: one more launch gives the same walk
+    """Best path as a list of Point (:79-123); RuntimeError when the transcript does not fit the frames."""
+    carried = getattr(trellis, "ssak_alignment", None)
+    if carried is not None and carried[0] == tuple(int(t) for t in tokens) and carried[1] == int(blank_id):
+        path = carried[2]
+    else:  # a trellis that did not come from get_trellis (or other tokens): one more launch gives the walk
         _, path = forced_align(emission, tokens, blank_id, first_as_garbage=False)
     if path is None:
         raise RuntimeError("Failed to align (not enough tokens for the duration?)")
     return path
 
 
+def _run_starts(values: np.ndarray) -> np.ndarray:
+    """Indices where a new run of equal values begins."""
+    if len(values) == 0:
+        return np.zeros(0, dtype=np.int64)
+    return np.flatnonzero(np.concatenate(([True], values[1:] != values[:-1])))
+
+
 def merge_repeats(transcript, path: List[Point]) -> List[Segment]:
-    i1, i2 = 0, 0
-    segments = []
-    while i1 < len(path):
-        while i2 < len(path) and path[i1].token_index == path[i2].token_index:
-            i2 += 1
-        score = sum(path[k].score for k in range(i1, i2)) / (i2 - i1)
-        segments.append(Segment(transcript[path[i1].token_index], path[i1].time_index, path[i2 - 1].time_index + 1, score))
-        i1 = i2
-    return segments
+    """Consecutive path points on the same transcript position -> one Segment per position: frames [first, last + 1), score =
+    mean of the points' scores (:140-156).  Run-length grouping over the path arrays."""
+    if not path:
+        return []
+    pos = np.fromiter((p.token_index for p in path), dtype=np.int64, count=len(path))
+    frame = np.fromiter((p.time_index for p in path), dtype=np.int64, count=len(path))
+    score = np.fromiter((p.score for p in path), dtype=np.float64, count=len(path))
+    first = _run_starts(pos)
+    last = np.concatenate((first[1:], [len(path)])) - 1
+    mean = np.add.reduceat(score, first) / (last - first + 1)
+    return [Segment(transcript[int(pos[a])], int(frame[a]), int(frame[b]) + 1, float(m)) for a, b, m in zip(first, last, mean)]
+
+
+def _pooled_score(segments: Sequence[Segment]) -> float:
+    """Duration-weighted mean score of a group of segments."""
+    dur = np.array([g.length for g in segments], dtype=np.float64)
+    return float(np.dot([g.score for g in segments], dur) / dur.sum())
 
 
 def merge_words(segments: List[Segment], separator: str = " ") -> List[Segment]:
+    """Character segments -> word segments: maximal runs without a separator label (:158-172)."""
+    is_sep = np.array([g.label == separator for g in segments], dtype=bool)
+    kept = np.flatnonzero(~is_sep)
+    if len(kept) == 0:
+        return []
+    breaks = np.flatnonzero(np.diff(kept) > 1) + 1  # a gap in the kept indices = at least one separator in between
     words = []
-    i1, i2 = 0, 0
-    while i1 < len(segments):
-        if i2 >= len(segments) or segments[i2].label == separator:
-            if i1 != i2:
-                segs = segments[i1:i2]
-                word = "".join(seg.label for seg in segs)
-                score = sum(seg.score * seg.length for seg in segs) / sum(seg.length for seg in segs)
-                words.append(Segment(word, segments[i1].start, segments[i2 - 1].end, score))
-            i1 = i2 + 1
-            i2 = i1
-        else:
-            i2 += 1
+    for run in np.split(kept, breaks):
+        group = segments[int(run[0]):int(run[-1]) + 1]
+        words.append(Segment("".join(g.label for g in group), group[0].start, group[-1].end, _pooled_score(group)))
     return words
 
 
@@ -192,15 +204,15 @@ def compute_alignment(audio, transcript, model, add_before_after=None, first_as_
     if transcript_words is None:
         word_segments = merge_words(char_segments)
     else:
+        # the caller's own word list: word k owns the character segments [offset_k, offset_k + len(word_k)), the single
+        # separator between words is skipped; timing and score come from its letters when it has any
+        # (spaces / punctuation only count for a word made of nothing else)
         word_segments = []
-        i2 = -1
+        offset = 0
         for word in transcript_words:
-            i1 = i2 + 1
-            i2 = i1 + len(word)
-            segs1 = char_segments[i1:i2]
-            assert "".join(seg.label for seg in segs1) == word
-            segs2 = [s for s in segs1 if s.label not in " " + _PUNCTUATION]
-            segs = segs2 if len(segs2) != 0 else segs1
-            score = sum(seg.score * seg.length for seg in segs) / sum(seg.length for seg in segs)
-            word_segments.append(Segment(word, segs[0].start, segs[-1].end, score))
+            chars = char_segments[offset:offset + len(word)]
+            offset += len(word) + 1
+            assert "".join(c.label for c in chars) == word
+            letters = [c for c in chars if c.label not in " " + _PUNCTUATION] or chars
+            word_segments.append(Segment(word, letters[0].start, letters[-1].end, _pooled_score(letters)))
     return labels, emission, trellis, char_segments, word_segments

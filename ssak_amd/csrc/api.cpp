@@ -2,7 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#include "../../include/ssak_hip.h"
+#include <vector>
+
+#include "kernels.h"
 
 static thread_local char g_err[512] = "";
 
@@ -15,3 +17,105 @@ void ssak_set_error(const char* fmt, ...) {
 
 extern "C" int ssak_version(void) { return 100; }
 extern "C" const char* ssak_last_error(void) { return g_err; }
+
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events around launches, on the launch's own stream ----
+// Slots 0..32 are the GEMM instantiations (named as rocprofv3 prints them); the slots after them are the other kernel
+// classes of the train step (kernels.h: PROF_*).  An event pair keeps consecutive kernels from overlapping head to tail, so
+// bracketing everything costs a few per cent of a step: benchmarks survey all slots in warm-up steps and bracket one slot
+// inside their timed region (ssak_prof_enable(2 + slot)).
+namespace {
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int slot;
+  double work;
+};
+int g_prof_mode = 0;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t prof_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+const char* kLayoutNames[8] = {"128, 128, 2, 2, false, false", "128, 128, 2, 2, false, true", "128, 128, 2, 2, true, false",
+                               "128, 128, 2, 2, true, true",   "128, 64, 2, 2, false, false",  "128, 64, 2, 2, false, true",
+                               "128, 64, 2, 2, true, false",   "128, 64, 2, 2, true, true"};
+struct ClassInfo {
+  const char* name;
+  int bound;  // SSAK_BOUND_*
+};
+const ClassInfo kClasses[PROF_SLOTS - PROF_GEMM_SLOTS] = {
+    {"attn_fwd_kernel (fused attention forward)", SSAK_BOUND_MFMA},
+    {"attn_bwd_dq_kernel + attn_bwd_dkv_kernel (fused attention backward)", SSAK_BOUND_MFMA},
+    {"ln_fwd_kernel (residual + dropout + LayerNorm)", SSAK_BOUND_HBM},
+    {"ln_bwd_kernel (LayerNorm backward + column partials)", SSAK_BOUND_HBM},
+    {"conv0_moments + conv0_channel_stats + conv0_kernel (conv0 + GroupNorm + GELU)", SSAK_BOUND_HBM},
+    {"adamw_kernel (clip + AdamW + bf16 shadow)", SSAK_BOUND_HBM},
+    {"sumsq_kernel (gradient norm)", SSAK_BOUND_HBM},
+    {"ctc_lsm + ctc_lat + ctc_grad (CTC loss + gradient)", SSAK_BOUND_LATENCY},
+    {"norm_stats + norm_apply (waveform normalise)", SSAK_BOUND_HBM},
+    {"row / element-wise helpers (pack, SpecAugment, casts, column sums, GELU', adds, reductions)", SSAK_BOUND_HBM},
+    {"positional-conv weight-norm prepare / backward", SSAK_BOUND_HBM},
+    {"softmax fwd / bwd (unfused attention fallback)", SSAK_BOUND_HBM},
+};
+}  // namespace
+
+bool ssak_prof_wanted(int slot) { return g_prof_mode == 1 || g_prof_mode == slot + 2; }
+
+ProfScope::ProfScope(int slot, double work, hipStream_t st) : st_(st), slot_(slot), work_(work), on_(ssak_prof_wanted(slot)) {
+  if (on_) {
+    e0_ = prof_event();
+    (void)hipEventRecord(e0_, st_);
+  }
+}
+ProfScope::~ProfScope() {
+  if (on_) {
+    hipEvent_t e1 = prof_event();
+    (void)hipEventRecord(e1, st_);
+    g_prof.push_back(ProfRec{e0_, e1, slot_, work_});
+  }
+}
+
+extern "C" int ssak_prof_enable(int on) {
+  g_prof_mode = on < 0 ? 0 : on;
+  return SSAK_OK;
+}
+
+extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
+  SSAK_REQUIRE(out && cap >= PROF_SLOTS, "prof_collect: need room for %d entries", PROF_SLOTS);
+  for (int i = 0; i < PROF_SLOTS; ++i) {
+    out[i].bound = SSAK_BOUND_MFMA;
+    if (i < 16)
+      snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
+    else if (i < 20)
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
+    else if (i < 32)
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<%d, %s, %s, false>", (i - 20) / 4 + 2, (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
+    else if (i == 32)
+      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<4, true, true, true>");  // grouped weight gradients
+    else {
+      snprintf(out[i].name, sizeof(out[i].name), "%s", kClasses[i - PROF_GEMM_SLOTS].name);
+      out[i].bound = kClasses[i - PROF_GEMM_SLOTS].bound;
+    }
+    out[i].launches = 0;
+    out[i].total_ms = 0.0;
+    out[i].total_flops = 0.0;
+  }
+  for (ProfRec& r : g_prof) {
+    SSAK_HIP(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    SSAK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    out[r.slot].launches += 1;
+    out[r.slot].total_ms += ms;
+    out[r.slot].total_flops += r.work;
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
+  }
+  g_prof.clear();
+  return PROF_SLOTS;
+}

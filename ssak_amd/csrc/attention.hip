@@ -637,6 +637,7 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens
   SSAK_REQUIRE(k_attention_supported(H, nh), "attention: fused kernels are built for head_dim 64 (got %d)", nh ? H / nh : 0);
   SSAK_REQUIRE((long)F * 3 * H * 2 < 2000000000L, "attention: one utterance of q|k|v must span < 2 GB");
   const AttnParams p = make_params(qkv, ctx, lse, klens, nullptr, nullptr, nullptr, B, F, nh, H, drop);
+  ProfScope prof_scope(PROF_ATTN_FWD, 4.0 * B * nh * (double)F * F * HD, st);  // S = Q K^T and O = P V
   attn_fwd_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -646,6 +647,7 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
                     bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, hipStream_t st) {
   SSAK_REQUIRE(k_attention_supported(H, nh), "attention: fused kernels are built for head_dim 64 (got %d)", nh ? H / nh : 0);
   const AttnParams p = make_params(qkv, const_cast<bf16*>(ctx), const_cast<float*>(lse), klens, dctx, delta, dqkv, B, F, nh, H, drop);
+  ProfScope prof_scope(PROF_ATTN_BWD, 8.0 * B * nh * (double)F * F * HD, st);  // dV, dP, dQ, dK (the recomputed S is not algorithmic work)
   attn_bwd_dq_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
   SSAK_LAUNCH_CHECK();
   constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 3 * KT * 4;

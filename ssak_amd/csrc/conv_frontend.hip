@@ -599,6 +599,7 @@ int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const fl
   SSAK_REQUIRE(T0 == (T - KS0) / ST0 + 1 && T0 > 0, "conv0: T0 mismatch");
   // stats layout: [B][2C] ordered sums | [B][nblk][2C] per-workgroup partials   (k_conv0_stats_doubles(B, T0, C) doubles)
   const int nblk = ssak_cdiv(T0, FR_STATS);
+  ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * 2.0), st);  // waveform in, bf16 channels-last out
   double* sums = stats;
   double* partial = stats + (size_t)B * 2 * C;
   static const bool direct_stats = getenv("SSAK_CONV0_DIRECT_STATS") != nullptr;  // development: the convolution-pass statistics
@@ -622,6 +623,7 @@ int k_conv0_bias(const float* x, const float* w, const float* bias, bf16* out, i
                  int stride, hipStream_t st) {
   SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
+  ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * 2.0), st);
   conv0_bias_kernel<<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, bias, out, T, T0, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -639,6 +641,7 @@ int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, 
   const int cg = H / G;
   // norms layout: [K] ||v||^2 | [K] dot scratch | [H][K] per-workgroup partials
   float* partial = norms + 2 * K;
+  ProfScope prof_scope(PROF_POSCONV_W, (double)H * cg * K * 8.0, st);  // v read (fp32), two bf16 layouts written
   posconv_colnorm_kernel<<<H, ((K + 63) / 64) * 64, 0, st>>>(v, nullptr, H / cg, K, cg, partial);  // H = groups * cg workgroups
   SSAK_LAUNCH_CHECK();
   posconv_colnorm_finalize_kernel<<<ssak_cdiv(K, 64), 1024, 0, st>>>(partial, H, K, norms);
@@ -655,6 +658,7 @@ int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const 
   const int cg = H / G;
   float* dot = const_cast<float*>(norms) + K;
   float* partial = const_cast<float*>(norms) + 2 * K;
+  ProfScope prof_scope(PROF_POSCONV_W, (double)H * cg * K * 12.0, st);  // dw and v read, dv written (fp32)
   posconv_colnorm_kernel<<<H, ((K + 63) / 64) * 64, 0, st>>>(v, dw, H / cg, K, cg, partial);
   SSAK_LAUNCH_CHECK();
   posconv_colnorm_finalize_kernel<<<ssak_cdiv(K, 64), 1024, 0, st>>>(partial, H, K, dot);
@@ -669,6 +673,7 @@ int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, h
   const int lead = K / 2, RS = F + K;
   const long rows_total = lead + (long)B * RS + K;
   const long n = rows_total * G * (H / G / 8);
+  ProfScope prof_scope(PROF_ROWWISE, (double)B * F * H * 4.0, st);
   posconv_pack_kernel<<<min(4096, ssak_cdiv(n, 256)), 256, 0, st>>>(h, pg, B, F, H, G, lead, RS, rows_total);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;

@@ -11,7 +11,7 @@
 // Latency-bound by construction (F sequential frames); all arithmetic fp32 in the log domain.
 #include <stdlib.h>
 
-#include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -525,6 +525,7 @@ extern "C" int ssak_ctc_loss_fwd_bwd(const float* logits, const int32_t* in_lens
   SSAK_REQUIRE(reduction == SSAK_REDUCTION_SUM || reduction == SSAK_REDUCTION_MEAN, "ctc: bad reduction %d", reduction);
   SSAK_REQUIRE(workspace_bytes >= ssak_ctc_workspace_bytes(B, F, V, Lmax), "ctc: workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope prof_scope(PROF_CTC, (double)B * F * V * 4.0 * (dlogits ? 2 : 1), st);  // logits in, gradient out
   float* ws = (float*)workspace;
   const int Smax = 2 * Lmax + 1;
   static const bool env_mono = getenv("SSAK_CTC_MONOLITHIC") != nullptr;  // development switch

@@ -8,7 +8,7 @@
 // computes the chunk's (count, mean, M2) with a two-pass in-register reduction and writes it out.
 // Pass 2: every workgroup Chan-merges its utterance's chunk statistics (<= a few hundred triples), then
 // re-reads its chunk (Infinity-Cache resident) and writes the normalised samples / zero padding / mask.
-#include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -147,6 +147,7 @@ extern "C" int ssak_wave_normalize(const float* in, const int32_t* lens, int B, 
   const int nch = ssak_cdiv(T, NCHUNK);
   dim3 grid(nch, B);
   hipStream_t st = (hipStream_t)stream;
+  ProfScope prof_scope(PROF_WAVE_NORM, (double)B * T * 8.0, st);  // 1.28 MB / 10 s utterance: read once, write once
   norm_stats_kernel<<<grid, NTHREADS, 0, st>>>(in, lens, T, nch, (float*)workspace);
   SSAK_LAUNCH_CHECK();
   norm_apply_kernel<<<grid, NTHREADS, 0, st>>>(in, lens, T, nch, (const float*)workspace, out, mask);

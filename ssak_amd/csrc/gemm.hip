@@ -626,31 +626,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
   }
 }
 
-// ---- optional per-launch timing (bench.py's roofline leg): HIP events around every GEMM launch ----
-struct ProfRec {
-  hipEvent_t e0, e1;
-  int variant;
-  double flops;
-};
-int g_prof_mode = 0;  // 0 = off, 1 = every GEMM launch, 2 + v = only kernel slot v (the events cost ~3 % of a step when all are on)
-inline bool prof_wanted(int variant) { return g_prof_mode == 1 || g_prof_mode == variant + 2; }
 bool g_no_big_tile = false;  // development switch (SSAK_GEMM_NO_BIG=1): keep the 128x128 kernels
-std::vector<ProfRec> g_prof;
-std::vector<hipEvent_t> g_event_pool;
-hipEvent_t prof_event() {
-  if (!g_event_pool.empty()) {
-    hipEvent_t e = g_event_pool.back();
-    g_event_pool.pop_back();
-    return e;
-  }
-  hipEvent_t e;
-  (void)hipEventCreate(&e);
-  return e;
-}
-const char* kLayoutNames[8] = {"128, 128, 2, 2, false, false", "128, 128, 2, 2, false, true", "128, 128, 2, 2, true, false",
-                               "128, 128, 2, 2, true, true",   "128, 64, 2, 2, false, false",  "128, 64, 2, 2, false, true",
-                               "128, 64, 2, 2, true, false",   "128, 64, 2, 2, true, true"};
-
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
 int launch(const GemmParams& p, bool dma, hipStream_t st) {
   const size_t lds = dma ? 2 * (size_t)(BM + BN) * 128 : 2 * (size_t)(Tile<BM, A_KM>::BYTES + Tile<BN, B_KM>::BYTES);
@@ -663,21 +639,9 @@ int launch(const GemmParams& p, bool dma, hipStream_t st) {
     }
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
-  ProfRec rec;
-  rec.variant = (dma ? 0 : 8) + (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
-  const bool prof = prof_wanted(rec.variant);
-  if (prof) {
-    rec.e0 = prof_event();
-    rec.e1 = prof_event();
-    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
-    (void)hipEventRecord(rec.e0, st);
-  }
+  ProfScope prof_scope((dma ? 0 : 8) + (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0), 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)nblk), NTHREADS, lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
-  if (prof) {
-    (void)hipEventRecord(rec.e1, st);
-    g_prof.push_back(rec);
-  }
   return SSAK_OK;
 }
 
@@ -691,21 +655,9 @@ int launch_big(const GemmParams& p, hipStream_t st) {
     attr_done = true;
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
-  ProfRec rec;
-  rec.variant = 16 + (A_KM ? 2 : 0) + (B_KM ? 1 : 0);
-  const bool prof = prof_wanted(rec.variant);
-  if (prof) {
-    rec.e0 = prof_event();
-    rec.e1 = prof_event();
-    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
-    (void)hipEventRecord(rec.e0, st);
-  }
+  ProfScope prof_scope(16 + (A_KM ? 2 : 0) + (B_KM ? 1 : 0), 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)nblk), 512, lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
-  if (prof) {
-    (void)hipEventRecord(rec.e1, st);
-    g_prof.push_back(rec);
-  }
   return SSAK_OK;
 }
 
@@ -900,20 +852,8 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   if (plan.p8) {
     p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
-    ProfRec rec;
-    rec.variant = 20 + (p8_bm / 64 - 2) * 4 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
-    const bool prof = prof_wanted(rec.variant);
-    if (prof) {
-      rec.e0 = prof_event();
-      rec.e1 = prof_event();
-      rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nz;
-      (void)hipEventRecord(rec.e0, st);
-    }
+    ProfScope prof_scope(20 + (p8_bm / 64 - 2) * 4 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0), 2.0 * p.M * p.N * (double)p.K * p.nz, st);
     rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
-    if (prof) {
-      (void)hipEventRecord(rec.e1, st);
-      g_prof.push_back(rec);
-    }
   } else if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
     p.tiles_m = ssak_cdiv(d->M, 256);
     p.tiles_n = ssak_cdiv(d->N, 128);
@@ -1003,54 +943,8 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
   p.drop_scale = 1.f;
   p.kt_per_split = ssak_cdiv(d0.K, BK);
   hipStream_t st = (hipStream_t)stream;
-  ProfRec rec;
-  rec.variant = 32;
-  const bool prof = prof_wanted(rec.variant);
-  if (prof) {
-    rec.e0 = prof_event();
-    rec.e1 = prof_event();
-    rec.flops = flops;
-    (void)hipEventRecord(rec.e0, st);
-  }
+  ProfScope prof_scope(32, flops, st);
   const int rc = ssak_gemm_p8_launch_grouped(&p, n, A, B, C, Ms, Ns, lda, ldb, ldc, ea, eb, d0.a_kmajor, d0.b_kmajor, st);
-  if (prof) {
-    (void)hipEventRecord(rec.e1, st);
-    g_prof.push_back(rec);
-  }
   return rc;
 }
 
-extern "C" int ssak_prof_enable(int on) {
-  g_prof_mode = on < 0 ? 0 : on;
-
-  return SSAK_OK;
-}
-
-extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
-  SSAK_REQUIRE(out && cap >= 33, "prof_collect: need room for 33 entries");
-  for (int i = 0; i < 33; ++i) {
-    if (i < 16)
-      snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
-    else if (i < 20)
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
-    else if (i < 32)
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<%d, %s, %s, false>", (i - 20) / 4 + 2, (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
-    else
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<4, true, true, true>");  // grouped weight gradients
-    out[i].launches = 0;
-    out[i].total_ms = 0.0;
-    out[i].total_flops = 0.0;
-  }
-  for (ProfRec& r : g_prof) {
-    SSAK_HIP(hipEventSynchronize(r.e1));
-    float ms = 0.f;
-    SSAK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-    out[r.variant].launches += 1;
-    out[r.variant].total_ms += ms;
-    out[r.variant].total_flops += r.flops;
-    g_event_pool.push_back(r.e0);
-    g_event_pool.push_back(r.e1);
-  }
-  g_prof.clear();
-  return 33;
-}

@@ -2,6 +2,31 @@
 #pragma once
 #include "common.h"
 
+// Per-launch timing slots (api.cpp; include/ssak_hip.h: ssak_prof_*).  GEMM instantiations own 0..32.
+enum : int {
+  PROF_GEMM_SLOTS = 33,
+  PROF_ATTN_FWD = 33, PROF_ATTN_BWD, PROF_LN_FWD, PROF_LN_BWD, PROF_CONV0, PROF_ADAMW, PROF_SUMSQ, PROF_CTC, PROF_WAVE_NORM,
+  PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX,
+  PROF_SLOTS
+};
+bool ssak_prof_wanted(int slot);
+// Brackets everything launched on `st` during its lifetime when the slot is being profiled; `work` = the ALGORITHMIC flops
+// (MFMA-bound slots) or bytes (HBM / latency-bound slots) of what it covers.
+class ProfScope {
+ public:
+  ProfScope(int slot, double work, hipStream_t st);
+  ~ProfScope();
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+
+ private:
+  hipStream_t st_;
+  hipEvent_t e0_ = nullptr;
+  int slot_;
+  double work_;
+  bool on_;
+};
+
 struct DropSpec {
   uint64_t seed = 0;
   uint32_t stream = 0;

@@ -639,6 +639,7 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
                 mid.stream, thresh_of(mid.p), scale_of(mid.p), post_gelu ? 1 : 0};
   const int grid = ssak_cdiv(M, ROW_THREADS / 64);
   const int nch = ssak_cdiv(C / 8, 64);
+  ProfScope prof_scope(PROF_LN_FWD, (double)M * C * 2.0 * ((y != nullptr) + (res != nullptr) + (r_out != nullptr) + (out != nullptr)), st);
   if (nch == 1)
     ln_fwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
@@ -663,6 +664,7 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   p.rows_per_wave = 0;
   const int grid = std::min(LN_BWD_BLOCKS, ssak_cdiv(M, ROW_THREADS / 64));
   const int nch = ssak_cdiv(C / 8, 64);
+  ProfScope prof_scope(PROF_LN_BWD, (double)M * C * 2.0 * (2 + (g2 != nullptr) + (g_res != nullptr) + 1 + (dy != nullptr && dy != dr)), st);
   if (C % 256 == 0 && C / 256 == 3 && (C / 8) % 64 != 0)  // (768: three chunks of 4 per lane, every lane busy)
     ln_bwd_kernel<3, 4><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 1)
@@ -690,6 +692,7 @@ int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int ro
                   scale_of(drop.p)};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
   const int nch = ssak_cdiv(ld / 8, 64);
+  ProfScope prof_scope(PROF_SOFTMAX, (double)rows * ld * 2.0 * (2 + (Pd != nullptr)), st);
   if (nch == 1)
     softmax_fwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
@@ -707,6 +710,7 @@ int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, 
                      scale_of(drop.p)};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
   const int nch = ssak_cdiv(ld / 8, 64);
+  ProfScope prof_scope(PROF_SOFTMAX, (double)rows * ld * 2.0 * 3, st);
   if (nch == 1)
     softmax_bwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
@@ -721,6 +725,7 @@ int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, f
              const uint8_t* rowmask, const int32_t* flens, int F) {
   SSAK_REQUIRE(M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ld);
   dim3 grid(ssak_cdiv(N, 64), min(64, ssak_cdiv(M, 32)));
+  ProfScope prof_scope(PROF_ROWWISE, (double)M * N * 2.0, st);
   const bool det = scratch && scratch_floats >= (size_t)grid.y * N;  // deterministic two-stage sum when a scratch is given
   colsum_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, out, det ? scratch : nullptr, rowmask, flens, F > 0 ? F : 1);
   SSAK_LAUNCH_CHECK();
@@ -736,6 +741,9 @@ thread_local ReduceSink* g_reduce_sink = nullptr;
 
 int k_reduce_flush(ReduceSink& sink, hipStream_t st) {
   int done = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < sink.n; ++i) bytes += (double)sink.jobs[i].slots * sink.jobs[i].ncols * 4.0;
+  ProfScope prof_scope(PROF_ROWWISE, bytes, st);
   while (done < sink.n) {
     // jobs that add into the same vector must not share a launch (plain +=): cut the batch at the first repeat
     ReduceTable t;
@@ -760,6 +768,7 @@ int k_reduce_flush(ReduceSink& sink, hipStream_t st) {
 
 int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st) {
   if (n <= 0) return SSAK_OK;
+  ProfScope prof_scope(PROF_ROWWISE, (double)n * 6.0, st);
   cast_f32_bf16_kernel<<<ssak_cdiv(ssak_cdiv(n, 4), 256), 256, 0, st>>>(in, out, n);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -768,6 +777,7 @@ int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st) {
 int k_specaug_fwd(bf16* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
                   hipStream_t st) {
   if (!mask && !flens) return SSAK_OK;
+  ProfScope prof_scope(PROF_ROWWISE, (double)B * F * 1.0, st);  // the mask is read; ~5 % of the rows are rewritten
   specaug_fwd_kernel<<<B * F, 128, 0, st>>>(h, mask, flens, embed, B * F, F, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -786,6 +796,7 @@ int k_specaug_bwd(bf16* dh, const uint8_t* mask, const int32_t* flens, float* de
 
 int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStream_t st) {
   SSAK_REQUIRE((n & 7) == 0, "gelu_grad_mul: n must be a multiple of 8");
+  ProfScope prof_scope(PROF_ROWWISE, (double)n * 6.0, st);
   gelu_grad_mul_kernel<<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(dy, pre, out, n / 8);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -793,6 +804,7 @@ int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStrea
 
 int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st) {
   SSAK_REQUIRE((n & 7) == 0, "add: n must be a multiple of 8");
+  ProfScope prof_scope(PROF_ROWWISE, (double)n * 6.0, st);
   add_bf16_kernel<<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(a, b, out, n / 8);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 int k_sumsq(const float* g, long n, float* out, float* partial, hipStream_t st, bool add) {
   if (n <= 0) return SSAK_OK;
   const int blocks = (int)fmin(1024.0, (double)ssak_cdiv(n, 1024));
+  ProfScope prof_scope(PROF_SUMSQ, (double)n * 4.0, st);
   sumsq_kernel<<<blocks, 256, 0, st>>>(g, n, partial);
   SSAK_LAUNCH_CHECK();
   sumsq_final_kernel<<<1, 1024, 0, st>>>(partial, blocks, out, add ? 1 : 0);
@@ -100,6 +101,8 @@ int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, 
   SSAK_REQUIRE(step >= 1, "adamw: step is 1-based");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  // p, g, m, v read (16 B) + p, m, v written (12 B) + the bf16 shadow (2 B) per parameter (SURVEY.md 8d counted reads only)
+  ProfScope prof_scope(PROF_ADAMW, (double)n * (shadow ? 30.0 : 28.0), st);
   adamw_kernel<<<(int)fmin(4096.0, (double)ssak_cdiv(n, 1024)), 256, 0, st>>>(p, g, m, v, shadow, n, gnorm_sq, max_norm,
                                                                               grad_scale, lr, beta1, beta2, eps, wd, bc1, bc2s);
   SSAK_LAUNCH_CHECK();

@@ -107,6 +107,8 @@ struct ssak_w2v2 {
   std::vector<int> keep;  // LayerDrop decisions of the last forward
   ssak_grad_ready_fn on_ready = nullptr;  // announces finished gradient ranges during backward (bucketed all-reduce)
   void* on_ready_user = nullptr;
+  // optimizer on a side stream: the forward waits for this event before its first read of a trainable parameter
+  hipEvent_t params_ready = nullptr, stall_begin = nullptr, stall_end = nullptr;
 };
 
 namespace {
@@ -632,6 +634,40 @@ extern "C" int ssak_w2v2_set_grad_ready_callback(ssak_w2v2* e, ssak_grad_ready_f
   return SSAK_OK;
 }
 
+extern "C" int ssak_w2v2_grad_ranges(const ssak_w2v2_config* cfg, long* offsets, long* counts, int cap) {
+  SSAK_REQUIRE(cfg && offsets && counts && cap > 0, "w2v2_grad_ranges: null pointer");
+  TRY(check_config(*cfg));
+  ssak_w2v2 e;
+  e.cfg = *cfg;
+  build_param_table(&e);
+  const ssak_w2v2_config& c = e.cfg;
+  const long H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+  const long n_grad = (c.arch == 1 || c.freeze_feature_encoder) ? e.n_train : e.n_total;
+  const long layer_span = (e.lp[0].w2 + H * I) - e.lp[0].wqkv;
+  int n = 0;
+  auto put = [&](long off, long cnt) {
+    if (cnt <= 0) return;
+    if (n < cap) {
+      offsets[n] = off;
+      counts[n] = cnt;
+    }
+    ++n;
+  };
+  put(e.p_lm_w, V * H);
+  for (int l = c.num_layers - 1; l >= 0; --l) put(e.lp[l].wqkv, layer_span);
+  put(0, e.lp[0].wqkv);
+  put(e.p_lm_w + V * H, n_grad - (e.p_lm_w + V * H));
+  return n;
+}
+
+extern "C" int ssak_w2v2_set_param_event(ssak_w2v2* e, void* params_ready, void* stall_begin, void* stall_end) {
+  SSAK_REQUIRE(e, "w2v2_set_param_event: null handle");
+  e->params_ready = (hipEvent_t)params_ready;
+  e->stall_begin = (hipEvent_t)stall_begin;
+  e->stall_end = (hipEvent_t)stall_end;
+  return SSAK_OK;
+}
+
 extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
   SSAK_REQUIRE(e && e->P && e->W, "w2v2_sync_weights: bind the parameter buffers first");
   hipStream_t st = (hipStream_t)stream;
@@ -719,6 +755,18 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
     return d;
   };
   const DropSpec none;
+  // the optimizer may still be updating params / shadow on its own stream (ssak_w2v2_set_param_event)
+  bool waited = false;
+  auto wait_params = [&]() -> int {
+    if (waited || !e->params_ready) return SSAK_OK;
+    waited = true;
+    if (e->stall_begin) SSAK_HIP(hipEventRecord(e->stall_begin, st));
+    SSAK_HIP(hipStreamWaitEvent(st, e->params_ready, 0));
+    if (e->stall_end) SSAK_HIP(hipEventRecord(e->stall_end, st));
+    return SSAK_OK;
+  };
+  // conv1 of the Whisper front end and an unfrozen feature encoder are trainable: wait before anything runs
+  if (whisper || !c.freeze_feature_encoder) TRY(wait_params());
 
   int32_t* flens = nullptr;
   const bool stable = whisper || c.do_stable_layer_norm != 0;
@@ -789,7 +837,8 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
       src = dst;
     }
   }
-  // ---- a4: feature projection  LN -> Linear (+ feat_proj_dropout)
+  // ---- a4: feature projection  LN -> Linear (+ feat_proj_dropout): the first read of trainable parameters
+  TRY(wait_params());
   TRY(k_layernorm_fwd(BF(p.feat), nullptr, P + e->p_fpln_w, P + e->p_fpln_b, nullptr, BF(p.ln0), FP(p.st0),
                       FP(p.st0) + M, M, C, c.layer_norm_eps, none, none, st));
   TRY(Gemm(M, H, C).a(BF(p.ln0), C).b(W + e->p_fp_w, C).c(BF(p.h0), H).with_bias(P + e->p_fp_b)

@@ -21,33 +21,38 @@ import numpy as np
 
 
 # ----------------------------------------------------------------------------- wav.scp / folders
+_QUOTED = re.compile(r"'([^']*)'")
+
+
+def _wavscp_audio_path(entry: str) -> str:
+    """The audio file a wav.scp entry (everything after the recording id) reads: a bare path, or a shell pipe whose reader
+    is sox (input file = first argument) or flac (input file = last argument); a single-quoted path may hold spaces."""
+    quoted = _QUOTED.search(entry)
+    if quoted:
+        return quoted.group(1)
+    words = [w for w in entry.split() if w != "|"]
+    if len(words) == 1:
+        return words[0]
+    reader = os.path.basename(words[0])
+    if reader == "sox":
+        return words[1]
+    if reader == "flac":
+        return words[-1]
+    raise RuntimeError(f"Unknown wav.scp format with {words[0]}")
+
+
 def parse_kaldi_wavscp(path: str) -> Dict[str, str]:
-    """wav.scp -> {recording id: audio path} (semantics of ssak/utils/kaldi.py:8-37)."""
-    wav: Dict[str, str] = {}
+    """wav.scp -> {recording id: audio path}, environment variables expanded (semantics of ssak/utils/kaldi.py:8-37; pinned by
+    the reference's own test folders, tests/golden/host_strings.json)."""
+    table: Dict[str, str] = {}
     with open(path) as f:
-        for line in f:
-            if not line.strip():
+        for raw in f:
+            rec_id, _, entry = raw.strip().partition(" ")
+            if not rec_id:
                 continue
-            fields = [x for x in line.strip().split() if x != "|"]
-            wid = fields[0]
-            if "'" in line:
-                i1 = line.find("'")
-                i2 = line.find("'", i1 + 1)
-                p = line[i1 + 1:i2]
-            elif len(fields) > 2:
-                exe = os.path.basename(fields[1])
-                if exe == "sox":
-                    p = fields[2]
-                elif exe == "flac":
-                    p = fields[-1]
-                else:
-                    raise RuntimeError(f"Unknown wav.scp format with {fields[1]}")
-            else:
-                p = fields[1]
-            if "$" in p:
-                p = os.path.expandvars(p)
-            wav[wid] = p
-    return wav
+            audio = _wavscp_audio_path(entry.strip()) if "'" not in raw else _QUOTED.search(raw).group(1)
+            table[rec_id] = os.path.expandvars(audio) if "$" in audio else audio
+    return table
 
 
 @dataclass
@@ -207,16 +212,16 @@ def write_wav(path: str, x: np.ndarray, sample_rate: int = 16000):
 _SPACES = re.compile(r"\s+")
 
 
-def remove_special_words(text: str, glue_apostrophe: bool = True) -> str:
-    """Label clean-up applied before tokenisation (ssak/utils/text_basic.py:91-125): drop ``<...>`` words,
-    glue (or un-glue) apostrophes, collapse whitespace."""
+def remove_special_words(text: str, glue_apostrophe: Optional[bool] = True) -> str:
+    """Label clean-up applied before tokenisation (ssak/utils/text_basic.py:91-125): ``<...>`` words dropped, apostrophes
+    glued to their neighbours (True), followed by a space (False) or left alone (None), whitespace collapsed."""
     if not text:
         return ""
     text = re.sub(r"<.*?>", "", text)
     if glue_apostrophe is True:
-        text = re.sub(r"[^\S]+'[^\S]+", "'", text)
+        text = re.sub(r"\s+'\s+", "'", text)
     elif glue_apostrophe is False:
-        text = re.sub(r"'", "' ", text).strip()
+        text = text.replace("'", "' ")
     return _SPACES.sub(" ", text).strip()
 
 

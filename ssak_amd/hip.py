@@ -36,7 +36,8 @@ class W2V2Config(C.Structure):
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 80), ("launches", C.c_long), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+    _fields_ = [("name", C.c_char * 112), ("launches", C.c_long), ("total_ms", C.c_double), ("total_flops", C.c_double),
+                ("bound", C.c_int)]
 
 
 GRAD_READY_FN = C.CFUNCTYPE(None, C.c_long, C.c_long, C.c_void_p)
@@ -91,6 +92,8 @@ def _load():
         "ssak_w2v2_forward": (i32, [vp, vp, vp, i32, i32, vp, vp, C.c_uint64, i32, vp, vp, vp, sz, vp]),
         "ssak_w2v2_backward": (i32, [vp, vp, vp, sz, vp]),
         "ssak_w2v2_set_grad_ready_callback": (i32, [vp, GRAD_READY_FN, vp]),
+        "ssak_w2v2_set_param_event": (i32, [vp, vp, vp, vp]),
+        "ssak_w2v2_grad_ranges": (i32, [C.POINTER(W2V2Config), C.POINTER(C.c_long), C.POINTER(C.c_long), i32]),
         "ssak_w2v2_forward_hidden": (i32, [vp, vp, vp, i32, i32, vp, vp, C.c_uint64, i32, vp, vp, vp, sz, vp]),
         "ssak_w2v2_backward_hidden": (i32, [vp, vp, vp, sz, vp]),
         "ssak_grad_sumsq_add": (i32, [vp, C.c_long, vp, vp, sz, vp]),
@@ -263,17 +266,21 @@ def gemm_grouped(problems, stream_=None):
 
 
 def prof_enable(mode: int):
-    """0 = off, 1 = every GEMM launch, 2 + i = only the instantiation at index i of :func:`prof_collect`'s list."""
+    """0 = off, 1 = every launch, 2 + i = only the slot at index i of :func:`prof_collect`'s list."""
     check(lib.ssak_prof_enable(int(mode)))
 
 
+BOUNDS = {0: "mfma", 1: "hbm", 2: "latency"}
+
+
 def prof_collect():
-    """[(kernel name, launches, total ms, total algorithmic flops)] since the last collect."""
-    arr = (ProfEntry * 33)()
-    n = lib.ssak_prof_collect(arr, 33)
+    """[(kernel name, launches, total ms, total algorithmic work, bound)] since the last collect; work = flops for "mfma"
+    slots, bytes for "hbm" / "latency" slots."""
+    arr = (ProfEntry * 64)()
+    n = lib.ssak_prof_collect(arr, 64)
     if n < 0:
         check(n)
-    return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops) for i in range(n)]
+    return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops, BOUNDS[arr[i].bound]) for i in range(n)]
 
 
 def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0):

@@ -102,8 +102,19 @@ class Wav2Vec2ForCTC:
         c.freeze_feature_encoder = int(freeze_feature_encoder)
         return c
 
+    @classmethod
+    def grad_ranges(cls, config, freeze_feature_encoder: bool = True):
+        """[(offset, count)] of the gradient buckets the backward announces, from the configuration alone (no GPU needed)."""
+        c = cls._c_config(config, freeze_feature_encoder)
+        off, cnt = (C.c_long * 128)(), (C.c_long * 128)()
+        n = hip.lib.ssak_w2v2_grad_ranges(C.byref(c), off, cnt, 128)
+        if n < 0:
+            hip.check(n)
+        return [(off[i], cnt[i]) for i in range(n)]
+
     def _finish_init(self, c, seed):
         config = self.config
+        self._seed = seed
         self._c = c
         h = C.c_void_p()
         hip.check(hip.lib.ssak_w2v2_create(C.byref(c), C.byref(h)))
@@ -124,10 +135,17 @@ class Wav2Vec2ForCTC:
         hip.check(hip.lib.ssak_w2v2_bind(h, hip.ptr(self.params), hip.ptr(self.grads), hip.ptr(self.shadow)))
         self._ws = None
         self._ws_key = None
-        self._step_seed = np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0]
-        self._host_rng = np.random.RandomState(seed)
+        self.train_forwards = 0
+        self.kept_layers = 0
+        self.reseed(seed)
         self._last = None
         self._pinned_mask = {}
+
+    def reseed(self, seed: int):
+        """Restart the dropout-mask counter stream and the host generator of the SpecAugment spans / LayerDrop decisions."""
+        self._seed = int(seed)
+        self._step_seed = np.random.SeedSequence(int(seed)).generate_state(1, dtype=np.uint64)[0]
+        self._host_rng = np.random.RandomState(int(seed) % (1 << 32))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -146,6 +164,7 @@ class Wav2Vec2ForCTC:
         return self.grads[off:off + n].view(shape)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        self.wait_params()
         V = self.config.vocab_size
         return {n: (self.param(n)[:V] if n in self._HEAD else self.param(n)).detach().cpu().clone() for n in self.layout}
 
@@ -169,6 +188,7 @@ class Wav2Vec2ForCTC:
         extra = [n for n in sd if n not in self.layout]
         if strict and (missing or extra):
             raise RuntimeError(f"state_dict mismatch: missing {missing[:4]} unexpected {extra[:4]}")
+        self.wait_params()
         for n, (off, numel, shape) in self.layout.items():
             if n in sd:
                 t = torch.as_tensor(sd[n]).to(torch.float32)
@@ -255,6 +275,9 @@ class Wav2Vec2ForCTC:
                 mask_dev = pin[1]
         if layer_keep is not None:
             keep_arr = (C.c_uint8 * cfg.num_hidden_layers)(*[int(bool(k)) for k in layer_keep])
+        if training:  # LayerDrop bookkeeping (benchmarks price the step by the layers that actually ran)
+            self.train_forwards += 1
+            self.kept_layers += cfg.num_hidden_layers if layer_keep is None else int(sum(bool(k) for k in layer_keep))
         self._step_seed = (int(self._step_seed) * 6364136223846793005 + 1442695040888963407) % (1 << 64)
         flens = torch.empty(B, dtype=torch.int32, device=self.device) if lens_dev is not None else None
         return x, B, T, F, lens_dev, ws, mask_dev, keep_arr, flens
@@ -312,6 +335,7 @@ class Wav2Vec2ForCTC:
             hip.check(hip.lib.ssak_w2v2_backward_hidden(self._h, hip.ptr(dhidden), hip.ptr(self._ws), self._ws.numel(),
                                                         hip.stream()))
         self._last = None
+        self._raise_callback_error()
 
     def backward(self, grad_scale: float = 1.0):
         """d loss / d params into ``self.grads`` (the counterpart of ``loss.backward()``)."""
@@ -323,6 +347,7 @@ class Wav2Vec2ForCTC:
         with torch.cuda.device(self.device):
             hip.check(hip.lib.ssak_w2v2_backward(self._h, hip.ptr(dlogits), hip.ptr(self._ws), self._ws.numel(), hip.stream()))
         self._last = None
+        self._raise_callback_error()
 
     def set_grad_ready_callback(self, fn):
         """``fn(offset, count)`` is called during :meth:`backward` whenever grads[offset:offset+count] is final
@@ -330,8 +355,49 @@ class Wav2Vec2ForCTC:
         if fn is None:
             self._cb = hip.GRAD_READY_FN()  # NULL function pointer
         else:
-            self._cb = hip.GRAD_READY_FN(lambda off, cnt, _user: fn(off, cnt))
+            def guarded(off, cnt, _user):
+                # ctypes would print and swallow an exception raised inside the callback (a failed all-reduce would go
+                # unnoticed): keep the first one and re-raise it when the backward call returns
+                try:
+                    fn(off, cnt)
+                except BaseException as exc:  # noqa: BLE001
+                    if self._cb_error is None:
+                        self._cb_error = exc
+            self._cb = hip.GRAD_READY_FN(guarded)
+        self._cb_error = None
         hip.check(hip.lib.ssak_w2v2_set_grad_ready_callback(self._h, self._cb, None))
+
+    def _raise_callback_error(self):
+        exc, self._cb_error = getattr(self, "_cb_error", None), None
+        if exc is not None:
+            raise exc
+
+    def set_param_event(self, event: Optional[torch.cuda.Event], stall_begin=None, stall_end=None):
+        """The optimizer runs on a side stream: ``event`` is recorded there after the update; every forward waits for it at
+        its first read of a trainable parameter (``ssak_w2v2_set_param_event``).  The host-side accessors wait through
+        :meth:`wait_params`."""
+        self._param_event = event
+        raw = [None if ev is None else C.c_void_p(ev.cuda_event) for ev in (event, stall_begin, stall_end)]
+        self._param_event_keep = (event, stall_begin, stall_end)  # the engine holds raw handles
+        hip.check(hip.lib.ssak_w2v2_set_param_event(self._h, *raw))
+
+    # The flat buffers are exposed through properties that first order the CURRENT stream behind a pending side-stream
+    # optimizer update (a stream-wait on an event: microseconds on the host, nothing on the device once the update is done),
+    # so host code can keep reading / writing ``model.params`` / ``model.grads`` right after ``Trainer.train_step``.
+    def _buf(self, name):
+        self.wait_params()
+        return self.__dict__[name]
+
+    params = property(lambda self: self._buf("_params"), lambda self, v: self.__dict__.__setitem__("_params", v))
+    grads = property(lambda self: self._buf("_grads"), lambda self, v: self.__dict__.__setitem__("_grads", v))
+    shadow = property(lambda self: self._buf("_shadow"), lambda self, v: self.__dict__.__setitem__("_shadow", v))
+
+    def wait_params(self):
+        """Make the current stream wait for a pending side-stream optimizer update (before reading or writing params)."""
+        ev = getattr(self, "_param_event", None)
+        if ev is not None:
+            with torch.cuda.device(self.device):
+                torch.cuda.current_stream().wait_event(ev)
 
     def named_grads(self):
         return {n: self.grad(n) for n, (off, _, _) in self.layout.items() if off < self.num_trainable}

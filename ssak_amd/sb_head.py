@@ -455,7 +455,14 @@ class Brain:
                 wk.wait()
             self._works.clear()
             # check_gradients: non-finite loss -> no update; otherwise clip the joint norm of all trainable parameters
-            ok = (not check_finite) or bool(torch.isfinite(loss).all())
+            # (the decision is made on the MINIMUM of the ranks' flags: the gradients are already summed over ranks, so a rank
+            # with a finite local loss must not apply what a non-finite rank poisoned, and replicas must not diverge)
+            ok = True
+            if check_finite:
+                flag = torch.isfinite(loss).all().to(torch.float32).reshape(1)
+                if self.dist:
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                ok = bool(flag.item() > 0)
             if ok:
                 scale = 1.0 / self.world
                 hip.check(hip.lib.ssak_grad_sumsq(hip.ptr(self.head.grads), self.head.num_params, hip.ptr(self.gnorm_sq),

@@ -7,7 +7,7 @@ computes eval_loss and WER with greedy decoding every ``--eval_steps`` and write
 from __future__ import annotations
 
 import argparse
-import hashlib
+import datetime
 import json
 import os
 import shutil
@@ -20,32 +20,8 @@ from . import hip
 from .checkpoint import load_pretrained, save_pretrained
 from .data import (length_grouped_batches, load_audio, load_kaldi, pad_labels, pad_waves, remove_special_words,
                    shard_batch)
+from .naming import train_folder_name
 from .trainer import AdamW, Trainer
-
-
-def hashmd5(obj) -> str:
-    return hashlib.md5(json.dumps(obj, sort_keys=True).encode()).hexdigest()
-
-
-def args_to_str(args, ignore=("gpus", "output_dir", "debug", "online", "disable_first_eval", "train", "valid",
-                              "data_augment_noise", "data_augment_rir")) -> str:
-    """Hyper-parameters encoded in the output folder name (wav2vec_train.py:210-236, ssak/utils/train_utils.py:4-16)."""
-    short = {"max_duration": "mxd", "min_duration": "mnd", "base_model": "bm", "learning_rate": "lr", "batch_size": "bs",
-             "num_epochs": "ne", "weight_decay": "wd", "attention_dropout": "ad", "hidden_dropout": "hd",
-             "feat_proj_dropout": "fd", "layer_dropout": "ld", "mask_time_prob": "mtp", "seed": "s", "eval_steps": "es",
-             "no_freeze": "nf", "data_augment": "da"}
-    parts = []
-    for k, v in sorted(vars(args).items()):
-        if k in ignore:
-            continue
-        if isinstance(v, bool):
-            if v:
-                parts.append(short.get(k, k))
-            continue
-        if isinstance(v, str):
-            v = os.path.basename(v.rstrip("/"))
-        parts.append(f"{short.get(k, k)}-{v}")
-    return "_".join(parts)
 
 
 def word_error_rate(refs, hyps) -> float:
@@ -89,6 +65,8 @@ def build_parser():
     p.add_argument("--disable_first_eval", default=False, action="store_true")
     p.add_argument("--seed", default=69, type=int)
     p.add_argument("--eval_steps", default=400, type=int)
+    p.add_argument("--data_augment_noise", default="", type=str, help="(used only with --data_augment)")
+    p.add_argument("--data_augment_rir", default="", type=str, help="(used only with --data_augment)")
     p.add_argument("--output_dir", default=".", type=str)
     return p
 
@@ -136,12 +114,21 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    args.online = args.online or args.data_augment  # wav2vec_train.py:188
     train_u = load_kaldi(args.train, args.min_duration, args.max_duration)
     valid_u = load_kaldi(args.valid, args.min_duration, args.max_duration)
     if args.debug:
-        train_u, valid_u = train_u[:64], valid_u[:16]
-    name = "hf_" + hashmd5([u.path for u in train_u])[:8] + "_" + args_to_str(args)
-    out_dir = os.path.join(args.output_dir, name)
+        # wav2vec_train.py:279-290 with dataset.py:278-283: the 2 * batch_size LONGEST utterances (does everything fit?)
+        keep = 2 * args.batch_size
+        train_u = sorted(train_u, key=lambda u: u.duration)[-keep:]
+        valid_u = sorted(valid_u, key=lambda u: u.duration)[-keep:]
+    else:
+        valid_u = valid_u[:480]  # max_data of the validation set, wav2vec_train.py:289
+    if len(train_u) < world:
+        raise RuntimeError(f"{len(train_u)} training utterances for {world} ranks: nothing to shard")
+    script = os.path.abspath(__file__)
+    out_dir = os.path.join(args.output_dir, train_folder_name(vars(args), script))
+    untrained_dir = os.path.join(args.output_dir, train_folder_name(vars(args), script, untrained=True))
     model, tok = load_pretrained(args.base_model, device=dev, freeze_feature_encoder=not args.no_freeze,
                                  attention_dropout=args.attention_dropout,
                                  hidden_dropout=args.hidden_dropout, feat_proj_dropout=args.feat_proj_dropout,
@@ -168,9 +155,21 @@ def main(argv=None):
     state = {"log_history": [], "global_step": 0, "max_steps": total}
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
-        if not args.disable_first_eval:
-            with open(os.path.join(out_dir, "init_eval.json"), "w") as f:
-                json.dump(evaluate(model, tok, vw, vl, args.batch_size), f, indent=1)
+        with open(os.path.join(out_dir, "README.txt"), "a") as readme:  # wav2vec_train.py:247-254
+            import sys
+            print(datetime.datetime.now(), file=readme)
+            print(" ".join(sys.argv), file=readme)
+            print(f"{len(train_u)} training / {len(valid_u)} validation utterances\n", file=readme)
+        # initial evaluation: computed once per (data, base model) in the "untrained" folder, copied into every run's folder,
+        # never redone on resume (wav2vec_train.py:397-410)
+        init_results = os.path.join(out_dir, "init_eval.json")
+        if not args.disable_first_eval and not os.path.isfile(init_results):
+            cached = os.path.join(untrained_dir, "init_eval.json")
+            if not os.path.exists(cached):
+                os.makedirs(untrained_dir, exist_ok=True)
+                with open(cached, "w") as f:
+                    json.dump(evaluate(model, tok, vw, vl, args.batch_size), f, indent=1)
+            shutil.copy(cached, init_results)
     rng = np.random.RandomState(args.seed)
     use_mask = model.config.feat_extract_norm == "layer"
     step, t0, run_loss = 0, time.time(), []
@@ -185,14 +184,19 @@ def main(argv=None):
         opt.load_state_dict(torch.load(os.path.join(last, "optimizer.pt")))
         with open(os.path.join(last, "trainer_state.json")) as f:
             state = json.load(f)
-        extra = torch.load(os.path.join(last, "rng.pt"), weights_only=False)
-        model._step_seed, _ = extra["step_seed"], model._host_rng.set_state(extra["host_rng"])
+        with open(os.path.join(last, "rng.json")) as f:  # plain JSON, no pickle
+            extra = json.load(f)
+        model._step_seed = int(extra["step_seed"])
+        kind, keys, pos, has_gauss, cached = extra["host_rng"]
+        model._host_rng.set_state((kind, np.asarray(keys, dtype=np.uint32), int(pos), int(has_gauss), float(cached)))
         resume_step = int(state["global_step"])
         if rank == 0:
             print(f"resuming from {last} (step {resume_step} of {total})")
     while step < total:
         plan = [shard_batch(idx, rank, world) if world > 1 else idx for idx in length_grouped_batches(train_len, args.batch_size, rng)]
         plan = [m for m in plan if m][:total - step]
+        if not plan:
+            raise RuntimeError("empty batch plan: fewer training utterances than data-parallel ranks per batch")
         if step < resume_step:  # batches the checkpointed run already consumed
             skip = min(len(plan), resume_step - step)
             plan, step = plan[skip:], step + skip
@@ -222,7 +226,10 @@ def main(argv=None):
                     ck = os.path.join(out_dir, f"checkpoint-{step}")
                     save_pretrained(model, tok, ck)
                     torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
-                    torch.save({"step_seed": int(model._step_seed), "host_rng": model._host_rng.get_state()}, os.path.join(ck, "rng.pt"))
+                    kind, keys, pos, has_gauss, cached = model._host_rng.get_state()
+                    with open(os.path.join(ck, "rng.json"), "w") as f:
+                        json.dump({"step_seed": int(model._step_seed),
+                                   "host_rng": [kind, [int(k) for k in keys], int(pos), int(has_gauss), float(cached)]}, f)
                     with open(os.path.join(ck, "trainer_state.json"), "w") as f:
                         json.dump(state, f, indent=1)
                     for old in sorted_checkpoints(out_dir)[:-2]:  # save_total_limit=2 (wav2vec_train.py:370)

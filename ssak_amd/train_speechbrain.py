@@ -33,7 +33,7 @@ import torch
 import yaml
 
 from .data import load_audio, load_kaldi, pad_waves, remove_special_words
-from .train import hashmd5
+from .naming import hashmd5
 
 
 # ------------------------------------------------------------------ yaml with hyperpyyaml tags
@@ -273,9 +273,12 @@ def main(argv=None):
             step += 1
             if step <= state["step"]:
                 continue  # consumed before the checkpoint this run resumed from
-            idx = gidx[rank::world] if world > 1 else gidx
-            if not idx:
+            # every rank takes the SAME number of utterances (data.shard_batch's rule: len // world each, remainder dropped):
+            # a tail batch smaller than the world is skipped by ALL ranks, so the collective counts never diverge
+            per = len(gidx) // world
+            if per == 0:
                 continue
+            idx = gidx[rank:per * world:world] if world > 1 else gidx
             wavs, wl, toks, tl = batch_of(idx, tw, tt)
             loss = brain.fit_batch(wavs, wl, toks, tl)
             run_loss, run_n = run_loss + float(loss.item()), run_n + 1

@@ -28,8 +28,38 @@ def linear_warmup_lr(base_lr: float, step: int, warmup_steps: int, total_steps: 
     return base_lr * max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
 
 
+def hf_decays(name: str, config) -> bool:
+    """HF Trainer's weight-decay parameter group (docker/transformers_modified/trainer.py:1013-1024): every parameter that
+    is not inside an ``nn.LayerNorm`` module and has no "bias" in its name.  The conv0 normalisation of the group-norm
+    ("base") feature encoder is an ``nn.GroupNorm`` -- not in ``ALL_LAYERNORM_LAYERS`` -- so its weight IS decayed."""
+    if "bias" in name:
+        return False
+    if "layer_norm" in name:
+        group_norm0 = (getattr(config, "feat_extract_norm", "") == "group"
+                       and name.startswith("wav2vec2.feature_extractor.conv_layers.0.layer_norm"))
+        return group_norm0
+    return True
+
+
+def decay_ranges(model):
+    """[(offset, count, decays)] covering [0, num_trainable) of the flat buffers, adjacent parameters of one group merged.
+    The engine lays the trainable matrices out first and the vectors after them, so the default (frozen feature encoder)
+    model is two ranges."""
+    items = sorted((off, name) for name, (off, _, _) in model.layout.items() if off < model.num_trainable)
+    out = []
+    for i, (off, name) in enumerate(items):
+        end = items[i + 1][0] if i + 1 < len(items) else model.num_trainable
+        d = hf_decays(name, model.config)
+        if out and out[-1][2] == d:
+            out[-1] = (out[-1][0], end - out[-1][0], d)
+        else:
+            out.append((off, end - off, d))
+    return out
+
+
 class AdamW:
-    """Flat-buffer AdamW with fused global-norm clipping (kernels: ssak_grad_sumsq / ssak_adamw_step)."""
+    """Flat-buffer AdamW with fused global-norm clipping (kernels: ssak_grad_sumsq / ssak_adamw_step) and HF Trainer's
+    two weight-decay groups (matrices decayed, biases / LayerNorm affines not)."""
 
     def __init__(self, model: Wav2Vec2ForCTC, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  max_grad_norm=1.0, warmup_steps=500, total_steps=100000):
@@ -42,41 +72,68 @@ class AdamW:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=model.device)
         self._sumsq_ws = torch.empty(1024, dtype=torch.float32, device=model.device)  # per-workgroup partials of the norm
         self.step_count = 0
+        self.ranges = decay_ranges(model)
 
     def current_lr(self) -> float:
         return linear_warmup_lr(self.lr, self.step_count, self.warmup_steps, self.total_steps)
 
-    def step(self, grad_scale: float = 1.0):
+    def _update_ranges(self):
+        """One sweep when nothing is decayed (the reference's default weight_decay 0.0), else one per group range."""
+        if self.weight_decay == 0.0:
+            return [(0, self.n, 0.0)]
+        return [(off, cnt, self.weight_decay if d else 0.0) for off, cnt, d in self.ranges]
+
+    def add_sumsq(self, offset: int, count: int, first: bool):
+        """gnorm_sq (+)= sum(grads[offset:offset+count]^2) on the current stream: the norm partial of one bucket."""
+        m = self.model
+        fn = hip.lib.ssak_grad_sumsq if first else hip.lib.ssak_grad_sumsq_add
+        hip.check(fn(hip.ptr(m.grads[offset:]), count, hip.ptr(self.gnorm_sq), hip.ptr(self._sumsq_ws),
+                     self._sumsq_ws.numel() * 4, hip.stream()))
+
+    def step(self, grad_scale: float = 1.0, norm_done: bool = False):
+        """Clip + update on the CURRENT stream.  ``norm_done``: gnorm_sq already holds the sum of squares (bucket partials)."""
         m = self.model
         lr = self.current_lr()
         self.step_count += 1
         with torch.cuda.device(m.device):
             st = hip.stream()
-            hip.check(hip.lib.ssak_grad_sumsq(hip.ptr(m.grads), self.n, hip.ptr(self.gnorm_sq), hip.ptr(self._sumsq_ws),
-                                              self._sumsq_ws.numel() * 4, st))
-            hip.check(hip.lib.ssak_adamw_step(hip.ptr(m.params), hip.ptr(m.grads), hip.ptr(self.exp_avg),
-                                              hip.ptr(self.exp_avg_sq), hip.ptr(m.shadow), self.n, hip.ptr(self.gnorm_sq),
-                                              self.max_grad_norm, grad_scale, lr, self.betas[0], self.betas[1], self.eps,
-                                              self.weight_decay, self.step_count, st))
+            if not norm_done:
+                self.add_sumsq(0, self.n, first=True)
+            for off, cnt, wd in self._update_ranges():
+                hip.check(hip.lib.ssak_adamw_step(hip.ptr(m.params[off:]), hip.ptr(m.grads[off:]), hip.ptr(self.exp_avg[off:]),
+                                                  hip.ptr(self.exp_avg_sq[off:]), hip.ptr(m.shadow[off:]), cnt,
+                                                  hip.ptr(self.gnorm_sq), self.max_grad_norm, grad_scale, lr, self.betas[0],
+                                                  self.betas[1], self.eps, wd, self.step_count, st))
         m.sync_weights(full=False)  # the weight-normed positional-conv layouts follow the updated (g, v)
 
     def grad_norm(self, grad_scale: float = 1.0) -> float:
+        self.model.wait_params()
         return float(self.gnorm_sq.sqrt().item()) * grad_scale
 
     def state_dict(self):
+        self.model.wait_params()
         return {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.step_count}
 
     def load_state_dict(self, sd):
+        self.model.wait_params()
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
 
 
 class Trainer:
-    """One optimizer step per call; data-parallel when a process group is initialised."""
+    """One optimizer step per call; data-parallel when a process group is initialised.
+
+    The optimizer tail runs on a SIDE STREAM (``optimizer_stream=True``, or environment SSAK_OPT_STREAM=0 to disable): as each
+    gradient bucket's all-reduce completes, its share of the clip norm is summed there (the norm partials ride with the
+    buckets); after the last one the clip coefficient is known and AdamW sweeps the buffers, still on the side stream.  The
+    compute stream meanwhile starts the next step -- waveform normalisation and the (frozen) conv feature encoder, a third of
+    the forward, read no trainable parameter -- and waits for the update only at the feature projection
+    (``ssak_w2v2_set_param_event``).  The exchange tail (last bucket) and the optimizer are hidden under that work."""
 
     def __init__(self, model: Wav2Vec2ForCTC, optimizer: AdamW, normalize_on_device: bool = True,
-                 grad_exchange_dtype: str | None = None):
+                 grad_exchange_dtype: str | None = None, optimizer_stream: bool | None = None, measure_stall: bool = False,
+                 per_rank_seed: bool = True):
         """``grad_exchange_dtype``: "fp32" (default; or environment SSAK_DP_GRAD_DTYPE) or "bf16" -- the gradient buckets are
         rounded to bf16 for the all-reduce and widened again before the clip + update: half the bytes over xGMI (180 MB
         instead of 361 MB per step for the base model) at bf16 rounding of the exchanged sums."""
@@ -90,7 +147,26 @@ class Trainer:
         self.normalize_on_device = normalize_on_device
         # group-norm ("base") models run without attention mask, layer-norm (XLSR) models with it
         self.use_mask = model.config.feat_extract_norm == "layer"
-        self._works = []
+        if self.dist and self.world > 1 and per_rank_seed:
+            # independent replicas draw independent regularisers: dropout masks, SpecAugment spans and LayerDrop decisions
+            # come from seed + rank (identical seeds would apply one mask pattern to every shard of the global batch)
+            model.reseed(model._seed + torch.distributed.get_rank())
+        self._works = []  # (work, offset, count) of this step's bucket all-reduces, in announcement order
+        self.bucket_log = []  # [(offset, count)] of the last step (bench: bucket sizes)
+        if optimizer_stream is None:
+            optimizer_stream = os.environ.get("SSAK_OPT_STREAM", "1") != "0"
+        self.opt_stream = None
+        self._stall = None
+        if optimizer_stream:
+            with torch.cuda.device(model.device):
+                self.opt_stream = torch.cuda.Stream()
+                self._ready = torch.cuda.Event()
+                if measure_stall:
+                    self._stall = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    for ev in self._stall:
+                        ev.record()  # (created lazily by torch: the engine needs the raw handles now)
+                self._ready.record(self.opt_stream)
+            model.set_param_event(self._ready, *(self._stall or (None, None)))
         if self.dist and self.world > 1:
             # RCCL's kernels take CUs away from the persistent GEMMs for a while: draw tiles from tickets (include/ssak_hip.h)
             hip.check(hip.lib.ssak_gemm_tile_order(1))
@@ -107,14 +183,41 @@ class Trainer:
             # ranges start at multiples of 8 elements for every supported topology; the cast runs on the compute stream,
             # behind the kernels that produced the range
             hip.check(hip.lib.ssak_cast_f32_bf16(hip.ptr(m.grads[offset:]), hip.ptr(self._g16[offset:]), count, hip.stream()))
-            self._works.append(torch.distributed.all_reduce(self._g16[offset:offset + count], async_op=True))
-            return
-        self._works.append(torch.distributed.all_reduce(m.grads[offset:offset + count], async_op=True))
+            work = torch.distributed.all_reduce(self._g16[offset:offset + count], async_op=True)
+        else:
+            work = torch.distributed.all_reduce(m.grads[offset:offset + count], async_op=True)
+        self._works.append((work, offset, count))
 
     def broadcast_parameters(self):
         if self.dist:
+            self.model.wait_params()
             torch.distributed.broadcast(self.model.params, src=0)
             self.model.sync_weights(full=True)
+
+    def stall_ms(self) -> float:
+        """Exposed part of the previous step's exchange + optimizer tail: how long the last forward's compute stream sat at
+        the parameter-ready wait (needs ``measure_stall=True``; synchronises)."""
+        if self._stall is None:
+            return float("nan")
+        self._stall[1].synchronize()
+        return self._stall[0].elapsed_time(self._stall[1])
+
+    def _tail(self, norm_from_buckets: bool, compute_stream=None):
+        """Norm partials per reduced bucket, clip + AdamW, positional-conv layouts: on the current stream."""
+        m = self.model
+        for i, (work, off, cnt) in enumerate(self._works):
+            work.wait()  # the current stream waits for this bucket's collective; the mean over ranks is folded into the optimizer
+            if self.grad_exchange_dtype == "bf16":
+                hip.check(hip.lib.ssak_cast_bf16_f32(hip.ptr(self._g16[off:]), hip.ptr(m.grads[off:]), cnt, hip.stream()))
+            if norm_from_buckets:
+                self.opt.add_sumsq(off, cnt, first=(i == 0))
+        self.bucket_log = [(off, cnt) for _, off, cnt in self._works]
+        have_norm = norm_from_buckets and bool(self._works)
+        self._works.clear()
+        if compute_stream is not None:
+            # everything of the backward (without a process group: the gradients themselves) precedes the update
+            torch.cuda.current_stream().wait_stream(compute_stream)
+        self.opt.step(grad_scale=1.0 / self.world, norm_done=have_norm)
 
     def train_step(self, waves: torch.Tensor, lengths, labels: torch.Tensor, raw: bool = True):
         """waves [B,T] fp32 on the device (raw samples when ``raw``: normalised here, a1), lengths [B] or None,
@@ -123,10 +226,12 @@ class Trainer:
         x = hip.wave_normalize(waves, lengths) if raw else waves
         out = m(x, lengths=lengths if self.use_mask else None, labels=labels)
         m.backward()  # with a process group: announces finished gradient ranges -> bucketed all-reduces overlap it
-        for w in self._works:
-            w.wait()  # the compute stream waits for the reduced buckets; mean over ranks is folded into the optimizer
-        if self._works and self.grad_exchange_dtype == "bf16":
-            hip.check(hip.lib.ssak_cast_bf16_f32(hip.ptr(self._g16), hip.ptr(m.grads), m.num_trainable, hip.stream()))
-        self._works.clear()
-        self.opt.step(grad_scale=1.0 / self.world)
+        if self.opt_stream is None:
+            self._tail(norm_from_buckets=False)
+            return out.loss
+        with torch.cuda.device(m.device):
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self.opt_stream):
+                self._tail(norm_from_buckets=True, compute_stream=cur)
+                self._ready.record(self.opt_stream)
         return out.loss

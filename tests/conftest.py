@@ -22,5 +22,15 @@ def gold():
     return load
 
 
+@pytest.fixture(scope="session")
+def gold_json():
+    import json
+
+    def load(name):
+        with open(os.path.join(GOLD, name)) as f:
+            return json.load(f)
+    return load
+
+
 def ctc_case_names(npz):
     return sorted({k.split("/")[0] for k in npz.files})

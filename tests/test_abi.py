@@ -26,3 +26,28 @@ def test_binding_rejects_without_gpu_compute():
     d = h.GemmDesc(0, 8, 8, 0, 0, 8, 8, 8, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0, 1, 0, 1, 0.0, 0, 0, 0, 0, 0)
     rc = h.lib.ssak_gemm_bf16(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
     assert rc == h.SSAK_ERR_INVALID and b"null" in h.lib.ssak_last_error()
+
+
+def test_base_gradient_buckets_cover_the_trainable_range():
+    """The gradient ranges the backward announces for the data-parallel exchange, from the configuration alone
+    (ssak_w2v2_grad_ranges: host arithmetic, no GPU): for wav2vec2-base with the frozen feature encoder they are disjoint,
+    16-byte aligned and cover [0, 90 195 872) -- the 360.8 MB fp32 all-reduce payload of SURVEY.md section 8e -- as the head
+    matrix, twelve 28.3 MB layer buckets (last layer first), the leading small matrices and the vector region."""
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    r = Wav2Vec2ForCTC.grad_ranges(Wav2Vec2Config())
+    assert len(r) == 1 + 12 + 2
+    assert all(off % 4 == 0 and cnt > 0 for off, cnt in r)  # 4 floats = 16 bytes
+    spans = sorted(r)
+    assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert spans[-1][0] + spans[-1][1] == 90_195_872
+    layer = 4 * 768 * 768 + 2 * 768 * 3072
+    assert [c for _, c in r[1:13]] == [layer] * 12 and r[0][1] == 32 * 768
+    assert [o for o, _ in r[1:13]] == sorted((o for o, _ in r[1:13]), reverse=True)  # announced from the last layer down
+    # the trained feature encoder (--no_freeze) extends the last range to all 94 396 320 parameters
+    r2 = Wav2Vec2ForCTC.grad_ranges(Wav2Vec2Config(), freeze_feature_encoder=False)
+    assert sum(c for _, c in r2) == 94_396_320
+    # XLSR-large: 24 layer buckets of 50.3 MB
+    x = Wav2Vec2ForCTC.grad_ranges(Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                                                   feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True))
+    assert len(x) == 27 and sorted(x)[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(sorted(x), sorted(x)[1:]))

@@ -149,35 +149,8 @@ def test_xlsr_layerdrop_and_dropout_vs_oracle(mods):
     assert (losses[0][1] - losses[1][1]).abs().max().item() < 1e-6
 
 
-def test_base_vs_hf_golden(mods, gold):
-    """wav2vec2-base, B=2, 10 s utterances (499 frames): logits / loss / per-parameter gradient norms against
-    transformers.Wav2Vec2ForCTC (golden), inputs regenerated from the committed seed."""
-    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
-    from oracle.gen_golden import base_inputs
-    z = gold("w2v2_base.npz")
-    x, labels = base_inputs()
-    assert np.abs(x[:, :64] - z["x_head"]).max() < 1e-6
-    oc = R.W2V2Config.base().deterministic()
-    model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).train()
-    model.load_state_dict(R.init_params(oc, 69))
-    out = model(torch.tensor(x), labels=torch.tensor(labels))
-    assert out.logits.shape == (2, 499, 32)
-    e = rel_l2(out.logits.cpu().numpy(), z["logits"])
-    print("base logits rel l2", e, "loss", out.loss.item(), float(z["loss"]))
-    assert e < 2e-2
-    assert abs(out.loss.item() - float(z["loss"])) < 2e-2 * float(z["loss"])
-    model.grads[:model.num_trainable].fill_(float("nan"))  # an earlier step's values must be overwritten or zeroed, never kept
-    model.backward()
-    worst = 0.0
-    gmax = float(z["grad_norms"].max())
-    for n, nr, hd in zip(z["grad_names"], z["grad_norms"], z["grad_heads"]):
-        g = model.grad(str(n)).double()
-        got = float(torch.sqrt((g * g).sum()))
-        if nr < 1e-4 * gmax:
-            continue
-        worst = max(worst, abs(got - nr) / nr)
-        assert abs(got - nr) < 6e-2 * nr, (n, got, nr)
-    print("base worst grad-norm rel err", worst)
+# (wav2vec2-base at full size -- logits, loss, gradient norms, random projections and every gradient tensor in full -- is
+# tests/test_gpu_fullsize.py::test_base_gradients_projections_and_full_tensors)
 
 
 def test_dropout_replay_and_layerdrop(mods):
@@ -247,6 +220,8 @@ def test_trainer_bucketed_allreduce_single_rank(mods):
     n_train = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).num_trainable
     assert spans[-1][0] + spans[-1][1] == n_train
     assert sum(c for _, c in spans) >= n_train - 8 * len(spans)  # only alignment padding is left out
+    # ... and they are exactly the static bucket list computed from the configuration (ssak_w2v2_grad_ranges), in order
+    assert per_step == Wav2Vec2ForCTC.grad_ranges(_cfg_from_oracle(Wav2Vec2Config, oc))
 
 
 def test_whisper_encoder_ctc_vs_hf(gold):

@@ -121,9 +121,13 @@ def test_train_and_infer_cli_on_kaldi_folder(tmp_path):
                         "--batch_size", "4", "--num_epochs", "20", "--eval_steps", "20", "--learning_rate", "3e-3",
                         "--min_duration", "0", "--output_dir", str(tmp_path / "out")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    outs = os.listdir(tmp_path / "out")
-    assert len(outs) == 1 and outs[0].startswith("hf_") and "bs-4" in outs[0]
+    # two folders (wav2vec_train.py:238-239,397-410): the run's, and the "untrained" one that caches the initial evaluation
+    outs = sorted(d for d in os.listdir(tmp_path / "out") if "_adamwt" in d)
+    cache = sorted(d for d in os.listdir(tmp_path / "out") if "_adamwt" not in d)
+    assert len(outs) == 1 and outs[0].startswith("hf_") and "_bs-4_" in outs[0] and outs[0].endswith("_s-69_adamwt")
+    assert len(cache) == 1 and outs[0].startswith(cache[0] + "_lr-0.003") and (tmp_path / "out" / cache[0] / "init_eval.json").exists()
     run = tmp_path / "out" / outs[0]
+    assert "ssak_amd" in open(run / "README.txt").read()
     assert (run / "init_eval.json").exists() and (run / "final" / "model.safetensors").exists()
     st = json.load(open(run / "checkpoint-40" / "trainer_state.json"))
     train_losses = [e["loss"] for e in st["log_history"] if "loss" in e]
@@ -155,7 +159,7 @@ def test_train_and_infer_cli_on_kaldi_folder(tmp_path):
                         "--min_duration", "0", "--output_dir", str(tmp_path / "out_online")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    run2 = tmp_path / "out_online" / os.listdir(tmp_path / "out_online")[0]
+    run2 = tmp_path / "out_online" / [d for d in os.listdir(tmp_path / "out_online") if d.endswith("_adamwt_online")][0]
     st2 = json.load(open(run2 / "checkpoint-40" / "trainer_state.json"))
     losses2 = [e["loss"] for e in st2["log_history"] if "loss" in e]
     assert len(losses2) == 2 and losses2[1] < losses2[0]

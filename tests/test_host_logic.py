@@ -9,7 +9,7 @@ from ssak_amd import data as D
 from ssak_amd.model import compute_mask_indices, conv_out_lengths
 from ssak_amd.config import Wav2Vec2Config
 from ssak_amd.trainer import linear_warmup_lr
-from ssak_amd.train import word_error_rate, args_to_str, build_parser
+from ssak_amd.train import word_error_rate, build_parser
 from ssak_amd.synth import synth_batch, VOCAB
 
 
@@ -113,9 +113,64 @@ def test_schedule_wer_naming():
     assert abs(linear_warmup_lr(1e-4, 2, 500, 10000) - 4e-7) < 1e-15
     assert linear_warmup_lr(1e-4, 500, 500, 1000) == 1e-4 and linear_warmup_lr(1e-4, 750, 500, 1000) == 0.5e-4
     assert word_error_rate(["a b c", "d"], ["a x c", "d e"]) == 2 / 4
-    a = build_parser().parse_args(["tr", "va", "--base_model", "/x/m"])
-    s = args_to_str(a)
-    assert "lr-0.0001" in s and "bs-8" in s and "bm-m" in s and "tr" not in s.split("_")
+
+
+def test_output_folder_names_equal_the_reference_tests_golden_strings(gold_json, tmp_path):
+    """The reference's own test asserts the folder names its train script creates
+    (tests/unittests/test_train_transformers.py:23-24,55-56).  Same command line through this build's parser and
+    ``train_folder_name`` (wav2vec_train.py:210-239) must give the same strings -- md5 of the data paths included."""
+    from ssak_amd.naming import train_folder_name
+    for case in gold_json("host_strings.json")["output_dir"]:
+        root = tmp_path / "ref"
+        for rel in (case["script"], case["train"], case["valid"]):
+            (root / rel).parent.mkdir(parents=True, exist_ok=True)
+        argv = [str(root / case["train"]), str(root / case["valid"]), "--base_model", case["base_model"]] + \
+            [str(root / f) if f.startswith("tests/") else f for f in case["flags"]]
+        a = build_parser().parse_args(argv)
+        a.online = a.online or a.data_augment
+        assert train_folder_name(vars(a), str(root / case["script"]), untrained=True) == case["untrained"]
+        assert train_folder_name(vars(a), str(root / case["script"])) == case["output"]
+    a = build_parser().parse_args(["tr", "va", "--base_model", "/x/m", "--debug", "--no_freeze"])
+    assert train_folder_name(vars(a), "/s.py") == "hf_DEBUG_md-15_md-1_bm-_x_m_lr-0.0001_bs-8_wd-0_ad-0.1_hd-0.05_fpd-0_ld-0.1_mtp-0.05_s-69_adamwt_nofreeze"
+
+
+def test_host_string_helpers_equal_the_reference(gold_json):
+    """remove_special_words / hashmd5 / remove_commonprefix / args_to_str against strings produced by importing the reference's
+    modules (oracle/gen_golden_host.py; ssak/utils/text_basic.py:91-125, misc.py:42-46,76-92, train_utils.py:4-38)."""
+    from ssak_amd import naming as N
+    z = gold_json("host_strings.json")
+    for text, kw, want in z["remove_special_words"]:
+        assert D.remove_special_words(text, **kw) == want, (text, kw)
+    for obj, want in z["hashmd5_tuple"]:
+        assert N.hashmd5(tuple(obj)) == want
+    for paths, stop, want in z["remove_commonprefix"]:
+        assert N.strip_common_prefix(paths, stop) == want
+    for d, want in z["args_to_str"]:
+        assert N.hparams_to_str(d) == want
+    for d, want in z["args_to_str_sorted"]:
+        assert N.hparams_to_str(d, sort=True) == want
+
+
+def test_wavscp_lines_of_the_reference_fixtures_resolve(gold_json, tmp_path, monkeypatch):
+    """Every wav.scp line of the reference's test Kaldi folders (tests/data/kaldi/{minimal,small,complete}: `id sox
+    $DATAPATH/... |`, one quoted path with a space) and the other forms ssak/utils/kaldi.py:13-35 accepts (plain path, flac
+    pipe, absolute sox) resolve to the expected audio path, with $VAR expansion; the weighted list file expands to
+    (folder, weight) pairs (ssak/utils/dataset.py:165-192)."""
+    z = gold_json("host_strings.json")
+    monkeypatch.setenv("DATAPATH", "/corpus")
+    for name, case in z["wavscp"].items():
+        f = tmp_path / f"{name}.scp"
+        f.write_text("\n".join(case["lines"]) + "\n")
+        got = D.parse_kaldi_wavscp(str(f))
+        assert got == {k: v.replace("$DATAPATH", "/corpus") for k, v in case["expected"].items()}, name
+    (tmp_path / "bad.scp").write_text("x ffmpeg -i a.mp3 - |\n")
+    with pytest.raises(RuntimeError):
+        D.parse_kaldi_wavscp(str(tmp_path / "bad.scp"))
+    for sub in ("small", "minimal"):
+        (tmp_path / "kaldi" / sub).mkdir(parents=True)
+    monkeypatch.setenv("DATAPATH", str(tmp_path))
+    (tmp_path / "list.txt").write_text(z["list_file"])
+    assert D.expand_kaldi_paths(str(tmp_path / "list.txt")) == [(str(tmp_path / "kaldi/small"), 1.0), (str(tmp_path / "kaldi/minimal"), 2.0)]
 
 
 def test_batching_and_sharding():
