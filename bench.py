@@ -147,6 +147,8 @@ def main():
     model.load_state_dict(sd)
     opt = AdamW(model, lr=1e-4, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=500, total_steps=100000)
     trainer = Trainer(model, opt, measure_stall=True)
+    if os.environ.get("SSAK_TILE_ORDER") == "1":  # development switch: ticket tile order without a process group
+        hip.check(hip.lib.ssak_gemm_tile_order(1))
     trainer.broadcast_parameters()
 
     T = int(round(args.seconds * 16000))

@@ -70,7 +70,10 @@ def gen_base_proj():
 
 
 # ----------------------------------------------------------------------------- base: 50-step matched-loss curve
-CURVE = dict(steps=50, lr=1e-4, warmup=5, n_batches=4, B=2, T=160000, weight_decay=0.0, max_grad_norm=1.0)
+# the train script's own schedule (wav2vec_train.py:353-384: lr 1e-4, warmup_steps=500, linear decay over the run, clip 1.0)
+CURVE = dict(steps=50, lr=1e-4, warmup=500, total=20000, n_batches=4, B=2, T=160000, weight_decay=0.0, max_grad_norm=1.0)
+# a 100x faster ramp: the loss falls from 15 to the blank plateau (3.3) within 7 steps through gradient-norm spikes of 166
+CURVE_FAST = dict(CURVE, warmup=5, total=50)
 
 
 def curve_inputs():
@@ -84,7 +87,11 @@ def curve_inputs():
     return batches
 
 
-def gen_base_curve():
+def gen_base_curve_fast():
+    gen_base_curve(CURVE_FAST, "w2v2_base_curve_fast.npz")
+
+
+def gen_base_curve(CURVE=CURVE, fname="w2v2_base_curve.npz"):
     """HF Trainer's inner loop (trainer.py:1754-1855: training_step -> clip_grad_norm_ -> optimizer.step ->
     lr_scheduler.step -> zero_grad) on transformers.Wav2Vec2ForCTC, feature encoder frozen, model.eval() so that the
     dropouts / LayerDrop / SpecAugment are inactive (SURVEY.md section 8d "Matched loss")."""
@@ -97,14 +104,14 @@ def gen_base_curve():
     train = [p for p in m.parameters() if p.requires_grad]
     # HF parameter groups (trainer.py:1013-1024); identical updates at weight_decay 0
     opt = torch.optim.AdamW(train, lr=CURVE["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=CURVE["weight_decay"])
-    sch = transformers.get_linear_schedule_with_warmup(opt, CURVE["warmup"], CURVE["steps"])
+    sch = transformers.get_linear_schedule_with_warmup(opt, CURVE["warmup"], CURVE["total"])
     batches = curve_inputs()
     losses, norms, lrs = [], [], []
     t0 = time.time()
     for step in range(CURVE["steps"]):
         x, labels = batches[step % len(batches)]
         lrs.append(sch.get_last_lr()[0])
-        assert abs(lrs[-1] - adamw_ref.linear_warmup_lr(CURVE["lr"], step, CURVE["warmup"], CURVE["steps"])) < 1e-12
+        assert abs(lrs[-1] - adamw_ref.linear_warmup_lr(CURVE["lr"], step, CURVE["warmup"], CURVE["total"])) < 1e-12
         out = m(torch.tensor(x), labels=torch.tensor(labels))
         out.loss.backward()
         nrm = torch.nn.utils.clip_grad_norm_(train, CURVE["max_grad_norm"])
@@ -118,10 +125,10 @@ def gen_base_curve():
     names = [n for n in R.trainable_names(cfg)]
     final = {n: sd[n].numpy() for n in names}
     s = grad_summary(final)  # same summary scheme, applied to the final parameters
-    np.savez_compressed(os.path.join(GOLD, "w2v2_base_curve.npz"), loss=np.array(losses), grad_norm=np.array(norms),
+    np.savez_compressed(os.path.join(GOLD, fname), loss=np.array(losses), grad_norm=np.array(norms),
                         lr=np.array(lrs), param_names=s["grad_names"], param_norms=s["grad_norms"],
                         param_projs=s["grad_projs"], **{("base_lr" if k == "lr" else k): np.array(v) for k, v in CURVE.items()})
-    print("w2v2_base_curve ok")
+    print(fname, "ok")
 
 
 # ----------------------------------------------------------------------------- XLSR-large, ragged

@@ -212,8 +212,10 @@ def test_trainer_bucketed_allreduce_single_rank(mods):
 
     p0, l0, _ = run(False)
     p1, l1, seen = run(True)
-    # not bitwise: the CTC posterior sums use LDS float atomics (order-dependent last bits)
-    assert abs(l0 - l1) <= 1e-5 * abs(l0) and (p0 - p1).abs().max().item() < 1e-5
+    # not bitwise: under a process group the clip norm is summed bucket by bucket as the all-reduces complete (a different fp32
+    # summation order: 23.555115 vs 23.555113), the first update differs in the last bit of a few parameters, and one flipped
+    # bf16 rounding of a shadow weight moves the SECOND step's gradients by bf16 noise (Adam turns that into fractions of lr)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) and (p0 - p1).abs().max().item() < 0.5e-3
     per_step = seen[:len(seen) // 2]
     spans = sorted(per_step)
     assert spans[0][0] == 0 and all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:]))
