@@ -156,6 +156,12 @@ typedef struct {
 } ssak_gemm_desc;
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same contraction with float operands, float results and float aux buffers on the fp32 matrix pipe
+ * (v_mfma_f32_32x32x2_f32): the GEMM of the fp32-exact verification mode (ssak_w2v2_config.exact).  The reference computes
+ * these products in fp32 (USE_MIXED_PRECISION = False, ssak/train/transformers/wav2vec_train.py:191-192).  out_f32, split_k,
+ * pads_are_zero are ignored (always float, never split, every access bounds-checked); colsum adds with float atomics. */
+int ssak_gemm_f32(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
+                  const void* aux_in, void* aux_out, void* stream);
 
 /* Grouped form: n <= 8 plain products (no bias / activation / dropout / batches / split-K) that share K, the operand layouts,
  * alpha and the output type run as ONE launch whose tiles are dealt over the whole chip -- the weight gradients
@@ -242,6 +248,12 @@ typedef struct {
    * Linear(d_model, vocab).  input_values is then the feature tensor [B, num_mel_bins, T] (T = 2 * frames, even). */
   int arch;
   int num_mel_bins, max_source_positions;
+  /* exact != 0: the fp32-exact VERIFICATION mode -- activations are stored in float, every product runs through
+   * ssak_gemm_f32 on the fp32 master weights, GELU is the exact erf form, attention takes the unfused GEMM + softmax path;
+   * the engine's sequencing, layouts, row kernels (the same templates as the bf16 mode) and the CTC kernels are then
+   * comparable with the fp32 reference at 1e-4 instead of bf16's 1e-2.  wav2vec2 topologies with the frozen feature
+   * encoder; a few per cent of the bf16 mode's speed.  Workspace sizes double. */
+  int exact;
 } ssak_w2v2_config;
 typedef struct ssak_w2v2 ssak_w2v2;
 

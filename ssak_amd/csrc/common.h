@@ -134,6 +134,115 @@ __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
 }
 __device__ __forceinline__ float gelu_f(float x) { return gelu2((f32x2){x, x})[0]; }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad2((f32x2){x, x})[0]; }
+// ---- storage-type helpers -----------------------------------------------------------------------------------------
+// Every activation kernel is a template over the element type T it loads and stores: bf16 in the production engine, float
+// in the fp32-exact verification mode (ssak_w2v2_config.exact).  Both modes run the same kernel source; what changes with T
+// is the width of a chunk in memory and -- for T = float -- the exact erf GELU instead of the 1.6e-5 logistic fit.
+template <typename T>
+struct Chunk8;  // 8 consecutive elements as they sit in memory
+template <>
+struct Chunk8<bf16> {
+  uint4 q;
+};
+template <>
+struct Chunk8<float> {
+  float4 a, b;
+};
+template <typename T>
+struct Chunk4;
+template <>
+struct Chunk4<bf16> {
+  uint2 q;
+};
+template <>
+struct Chunk4<float> {
+  float4 a;
+};
+template <typename T>
+__device__ __forceinline__ Chunk8<T> ld8(const T* p) {
+  return *reinterpret_cast<const Chunk8<T>*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, const Chunk8<T>& c) {
+  *reinterpret_cast<Chunk8<T>*>(p) = c;
+}
+template <typename T>
+__device__ __forceinline__ Chunk4<T> ld4(const T* p) {
+  return *reinterpret_cast<const Chunk4<T>*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, const Chunk4<T>& c) {
+  *reinterpret_cast<Chunk4<T>*>(p) = c;
+}
+__device__ __forceinline__ void chunk_to_f(const Chunk8<bf16>& c, float* f) {
+  const uint32_t w[4] = {c.q.x, c.q.y, c.q.z, c.q.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void chunk_to_f(const Chunk8<float>& c, float* f) {
+  *reinterpret_cast<float4*>(f) = c.a;
+  *reinterpret_cast<float4*>(f + 4) = c.b;
+}
+__device__ __forceinline__ void chunk_to_f(const Chunk4<bf16>& c, float* f) {
+  const uint32_t w[2] = {c.q.x, c.q.y};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void chunk_to_f(const Chunk4<float>& c, float* f) { *reinterpret_cast<float4*>(f) = c.a; }
+template <typename T>
+__device__ __forceinline__ Chunk8<T> f_to_chunk8(const float* f);
+template <>
+__device__ __forceinline__ Chunk8<bf16> f_to_chunk8<bf16>(const float* f) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2 t = {(bf16)f[2 * i], (bf16)f[2 * i + 1]};
+    w[i] = __builtin_bit_cast(uint32_t, t);
+  }
+  Chunk8<bf16> c;
+  c.q = make_uint4(w[0], w[1], w[2], w[3]);
+  return c;
+}
+template <>
+__device__ __forceinline__ Chunk8<float> f_to_chunk8<float>(const float* f) {
+  Chunk8<float> c;
+  c.a = *reinterpret_cast<const float4*>(f);
+  c.b = *reinterpret_cast<const float4*>(f + 4);
+  return c;
+}
+template <typename T>
+__device__ __forceinline__ Chunk4<T> f_to_chunk4(const float* f);
+template <>
+__device__ __forceinline__ Chunk4<bf16> f_to_chunk4<bf16>(const float* f) {
+  const bf16x2 t0 = {(bf16)f[0], (bf16)f[1]}, t1 = {(bf16)f[2], (bf16)f[3]};
+  Chunk4<bf16> c;
+  c.q = make_uint2(__builtin_bit_cast(uint32_t, t0), __builtin_bit_cast(uint32_t, t1));
+  return c;
+}
+template <>
+__device__ __forceinline__ Chunk4<float> f_to_chunk4<float>(const float* f) {
+  Chunk4<float> c;
+  c.a = *reinterpret_cast<const float4*>(f);
+  return c;
+}
+// GELU / GELU' at the accuracy of the storage type
+template <typename T>
+__device__ __forceinline__ float gelu_s(float x) {
+  if constexpr (sizeof(T) == 4) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+  else return gelu_f(x);
+}
+template <typename T>
+__device__ __forceinline__ float gelu_grad_s(float x) {
+  if constexpr (sizeof(T) == 4)
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+  else return gelu_grad_f(x);
+}
 // counter-based RNG for dropout masks: the forward and backward kernels recompute the same bits from
 // (seed, stream, element index); no mask tensor is stored.  "lowbias32" mixer: 2 integer multiplies (v_mul_lo_u32 is
 // a slow VALU op; the GEMM epilogues and the attention kernels were VALU-bound on a 3-multiply hash).

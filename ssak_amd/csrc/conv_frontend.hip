@@ -19,10 +19,10 @@ namespace {
 constexpr int KS0 = 10, ST0 = 5;  // conv0 taps / stride
 constexpr int FR_STATS = 1024, FR_APPLY = 128;  // frames per workgroup (statistics pass: few, contended fp64 atomics)
 
-template <bool APPLY, int FR0>
+template <typename OT, bool APPLY, int FR0>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    bf16* __restrict__ out, double* __restrict__ stats,
+                                                    OT* __restrict__ out, double* __restrict__ stats,
                                                     const double* __restrict__ sums, int T, int T0, int C) {
   constexpr int NS0 = (FR0 - 1) * ST0 + KS0;
   __shared__ float xs[NS0];
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
       v[j] = a;
     }
     if (APPLY) {
-      bf16x4 o;
+      float o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16)gelu_f((v[j] - mu[j]) * rs[j] * ga[j] + be[j]);
-      *reinterpret_cast<bf16x4*>(out + ((size_t)b * T0 + f0 + f) * C + q * 4) = o;
+      for (int j = 0; j < 4; ++j) o[j] = gelu_s<OT>((v[j] - mu[j]) * rs[j] * ga[j] + be[j]);
+      st4<OT>(out + ((size_t)b * T0 + f0 + f) * C + q * 4, f_to_chunk4<OT>(o));
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
 
 // conv0 (+ bias) only, bf16 channels-last: the layer-norm feature encoder (XLSR) normalises over channels per frame
 // afterwards (LayerNorm + GELU row kernel), so no time statistics are needed here.
+template <typename OT>
 __global__ __launch_bounds__(256) void conv0_bias_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, bf16* __restrict__ out, int T,
+                                                         const float* __restrict__ bias, OT* __restrict__ out, int T,
                                                          int T0, int C) {
   constexpr int FR0 = FR_APPLY, NS0 = (FR0 - 1) * ST0 + KS0;
   __shared__ float xs[NS0];
@@ -133,15 +134,15 @@ __global__ __launch_bounds__(256) void conv0_bias_kernel(const float* __restrict
   }
   __syncthreads();
   for (int f = fli; f < nfr; f += fl) {
-    bf16x4 o;
+    float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float a = bb[j];
 #pragma unroll
       for (int k = 0; k < KS0; ++k) a = fmaf(wr[j][k], xs[f * ST0 + k], a);
-      o[j] = (bf16)a;
+      o[j] = a;
     }
-    *reinterpret_cast<bf16x4*>(out + ((size_t)b * T0 + f0 + f) * C + q * 4) = o;
+    st4<OT>(out + ((size_t)b * T0 + f0 + f) * C + q * 4, f_to_chunk4<OT>(o));
   }
 }
 
@@ -383,13 +384,14 @@ __global__ void conv0_bwd_dw_kernel(const float* __restrict__ partial, int nslab
   dw[e] += s;
 }
 
-__global__ void conv_w_rearrange_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Co, int Ci, int k) {
+template <typename OT>
+__global__ void conv_w_rearrange_kernel(const float* __restrict__ w, OT* __restrict__ out, int Co, int Ci, int k) {
   const long n = (long)Co * Ci * k;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const int kk = (int)(e % k);
     const int ci = (int)((e / k) % Ci);
     const int co = (int)(e / ((long)k * Ci));
-    out[((long)co * k + kk) * Ci + ci] = (bf16)w[e];
+    out[((long)co * k + kk) * Ci + ci] = (OT)w[e];
   }
 }
 
@@ -442,9 +444,10 @@ __global__ __launch_bounds__(1024) void posconv_colnorm_finalize_kernel(const fl
 // one [cg][K] slab through LDS -- slab o for wf (blocks [0, H)), the slab of (group, c) over its cg output channels for wb
 // (blocks [H, 2H)) -- so that global reads and writes are both contiguous (the element-wise version scattered 2-byte
 // stores: 48 us for 38 MB).
+template <typename OT>
 __global__ __launch_bounds__(256) void posconv_materialize_kernel(const float* __restrict__ g, const float* __restrict__ v,
-                                                                  const float* __restrict__ nsq, bf16* __restrict__ wf,
-                                                                  bf16* __restrict__ wb, int H, int cg, int K) {
+                                                                  const float* __restrict__ nsq, OT* __restrict__ wf,
+                                                                  OT* __restrict__ wb, int H, int cg, int K) {
   extern __shared__ float slab[];  // [cg][K + 1]
   const int KP = K + 1;
   const bool back = (int)blockIdx.x >= H;
@@ -456,8 +459,8 @@ __global__ __launch_bounds__(256) void posconv_materialize_kernel(const float* _
       slab[c * KP + k] = g[k] * src[j] * rsqrtf(nsq[k]);
     }
     __syncthreads();
-    bf16* dst = wf + (long)id * K * cg;  // wf[o][k][c]
-    for (int j = threadIdx.x; j < K * cg; j += 256) dst[j] = (bf16)slab[(j % cg) * KP + j / cg];
+    OT* dst = wf + (long)id * K * cg;  // wf[o][k][c]
+    for (int j = threadIdx.x; j < K * cg; j += 256) dst[j] = (OT)slab[(j % cg) * KP + j / cg];
   } else {
     const int grp = id / cg, c = id % cg;
     for (int j = threadIdx.x; j < cg * K; j += 256) {
@@ -465,8 +468,8 @@ __global__ __launch_bounds__(256) void posconv_materialize_kernel(const float* _
       slab[nn * KP + k] = g[k] * v[(((long)grp * cg + nn) * cg + c) * K + k] * rsqrtf(nsq[k]);
     }
     __syncthreads();
-    bf16* dst = wb + (long)id * K * cg;  // wb[group][c][kk][n], kk = K - 1 - k
-    for (int j = threadIdx.x; j < K * cg; j += 256) dst[j] = (bf16)slab[(j % cg) * KP + (K - 1 - j / cg)];
+    OT* dst = wb + (long)id * K * cg;  // wb[group][c][kk][n], kk = K - 1 - k
+    for (int j = threadIdx.x; j < K * cg; j += 256) dst[j] = (OT)slab[(j % cg) * KP + (K - 1 - j / cg)];
   }
 }
 
@@ -495,7 +498,8 @@ __global__ __launch_bounds__(256) void posconv_wbwd_kernel(const float* __restri
     for (int k = threadIdx.x; k < K; k += 256) dg[k] += dot[k] * rsqrtf(nsq[k]);
 }
 
-__global__ void posconv_pack_kernel(const bf16* __restrict__ h, bf16* __restrict__ pg, int B, int F, int H, int G,
+template <typename T>
+__global__ void posconv_pack_kernel(const T* __restrict__ h, T* __restrict__ pg, int B, int F, int H, int G,
                                     int lead, int RS, long rows_total) {
   const int cg = H / G, cpr = cg >> 3;
   const long n = rows_total * G * cpr;
@@ -504,12 +508,12 @@ __global__ void posconv_pack_kernel(const bf16* __restrict__ h, bf16* __restrict
     const long r = (e / cpr) % rows_total;
     const int g = (int)(e / ((long)cpr * rows_total));
     const long rr = r - lead;
-    uint4 val = make_uint4(0u, 0u, 0u, 0u);
+    Chunk8<T> val = {};
     if (rr >= 0) {
       const int b = (int)(rr / RS), t = (int)(rr % RS);
-      if (b < B && t < F) val = *reinterpret_cast<const uint4*>(h + ((long)b * F + t) * H + g * cg + cc * 8);
+      if (b < B && t < F) val = ld8<T>(h + ((long)b * F + t) * H + g * cg + cc * 8);
     }
-    *reinterpret_cast<uint4*>(pg + ((long)g * rows_total + r) * cg + cc * 8) = val;
+    st8<T>(pg + ((long)g * rows_total + r) * cg + cc * 8, val);
   }
 }
 
@@ -592,19 +596,20 @@ size_t k_conv0_stats_doubles(int B, int T0, int C) {
   return (size_t)B * 2 * C + (size_t)B * ssak_cdiv(T0, FR_STATS) * std::max(2 * C, NMOM);
 }
 
-int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,
-                    int B, int T, int T0, int C, int ksize, int stride, hipStream_t st) {
+template <typename OT>
+int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const float* beta, OT* out, double* stats,
+                      int B, int T, int T0, int C, int ksize, int stride, hipStream_t st) {
   SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
   SSAK_REQUIRE(T0 == (T - KS0) / ST0 + 1 && T0 > 0, "conv0: T0 mismatch");
   // stats layout: [B][2C] ordered sums | [B][nblk][2C] per-workgroup partials   (k_conv0_stats_doubles(B, T0, C) doubles)
   const int nblk = ssak_cdiv(T0, FR_STATS);
-  ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * 2.0), st);  // waveform in, bf16 channels-last out
+  ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * sizeof(OT)), st);  // waveform in, channels-last out
   double* sums = stats;
   double* partial = stats + (size_t)B * 2 * C;
   static const bool direct_stats = getenv("SSAK_CONV0_DIRECT_STATS") != nullptr;  // development: the convolution-pass statistics
   if (direct_stats) {
-    conv0_kernel<false, FR_STATS><<<dim3(nblk, B), 256, 0, st>>>(x, w, gamma, beta, out, partial, nullptr, T, T0, C);
+    conv0_kernel<OT, false, FR_STATS><<<dim3(nblk, B), 256, 0, st>>>(x, w, gamma, beta, out, partial, nullptr, T, T0, C);
     SSAK_LAUNCH_CHECK();
     conv0_stats_finalize_kernel<<<dim3(ssak_cdiv(2 * C, 256), B), 256, 0, st>>>(partial, nblk, C, sums);
     SSAK_LAUNCH_CHECK();
@@ -614,29 +619,32 @@ int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const fl
     conv0_channel_stats_kernel<<<dim3(ssak_cdiv(C, 256), B), 256, 0, st>>>(partial, nblk, w, C, sums);
     SSAK_LAUNCH_CHECK();
   }
-  conv0_kernel<true, FR_APPLY><<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, gamma, beta, out, nullptr, sums, T, T0, C);
+  conv0_kernel<OT, true, FR_APPLY><<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, gamma, beta, out, nullptr, sums, T, T0, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_conv0_bias(const float* x, const float* w, const float* bias, bf16* out, int B, int T, int T0, int C, int ksize,
-                 int stride, hipStream_t st) {
+template <typename OT>
+int k_conv0_bias_t(const float* x, const float* w, const float* bias, OT* out, int B, int T, int T0, int C, int ksize,
+                   int stride, hipStream_t st) {
   SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
-  ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * 2.0), st);
-  conv0_bias_kernel<<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, bias, out, T, T0, C);
+  ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * sizeof(OT)), st);
+  conv0_bias_kernel<OT><<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, bias, out, T, T0, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_conv_weight_rearrange(const float* w, bf16* out, int Co, int Ci, int k, hipStream_t st) {
-  conv_w_rearrange_kernel<<<min(2048, ssak_cdiv((long)Co * Ci * k, 256)), 256, 0, st>>>(w, out, Co, Ci, k);
+template <typename OT>
+int k_conv_weight_rearrange_t(const float* w, OT* out, int Co, int Ci, int k, hipStream_t st) {
+  conv_w_rearrange_kernel<OT><<<min(2048, ssak_cdiv((long)Co * Ci * k, 256)), 256, 0, st>>>(w, out, Co, Ci, k);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, float* norms, int H, int G, int K,
-                      hipStream_t st) {
+template <typename OT>
+int k_posconv_prepare_t(const float* g, const float* v, OT* w_fwd, OT* w_bwd, float* norms, int H, int G, int K,
+                        hipStream_t st) {
   SSAK_REQUIRE(K <= 1024 && H % G == 0 && ((H / G) & 7) == 0, "posconv: K=%d <= 1024 and (H/G)=%d %% 8 == 0 required", K, H / G);
   const int cg = H / G;
   // norms layout: [K] ||v||^2 | [K] dot scratch | [H][K] per-workgroup partials
@@ -647,7 +655,7 @@ int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, 
   posconv_colnorm_finalize_kernel<<<ssak_cdiv(K, 64), 1024, 0, st>>>(partial, H, K, norms);
   SSAK_LAUNCH_CHECK();
   SSAK_REQUIRE((size_t)cg * (K + 1) * sizeof(float) <= 64 * 1024, "posconv: (H/G) x K slab does not fit in LDS");
-  posconv_materialize_kernel<<<2 * H, 256, (size_t)cg * (K + 1) * sizeof(float), st>>>(g, v, norms, w_fwd, w_bwd, H, cg, K);
+  posconv_materialize_kernel<OT><<<2 * H, 256, (size_t)cg * (K + 1) * sizeof(float), st>>>(g, v, norms, w_fwd, w_bwd, H, cg, K);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -669,12 +677,13 @@ int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const 
   return SSAK_OK;
 }
 
-int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, hipStream_t st) {
+template <typename T>
+int k_posconv_pack_t(const T* h, T* pg, int B, int F, int H, int G, int K, hipStream_t st) {
   const int lead = K / 2, RS = F + K;
   const long rows_total = lead + (long)B * RS + K;
   const long n = rows_total * G * (H / G / 8);
-  ProfScope prof_scope(PROF_ROWWISE, (double)B * F * H * 4.0, st);
-  posconv_pack_kernel<<<min(4096, ssak_cdiv(n, 256)), 256, 0, st>>>(h, pg, B, F, H, G, lead, RS, rows_total);
+  ProfScope prof_scope(PROF_ROWWISE, (double)B * F * H * 2.0 * sizeof(T), st);
+  posconv_pack_kernel<T><<<min(4096, ssak_cdiv(n, 256)), 256, 0, st>>>(h, pg, B, F, H, G, lead, RS, rows_total);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -725,3 +734,13 @@ int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, cons
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
+
+#define SSAK_INSTANTIATE_CONV_KERNELS(T)                                                                                       \
+  template int k_conv0_gn_gelu_t<T>(const float*, const float*, const float*, const float*, T*, double*, int, int, int, int,   \
+                                    int, int, hipStream_t);                                                                    \
+  template int k_conv0_bias_t<T>(const float*, const float*, const float*, T*, int, int, int, int, int, int, hipStream_t);     \
+  template int k_conv_weight_rearrange_t<T>(const float*, T*, int, int, int, hipStream_t);                                     \
+  template int k_posconv_prepare_t<T>(const float*, const float*, T*, T*, float*, int, int, int, hipStream_t);                 \
+  template int k_posconv_pack_t<T>(const T*, T*, int, int, int, int, int, hipStream_t);
+SSAK_INSTANTIATE_CONV_KERNELS(bf16)
+SSAK_INSTANTIATE_CONV_KERNELS(float)

@@ -57,56 +57,81 @@ struct ReduceSink {
 extern thread_local ReduceSink* g_reduce_sink;
 int k_reduce_flush(ReduceSink& sink, hipStream_t st);
 
-// norm_act.hip
+// norm_act.hip -- row / element-wise kernels, templates over the activation storage type T (bf16: production engine,
+// float: fp32-exact verification mode); explicitly instantiated for both in norm_act.hip
+template <typename T>
+int k_layernorm_fwd_t(const T* y, const T* res, const float* gamma, const float* beta, T* r_out, T* out,
+                      float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
+                      hipStream_t st, const DropSpec& mid = DropSpec(), bool post_gelu = false);
+template <typename T>
+int k_layernorm_bwd_t(const T* g1, const T* g2, const T* r, const float* mean, const float* rstd,
+                      const float* gamma, const T* g_res, T* dr, T* dy, float* dgamma, float* dbeta,
+                      float* partial /*[LN_BWD_BLOCKS*3*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
+                      hipStream_t st, const DropSpec& mid = DropSpec(), float* dy_colsum = nullptr /*[C] += column sums of dy*/,
+                      const float* post_gelu_beta = nullptr /*forward was gelu(LN(x)): beta of that LN*/);
+constexpr int LN_BWD_BLOCKS = 512;
+template <typename T>
+int k_softmax_fwd_t(const T* S, T* P, T* Pd, const int32_t* klens, int rows, int cols, int ld,
+                    int rows_per_batch, const DropSpec& drop, hipStream_t st);
+template <typename T>
+int k_softmax_bwd_t(const T* dPd, const T* P, T* dS, int rows, int cols, int ld, const DropSpec& drop,
+                    hipStream_t st);
+// out[n] += column sums of X; with a scratch of >= min(64, ceil(M/32)) * N floats the sum is two-stage and deterministic
+// (without one: float atomics).  rowmask / flens / F: only masked, non-padding rows (SpecAugment embedding gradient).
+template <typename T>
+int k_colsum_t(const T* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0,
+               const uint8_t* rowmask = nullptr, const int32_t* flens = nullptr, int F = 0);
+int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st);
+template <typename T>
+int k_specaug_fwd_t(T* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
+                    hipStream_t st);
+template <typename T>
+int k_specaug_bwd_t(T* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
+                    hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
+template <typename T>
+int k_gelu_grad_mul_t(const T* dy, const T* pre, T* out, long n, hipStream_t st);
+template <typename T>
+int k_add_t(const T* a, const T* b, T* out, long n, hipStream_t st);
+// bf16-named forms used by the other kernel files (sb_head.hip, ...)
 int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
                     float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
                     hipStream_t st, const DropSpec& mid = DropSpec(), bool post_gelu = false);
 int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
                     const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
-                    float* partial /*[LN_BWD_BLOCKS*3*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
-                    hipStream_t st, const DropSpec& mid = DropSpec(), float* dy_colsum = nullptr /*[C] += column sums of dy*/,
-                    const float* post_gelu_beta = nullptr /*forward was gelu(LN(x)): beta of that LN*/);
-constexpr int LN_BWD_BLOCKS = 512;
-int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
-                  int rows_per_batch, const DropSpec& drop, hipStream_t st);
-int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
-                  hipStream_t st);
-// out[n] += column sums of X; with a scratch of >= min(64, ceil(M/32)) * N floats the sum is two-stage and deterministic
-// (without one: float atomics).  rowmask / flens / F: only masked, non-padding rows (SpecAugment embedding gradient).
+                    float* partial, int M, int C, const DropSpec& pre, const DropSpec& post,
+                    hipStream_t st, const DropSpec& mid = DropSpec(), float* dy_colsum = nullptr,
+                    const float* post_gelu_beta = nullptr);
 int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0,
              const uint8_t* rowmask = nullptr, const int32_t* flens = nullptr, int F = 0);
-int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st);
-int k_specaug_fwd(bf16* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
-                  hipStream_t st);
-int k_specaug_bwd(bf16* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
-                  hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0);
-
-int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStream_t st);
-int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st);
 
 // conv_frontend.hip
 size_t k_conv0_stats_doubles(int B, int T0, int C);
-int k_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, bf16* out, double* stats,
-                    int B, int T, int T0, int C, int ksize, int stride, hipStream_t st);
+template <typename T>
+int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const float* beta, T* out, double* stats,
+                      int B, int Tn, int T0, int C, int ksize, int stride, hipStream_t st);
 // dw [C][ksize] += sum over frames of d[b,t,c] * x[b, stride*t + k] (conv0 weight gradient of the layer-norm feature encoder,
 // Cin = 1); scratch >= k_conv0_wgrad_scratch_floats() floats; deterministic (per-workgroup partials, fixed-order sum)
 size_t k_conv0_wgrad_scratch_floats(int B, int C, int ksize);
 int k_conv0_wgrad(const bf16* d, const float* x, float* dw, float* scratch, int B, int T, int T0, int C, int ksize, int stride,
                   hipStream_t st);
-int k_conv0_bias(const float* x, const float* w, const float* bias, bf16* out, int B, int T, int T0, int C, int ksize,
-                 int stride, hipStream_t st);
+template <typename T>
+int k_conv0_bias_t(const float* x, const float* w, const float* bias, T* out, int B, int Tn, int T0, int C, int ksize,
+                   int stride, hipStream_t st);
 int k_col2im(const bf16* dxcol, bf16* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st);
 int k_sum_slabs(const float* slabs, int nb, long n, float* out, hipStream_t st);
 size_t k_conv0_bwd_scratch_floats(int B, int T0, int C);
 int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, const float* beta, const bf16* dy,
                         const double* sums, float* scratch, float* dw, float* dgamma, float* dbeta, int B, int T, int T0, int C,
                         hipStream_t st);
-int k_conv_weight_rearrange(const float* w, bf16* out, int Co, int Ci, int k, hipStream_t st);
-int k_posconv_prepare(const float* g, const float* v, bf16* w_fwd, bf16* w_bwd, float* norms, int H, int G, int K,
-                      hipStream_t st);
+template <typename T>
+int k_conv_weight_rearrange_t(const float* w, T* out, int Co, int Ci, int k, hipStream_t st);
+template <typename T>
+int k_posconv_prepare_t(const float* g, const float* v, T* w_fwd, T* w_bwd, float* norms, int H, int G, int K,
+                        hipStream_t st);
 int k_posconv_weight_bwd(const float* dw, const float* g, const float* v, const float* norms, float* dg, float* dv,
                          int H, int G, int K, hipStream_t st);
-int k_posconv_pack(const bf16* h, bf16* pg, int B, int F, int H, int G, int K, hipStream_t st);
+template <typename T>
+int k_posconv_pack_t(const T* h, T* pg, int B, int F, int H, int G, int K, hipStream_t st);
 
 // attention.hip (fused, head_dim 64)
 bool k_attention_supported(int H, int nh);

@@ -16,56 +16,23 @@ namespace {
 
 constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows per workgroup
 
-__device__ __forceinline__ void unpack8(const uint4& q, float* f) {
-  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __uint_as_float(w[i] << 16);
-    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-  }
-}
-__device__ __forceinline__ uint4 pack8(const float* f) {
-  uint32_t w[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bf16x2 t = {(bf16)f[2 * i], (bf16)f[2 * i + 1]};
-    w[i] = __builtin_bit_cast(uint32_t, t);
-  }
-  return make_uint4(w[0], w[1], w[2], w[3]);
+// chunk of VEC elements of type T (common.h: Chunk8 / Chunk4)
+template <typename T, int VEC>
+using ChunkT = typename std::conditional<VEC == 8, Chunk8<T>, Chunk4<T>>::type;
+template <typename T, int VEC>
+__device__ __forceinline__ ChunkT<T, VEC> f_to_chunk(const float* f) {
+  if constexpr (VEC == 8) return f_to_chunk8<T>(f);
+  else return f_to_chunk4<T>(f);
 }
 
-template <int VEC>
-__device__ __forceinline__ void unpackv(const uint4& q, float* f) {
-  unpack8(q, f);
-}
-template <int VEC>
-__device__ __forceinline__ void unpackv(const uint2& q, float* f) {
-  const uint32_t w[2] = {q.x, q.y};
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    f[2 * i] = __uint_as_float(w[i] << 16);
-    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-  }
-}
-template <int VEC>
-__device__ __forceinline__ typename std::conditional<VEC == 8, uint4, uint2>::type packv(const float* f);
-template <>
-__device__ __forceinline__ uint4 packv<8>(const float* f) {
-  return pack8(f);
-}
-template <>
-__device__ __forceinline__ uint2 packv<4>(const float* f) {
-  const bf16x2 t0 = {(bf16)f[0], (bf16)f[1]}, t1 = {(bf16)f[2], (bf16)f[3]};
-  return make_uint2(__builtin_bit_cast(uint32_t, t0), __builtin_bit_cast(uint32_t, t1));
-}
-
+template <typename T>
 struct LnFwdParams {
-  const bf16* y;      // [M,C] branch output (may be null -> r = res)
-  const bf16* res;    // [M,C] residual (may be null)
+  const T* y;         // [M,C] branch output (may be null -> r = res)
+  const T* res;       // [M,C] residual (may be null)
   const float* gamma;
   const float* beta;
-  bf16* r_out;        // [M,C] r = res + drop(y)   (may be null)
-  bf16* out;          // [M,C] LN(r) (then optional post-dropout); null -> no LN (plain residual add)
+  T* r_out;           // [M,C] r = res + drop(y)   (may be null)
+  T* out;             // [M,C] LN(r) (then optional post-dropout); null -> no LN (plain residual add)
   float* mean;
   float* rstd;
   int M, C;
@@ -78,8 +45,8 @@ struct LnFwdParams {
   int post_gelu;                    // out = gelu(LN(r))  (layer-norm feature-encoder conv layers)
 };
 
-template <int NCH>
-__global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p) {
+template <typename T, int NCH>
+__global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams<T> p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= p.M) return;
@@ -95,7 +62,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
       const size_t o = (size_t)row * p.C + ch * 8;
       __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       if (p.y) {
-        unpack8(*reinterpret_cast<const uint4*>(p.y + o), v[i]);
+        chunk_to_f(ld8<T>(p.y + o), v[i]);
         if (p.pre_thresh) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[i][k] = keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh) ? v[i][k] * p.pre_scale : 0.f;
@@ -103,7 +70,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
       }
       if (p.res) {
         float r[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.res + o), r);
+        chunk_to_f(ld8<T>(p.res + o), r);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[i][k] += r[k];
       }
@@ -112,10 +79,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
         for (int k = 0; k < 8; ++k) v[i][k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? v[i][k] * p.mid_scale : 0.f;
       }
       if (p.r_out) {
-        // round through bf16 so that forward and backward see the same LN input
-        const uint4 q = pack8(v[i]);
-        *reinterpret_cast<uint4*>(p.r_out + o) = q;
-        unpack8(q, v[i]);
+        // round through the storage type so that forward and backward see the same LN input
+        const Chunk8<T> q = f_to_chunk8<T>(v[i]);
+        st8<T>(p.r_out + o, q);
+        chunk_to_f(q, v[i]);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += v[i][k];
@@ -152,24 +119,25 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams p
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         w[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
-        if (p.post_gelu) w[k] = gelu_f(w[k]);
+        if (p.post_gelu) w[k] = gelu_s<T>(w[k]);
         if (p.post_thresh) w[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? w[k] * p.post_scale : 0.f;
       }
-      *reinterpret_cast<uint4*>(p.out + o) = pack8(w);
+      st8<T>(p.out + o, f_to_chunk8<T>(w));
     }
   }
 }
 
+template <typename T>
 struct LnBwdParams {
-  const bf16* g1;     // [M,C] grad wrt (post-dropout) LN output
-  const bf16* g2;     // [M,C] second contribution or null
-  const bf16* r;      // [M,C] saved LN input
+  const T* g1;        // [M,C] grad wrt (post-dropout) LN output
+  const T* g2;        // [M,C] second contribution or null
+  const T* r;         // [M,C] saved LN input
   const float* mean;
   const float* rstd;
   const float* gamma;
-  const bf16* g_res;  // [M,C] extra gradient added to dr AFTER the LN backward (pre-LN residual stream) or null
-  bf16* dr;           // [M,C] grad wrt r (residual path)
-  bf16* dy;           // [M,C] grad wrt y = dr * premask/(1-p)  (null when no pre-dropout: use dr)
+  const T* g_res;     // [M,C] extra gradient added to dr AFTER the LN backward (pre-LN residual stream) or null
+  T* dr;              // [M,C] grad wrt r (residual path)
+  T* dy;              // [M,C] grad wrt y = dr * premask/(1-p)  (null when no pre-dropout: use dr)
   float* dgamma;      // [C] += (finalize kernel)
   float* dbeta;
   float* partial;     // [gridDim.x][3][C] per-workgroup column partials
@@ -188,9 +156,9 @@ struct LnBwdParams {
 // VEC = elements per lane chunk: 8 (16-byte accesses) in general; 4 (8-byte accesses) when that divides the row evenly over
 // the 64 lanes -- C = 768 is 96 chunks of 8, i.e. 64 + 32 lanes (a quarter of the lane slots and of the registers idle), but
 // exactly 3 chunks of 4 per lane.
-template <int NCH, int VEC>
-__global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p) {
-  using VecT = typename std::conditional<VEC == 8, uint4, uint2>::type;
+template <typename T, int NCH, int VEC>
+__global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T> p) {
+  using VecT = ChunkT<T, VEC>;
   __shared__ float red[3][ROW_THREADS / 64][NCH * VEC][64];  // [dgamma|dbeta|dy sum][wave][slot][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.C / VEC;
@@ -253,19 +221,19 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
         const size_t o = (size_t)row * p.C + ch * VEC;
         __builtin_assume((o & (VEC - 1)) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
         float a[VEC], x[VEC];
-        unpackv<VEC>(ca[i], a);
+        chunk_to_f(ca[i], a);
         if (p.g2) {
           float b2[VEC];
-          unpackv<VEC>(cb[i], b2);
+          chunk_to_f(cb[i], b2);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) a[k] += b2[k];
         }
-        unpackv<VEC>(cx[i], x);
+        chunk_to_f(cx[i], x);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           if (p.post_thresh) a[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? a[k] * p.post_scale : 0.f;
           xh[i][k] = (x[k] - mean) * rstd;
-          if (p.beta) a[k] *= gelu_grad_f(fmaf(xh[i][k], gm[i][k], bt[i][k]));
+          if (p.beta) a[k] *= gelu_grad_s<T>(fmaf(xh[i][k], gm[i][k], bt[i][k]));
           ag[i][k] += a[k] * xh[i][k];
           ab[i][k] += a[k];
           dyv[i][k] = a[k] * gm[i][k];
@@ -287,7 +255,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
         for (int k = 0; k < VEC; ++k) d[k] = rstd * (dyv[i][k] - s1 - xh[i][k] * s2);
         if (p.g_res) {
           float e[VEC];
-          unpackv<VEC>(*reinterpret_cast<const VecT*>(p.g_res + o), e);
+          chunk_to_f(*reinterpret_cast<const VecT*>(p.g_res + o), e);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) d[k] += e[k];
         }
@@ -295,14 +263,14 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams p
 #pragma unroll
           for (int k = 0; k < VEC; ++k) d[k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? d[k] * p.mid_scale : 0.f;
         }
-        *reinterpret_cast<VecT*>(p.dr + o) = packv<VEC>(d);
+        *reinterpret_cast<VecT*>(p.dr + o) = f_to_chunk<T, VEC>(d);
         if (p.dy) {
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
             d[k] = (!p.pre_thresh || keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh)) ? d[k] * p.pre_scale : 0.f;
-            ay[i][k] += d[k];  // fp32 values, before the bf16 rounding of the store
+            ay[i][k] += d[k];  // fp32 values, before the rounding of the store
           }
-          *reinterpret_cast<VecT*>(p.dy + o) = packv<VEC>(d);
+          *reinterpret_cast<VecT*>(p.dy + o) = f_to_chunk<T, VEC>(d);
         }
       }
     }
@@ -393,10 +361,11 @@ __global__ __launch_bounds__(1024) void reduce_jobs_kernel(const ReduceTable t) 
 // ---------------------------------------------------------------------------------------------- softmax
 // Scores arrive in bf16 (what the bf16 QK^T GEMM produces); statistics are fp32.  One wave per row; a lane owns
 // 16-byte chunks (8 consecutive keys) so every access is a full-width vector load/store.
+template <typename T>
 struct SoftmaxParams {
-  const bf16* S;        // [rows, ld] scores (already scaled)
-  bf16* P;              // [rows, ld] probabilities (pre-dropout); pad columns [cols, ld) are written as 0
-  bf16* Pd;             // [rows, ld] dropped probabilities or null
+  const T* S;           // [rows, ld] scores (already scaled)
+  T* P;                 // [rows, ld] probabilities (pre-dropout); pad columns [cols, ld) are written as 0
+  T* Pd;                // [rows, ld] dropped probabilities or null
   const int32_t* klens; // [B] valid keys per utterance or null
   int rows, cols, ld, rows_per_batch;
   uint64_t seed;
@@ -404,8 +373,8 @@ struct SoftmaxParams {
   float scale;
 };
 
-template <int NCH>
-__global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxParams p) {
+template <typename T, int NCH>
+__global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxParams<T> p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= p.rows) return;
@@ -420,7 +389,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxP
     for (int k = 0; k < 8; ++k) v[i][k] = -INFINITY;
     if (ch < nch) {
       float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.S + (size_t)row * p.ld + ch * 8), f);
+      chunk_to_f(ld8<T>(p.S + (size_t)row * p.ld + ch * 8), f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         v[i][k] = (ch * 8 + k < kl) ? f[k] : -INFINITY;
@@ -447,28 +416,29 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxP
       float pr[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) pr[k] = v[i][k] * inv;
-      *reinterpret_cast<uint4*>(p.P + o) = pack8(pr);
+      st8<T>(p.P + o, f_to_chunk8<T>(pr));
       if (p.Pd) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) pr[k] = (!p.thresh || keep_bit(p.seed, p.stream, o + k, p.thresh)) ? pr[k] * p.scale : 0.f;
-        *reinterpret_cast<uint4*>(p.Pd + o) = pack8(pr);
+        st8<T>(p.Pd + o, f_to_chunk8<T>(pr));
       }
     }
   }
 }
 
+template <typename T>
 struct SoftmaxBwdParams {
-  const bf16* dPd;   // [rows, ld] grad wrt dropped probabilities
-  const bf16* P;     // [rows, ld]
-  bf16* dS;          // [rows, ld]; pad columns written as 0
+  const T* dPd;      // [rows, ld] grad wrt dropped probabilities
+  const T* P;        // [rows, ld]
+  T* dS;             // [rows, ld]; pad columns written as 0
   int rows, cols, ld;
   uint64_t seed;
   uint32_t stream, thresh;
   float scale;
 };
 
-template <int NCH>
-__global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxBwdParams p) {
+template <typename T, int NCH>
+__global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxBwdParams<T> p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= p.rows) return;
@@ -487,8 +457,8 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
       const size_t o = (size_t)row * p.ld + ch * 8;
       __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       float g[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.P + o), pr[i]);
-      unpack8(*reinterpret_cast<const uint4*>(p.dPd + o), g);
+      chunk_to_f(ld8<T>(p.P + o), pr[i]);
+      chunk_to_f(ld8<T>(p.dPd + o), g);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const bool in = ch * 8 + k < p.cols;
@@ -506,7 +476,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
       float d[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) d[k] = pr[i][k] * (dp[i][k] - dot);
-      *reinterpret_cast<uint4*>(p.dS + (size_t)row * p.ld + ch * 8) = pack8(d);
+      st8<T>(p.dS + (size_t)row * p.ld + ch * 8, f_to_chunk8<T>(d));
     }
   }
 }
@@ -516,7 +486,8 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
 // With a `partial` buffer [gridDim.y][N] every group writes its own row (summed afterwards in a fixed order: deterministic);
 // without one the groups add into `out` atomically.  rowmask (optional): only rows with rowmask[m] != 0 that are not
 // padding (frame < flens[m / F]) count -- the gradient of the SpecAugment mask embedding.
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, long ld, int M, int N, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, float* __restrict__ out,
                                                      float* __restrict__ partial, const uint8_t* __restrict__ rowmask,
                                                      const int32_t* __restrict__ flens, int F) {
   __shared__ float red[32][65];
@@ -527,7 +498,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X,
     for (int m = blockIdx.y * 32 + ry; m < M; m += gridDim.y * 32) {
       if (rowmask && (!rowmask[m] || (flens && m % F >= flens[m / F]))) continue;
       float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(X + (size_t)m * ld + c0), f);
+      chunk_to_f(ld8<T>(X + (size_t)m * ld + c0), f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += f[k];
     }
@@ -578,17 +549,19 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restr
 }
 
 // SpecAugment + padding: h[row,:] = embed where mask[row]; = 0 where frame >= flen[b]
-__global__ void specaug_fwd_kernel(bf16* __restrict__ h, const uint8_t* __restrict__ mask,
+template <typename T>
+__global__ void specaug_fwd_kernel(T* __restrict__ h, const uint8_t* __restrict__ mask,
                                    const int32_t* __restrict__ flens, const float* __restrict__ embed, int M, int F, int C) {
   const int row = blockIdx.x;
   const int b = row / F, t = row % F;
   const bool pad = flens && t >= flens[b];
   const bool mk = mask && mask[row];
   if (!pad && !mk) return;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) h[(size_t)row * C + c] = pad ? (bf16)0.f : (bf16)embed[c];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) h[(size_t)row * C + c] = pad ? (T)0.f : (T)embed[c];
 }
 // backward: rows that were overwritten pass no gradient; masked rows feed d embed
-__global__ void specaug_bwd_kernel(bf16* __restrict__ dh, const uint8_t* __restrict__ mask,
+template <typename T>
+__global__ void specaug_bwd_kernel(T* __restrict__ dh, const uint8_t* __restrict__ mask,
                                    const int32_t* __restrict__ flens, float* __restrict__ dembed, int M, int F, int C) {
   const int row = blockIdx.x;
   const int b = row / F, t = row % F;
@@ -596,28 +569,30 @@ __global__ void specaug_bwd_kernel(bf16* __restrict__ dh, const uint8_t* __restr
   const bool mk = mask && mask[row];
   if (!pad && !mk) return;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    dh[(size_t)row * C + c] = (bf16)0.f;  // (the masked rows' sum -> d embed is taken before, by the masked column sum)
+    dh[(size_t)row * C + c] = (T)0.f;  // (the masked rows' sum -> d embed is taken before, by the masked column sum)
   }
 }
 
-__global__ void gelu_grad_mul_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ pre, bf16* __restrict__ out, long n8) {
+template <typename T>
+__global__ void gelu_grad_mul_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, long n8) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float a[8], x[8];
-    unpack8(reinterpret_cast<const uint4*>(dy)[i], a);
-    unpack8(reinterpret_cast<const uint4*>(pre)[i], x);
+    chunk_to_f(ld8<T>(dy + 8 * i), a);
+    chunk_to_f(ld8<T>(pre + 8 * i), x);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] *= gelu_grad_f(x[k]);
-    reinterpret_cast<uint4*>(out)[i] = pack8(a);
+    for (int k = 0; k < 8; ++k) a[k] *= gelu_grad_s<T>(x[k]);
+    st8<T>(out + 8 * i, f_to_chunk8<T>(a));
   }
 }
-__global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out, long n8) {
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long n8) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float x[8], y[8];
-    unpack8(reinterpret_cast<const uint4*>(a)[i], x);
-    unpack8(reinterpret_cast<const uint4*>(b)[i], y);
+    chunk_to_f(ld8<T>(a + 8 * i), x);
+    chunk_to_f(ld8<T>(b + 8 * i), y);
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] += y[k];
-    reinterpret_cast<uint4*>(out)[i] = pack8(x);
+    st8<T>(out + 8 * i, f_to_chunk8<T>(x));
   }
 }
 
@@ -629,11 +604,12 @@ float scale_of(float p) { return p <= 0.f ? 1.f : 1.f / (1.f - (float)thresh_of(
 
 // ---- internal C++ entry points used by the engine (declared in kernels.h) ------------------------
 
-int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
-                    float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
-                    hipStream_t st, const DropSpec& mid, bool post_gelu) {
+template <typename T>
+int k_layernorm_fwd_t(const T* y, const T* res, const float* gamma, const float* beta, T* r_out, T* out,
+                      float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
+                      hipStream_t st, const DropSpec& mid, bool post_gelu) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
-  LnFwdParams p{y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, pre.seed,
+  LnFwdParams<T> p{y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
                 scale_of(pre.p), scale_of(post.p),
                 mid.stream, thresh_of(mid.p), scale_of(mid.p), post_gelu ? 1 : 0};
@@ -641,22 +617,23 @@ int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const fl
   const int nch = ssak_cdiv(C / 8, 64);
   ProfScope prof_scope(PROF_LN_FWD, (double)M * C * 2.0 * ((y != nullptr) + (res != nullptr) + (r_out != nullptr) + (out != nullptr)), st);
   if (nch == 1)
-    ln_fwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_fwd_kernel<T, 1><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
-    ln_fwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_fwd_kernel<T, 2><<<grid, ROW_THREADS, 0, st>>>(p);
   else
-    ln_fwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_fwd_kernel<T, 3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
-                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
-                    float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st,
-                    const DropSpec& mid, float* dy_colsum, const float* post_gelu_beta) {
+template <typename T>
+int k_layernorm_bwd_t(const T* g1, const T* g2, const T* r, const float* mean, const float* rstd,
+                      const float* gamma, const T* g_res, T* dr, T* dy, float* dgamma, float* dbeta,
+                      float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st,
+                      const DropSpec& mid, float* dy_colsum, const float* post_gelu_beta) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm_bwd: C=%d must be a multiple of 8 and <= 1536", C);
   SSAK_REQUIRE(!dy_colsum || dy, "layernorm_bwd: the dy column sum needs the dy output");
-  LnBwdParams p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, post_gelu_beta, M, C, pre.seed,
+  LnBwdParams<T> p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, post_gelu_beta, M, C, pre.seed,
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
                 scale_of(pre.p), scale_of(post.p), 1,
                 mid.stream, thresh_of(mid.p), scale_of(mid.p)};
@@ -666,13 +643,13 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   const int nch = ssak_cdiv(C / 8, 64);
   ProfScope prof_scope(PROF_LN_BWD, (double)M * C * 2.0 * (2 + (g2 != nullptr) + (g_res != nullptr) + 1 + (dy != nullptr && dy != dr)), st);
   if (C % 256 == 0 && C / 256 == 3 && (C / 8) % 64 != 0)  // (768: three chunks of 4 per lane, every lane busy)
-    ln_bwd_kernel<3, 4><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_bwd_kernel<T, 3, 4><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 1)
-    ln_bwd_kernel<1, 8><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_bwd_kernel<T, 1, 8><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
-    ln_bwd_kernel<2, 8><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_bwd_kernel<T, 2, 8><<<grid, ROW_THREADS, 0, st>>>(p);
   else
-    ln_bwd_kernel<3, 8><<<grid, ROW_THREADS, 0, st>>>(p);
+    ln_bwd_kernel<T, 3, 8><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
   if (g_reduce_sink && g_reduce_sink->n + 3 <= ReduceSink::CAP) {  // second stage queued: one launch for many (kernels.h)
     g_reduce_sink->push(partial, 3L * C, grid, C, dgamma);
@@ -685,49 +662,52 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
   return SSAK_OK;
 }
 
-int k_softmax_fwd(const bf16* S, bf16* P, bf16* Pd, const int32_t* klens, int rows, int cols, int ld,
-                  int rows_per_batch, const DropSpec& drop, hipStream_t st) {
+template <typename T>
+int k_softmax_fwd_t(const T* S, T* P, T* Pd, const int32_t* klens, int rows, int cols, int ld,
+                    int rows_per_batch, const DropSpec& drop, hipStream_t st) {
   SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld & 7) == 0 && ld <= 1536, "softmax: cols=%d ld=%d unsupported (ld %% 8 == 0, <= 1536)", cols, ld);
-  SoftmaxParams p{S, P, Pd, klens, rows, cols, ld, rows_per_batch, drop.seed, drop.stream, thresh_of(drop.p),
+  SoftmaxParams<T> p{S, P, Pd, klens, rows, cols, ld, rows_per_batch, drop.seed, drop.stream, thresh_of(drop.p),
                   scale_of(drop.p)};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
   const int nch = ssak_cdiv(ld / 8, 64);
   ProfScope prof_scope(PROF_SOFTMAX, (double)rows * ld * 2.0 * (2 + (Pd != nullptr)), st);
   if (nch == 1)
-    softmax_fwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_fwd_kernel<T, 1><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
-    softmax_fwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_fwd_kernel<T, 2><<<grid, ROW_THREADS, 0, st>>>(p);
   else
-    softmax_fwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_fwd_kernel<T, 3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_softmax_bwd(const bf16* dPd, const bf16* P, bf16* dS, int rows, int cols, int ld, const DropSpec& drop,
-                  hipStream_t st) {
+template <typename T>
+int k_softmax_bwd_t(const T* dPd, const T* P, T* dS, int rows, int cols, int ld, const DropSpec& drop,
+                    hipStream_t st) {
   SSAK_REQUIRE(rows > 0 && cols > 0 && ld >= cols && (ld & 7) == 0 && ld <= 1536, "softmax_bwd: cols=%d ld=%d unsupported", cols, ld);
-  SoftmaxBwdParams p{dPd, P, dS, rows, cols, ld, drop.seed, drop.stream, thresh_of(drop.p),
+  SoftmaxBwdParams<T> p{dPd, P, dS, rows, cols, ld, drop.seed, drop.stream, thresh_of(drop.p),
                      scale_of(drop.p)};
   const int grid = ssak_cdiv(rows, ROW_THREADS / 64);
   const int nch = ssak_cdiv(ld / 8, 64);
   ProfScope prof_scope(PROF_SOFTMAX, (double)rows * ld * 2.0 * 3, st);
   if (nch == 1)
-    softmax_bwd_kernel<1><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_bwd_kernel<T, 1><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)
-    softmax_bwd_kernel<2><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_bwd_kernel<T, 2><<<grid, ROW_THREADS, 0, st>>>(p);
   else
-    softmax_bwd_kernel<3><<<grid, ROW_THREADS, 0, st>>>(p);
+    softmax_bwd_kernel<T, 3><<<grid, ROW_THREADS, 0, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch, size_t scratch_floats,
-             const uint8_t* rowmask, const int32_t* flens, int F) {
+template <typename T>
+int k_colsum_t(const T* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch, size_t scratch_floats,
+               const uint8_t* rowmask, const int32_t* flens, int F) {
   SSAK_REQUIRE(M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0, "colsum: N=%d ld=%ld must be multiples of 8", N, ld);
   dim3 grid(ssak_cdiv(N, 64), min(64, ssak_cdiv(M, 32)));
-  ProfScope prof_scope(PROF_ROWWISE, (double)M * N * 2.0, st);
+  ProfScope prof_scope(PROF_ROWWISE, (double)M * N * sizeof(T), st);
   const bool det = scratch && scratch_floats >= (size_t)grid.y * N;  // deterministic two-stage sum when a scratch is given
-  colsum_kernel<<<grid, 256, 0, st>>>(X, ld, M, N, out, det ? scratch : nullptr, rowmask, flens, F > 0 ? F : 1);
+  colsum_kernel<T><<<grid, 256, 0, st>>>(X, ld, M, N, out, det ? scratch : nullptr, rowmask, flens, F > 0 ? F : 1);
   SSAK_LAUNCH_CHECK();
   if (det) {
     if (g_reduce_sink && g_reduce_sink->push(scratch, N, (int)grid.y, N, out)) return SSAK_OK;
@@ -774,38 +754,77 @@ int k_cast_f32_bf16(const float* in, bf16* out, long n, hipStream_t st) {
   return SSAK_OK;
 }
 
-int k_specaug_fwd(bf16* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
-                  hipStream_t st) {
+template <typename T>
+int k_specaug_fwd_t(T* h, const uint8_t* mask, const int32_t* flens, const float* embed, int B, int F, int C,
+                    hipStream_t st) {
   if (!mask && !flens) return SSAK_OK;
   ProfScope prof_scope(PROF_ROWWISE, (double)B * F * 1.0, st);  // the mask is read; ~5 % of the rows are rewritten
-  specaug_fwd_kernel<<<B * F, 128, 0, st>>>(h, mask, flens, embed, B * F, F, C);
+  specaug_fwd_kernel<T><<<B * F, 128, 0, st>>>(h, mask, flens, embed, B * F, F, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_specaug_bwd(bf16* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
-                  hipStream_t st, float* scratch, size_t scratch_floats) {
+template <typename T>
+int k_specaug_bwd_t(T* dh, const uint8_t* mask, const int32_t* flens, float* dembed, int B, int F, int C,
+                    hipStream_t st, float* scratch, size_t scratch_floats) {
   if (!mask && !flens) return SSAK_OK;
   // d embed = sum of the masked (non-padding) rows of dh, taken before they are zeroed
   if (mask && dembed)
-    if (int rc = k_colsum(dh, C, B * F, C, dembed, st, scratch, scratch_floats, mask, flens, F)) return rc;
-  specaug_bwd_kernel<<<B * F, 128, 0, st>>>(dh, mask, flens, dembed, B * F, F, C);
+    if (int rc = k_colsum_t<T>(dh, C, B * F, C, dembed, st, scratch, scratch_floats, mask, flens, F)) return rc;
+  specaug_bwd_kernel<T><<<B * F, 128, 0, st>>>(dh, mask, flens, dembed, B * F, F, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_gelu_grad_mul(const bf16* dy, const bf16* pre, bf16* out, long n, hipStream_t st) {
+template <typename T>
+int k_gelu_grad_mul_t(const T* dy, const T* pre, T* out, long n, hipStream_t st) {
   SSAK_REQUIRE((n & 7) == 0, "gelu_grad_mul: n must be a multiple of 8");
   ProfScope prof_scope(PROF_ROWWISE, (double)n * 6.0, st);
-  gelu_grad_mul_kernel<<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(dy, pre, out, n / 8);
+  gelu_grad_mul_kernel<T><<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(dy, pre, out, n / 8);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
 
-int k_add_bf16(const bf16* a, const bf16* b, bf16* out, long n, hipStream_t st) {
+template <typename T>
+int k_add_t(const T* a, const T* b, T* out, long n, hipStream_t st) {
   SSAK_REQUIRE((n & 7) == 0, "add: n must be a multiple of 8");
   ProfScope prof_scope(PROF_ROWWISE, (double)n * 6.0, st);
-  add_bf16_kernel<<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(a, b, out, n / 8);
+  add_kernel<T><<<min(4096, ssak_cdiv(n / 8, 256)), 256, 0, st>>>(a, b, out, n / 8);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
+}
+
+// ---- explicit instantiations (bf16: the production engine; float: the fp32-exact verification mode) and the bf16-named
+// entry points the other kernel files call
+#define SSAK_INSTANTIATE_ROW_KERNELS(T)                                                                                           \
+  template int k_layernorm_fwd_t<T>(const T*, const T*, const float*, const float*, T*, T*, float*, float*, int, int, float,      \
+                                    const DropSpec&, const DropSpec&, hipStream_t, const DropSpec&, bool);                        \
+  template int k_layernorm_bwd_t<T>(const T*, const T*, const T*, const float*, const float*, const float*, const T*, T*, T*,     \
+                                    float*, float*, float*, int, int, const DropSpec&, const DropSpec&, hipStream_t,              \
+                                    const DropSpec&, float*, const float*);                                                       \
+  template int k_softmax_fwd_t<T>(const T*, T*, T*, const int32_t*, int, int, int, int, const DropSpec&, hipStream_t);            \
+  template int k_softmax_bwd_t<T>(const T*, const T*, T*, int, int, int, const DropSpec&, hipStream_t);                           \
+  template int k_colsum_t<T>(const T*, long, int, int, float*, hipStream_t, float*, size_t, const uint8_t*, const int32_t*, int); \
+  template int k_specaug_fwd_t<T>(T*, const uint8_t*, const int32_t*, const float*, int, int, int, hipStream_t);                  \
+  template int k_specaug_bwd_t<T>(T*, const uint8_t*, const int32_t*, float*, int, int, int, hipStream_t, float*, size_t);        \
+  template int k_gelu_grad_mul_t<T>(const T*, const T*, T*, long, hipStream_t);                                                   \
+  template int k_add_t<T>(const T*, const T*, T*, long, hipStream_t);
+SSAK_INSTANTIATE_ROW_KERNELS(bf16)
+SSAK_INSTANTIATE_ROW_KERNELS(float)
+
+int k_layernorm_fwd(const bf16* y, const bf16* res, const float* gamma, const float* beta, bf16* r_out, bf16* out,
+                    float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
+                    hipStream_t st, const DropSpec& mid, bool post_gelu) {
+  return k_layernorm_fwd_t<bf16>(y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, pre, post, st, mid, post_gelu);
+}
+int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* mean, const float* rstd,
+                    const float* gamma, const bf16* g_res, bf16* dr, bf16* dy, float* dgamma, float* dbeta,
+                    float* partial, int M, int C, const DropSpec& pre, const DropSpec& post, hipStream_t st,
+                    const DropSpec& mid, float* dy_colsum, const float* post_gelu_beta) {
+  return k_layernorm_bwd_t<bf16>(g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, M, C, pre, post, st, mid,
+                                 dy_colsum, post_gelu_beta);
+}
+int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch, size_t scratch_floats,
+             const uint8_t* rowmask, const int32_t* flens, int F) {
+  return k_colsum_t<bf16>(X, ld, M, N, out, st, scratch, scratch_floats, rowmask, flens, F);
 }

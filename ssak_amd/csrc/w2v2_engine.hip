@@ -93,9 +93,10 @@ struct ssak_w2v2 {
   float* G = nullptr;
   bf16* W = nullptr;
   // engine-owned derived weights
-  bf16* conv_w[8] = {nullptr};
-  bf16* pc_wf = nullptr;
-  bf16* pc_wb = nullptr;
+  // engine-owned derived weights, in the activation type of the mode (bf16, or float when cfg.exact)
+  void* conv_w[8] = {nullptr};
+  void* pc_wf = nullptr;
+  void* pc_wb = nullptr;
   float* pc_norms = nullptr;  // [2K]: ||v||^2 per tap | scratch
   Plan plan;
   bool have_fwd = false;
@@ -244,6 +245,7 @@ void build_param_table(ssak_w2v2* e) {
 
 int check_config(const ssak_w2v2_config& c) {
   if (c.arch == 1) {
+    SSAK_REQUIRE(!c.exact, "whisper: the fp32-exact mode is built for the wav2vec2 topologies");
     SSAK_REQUIRE(c.num_mel_bins > 0 && c.num_mel_bins % 8 == 0 && c.max_source_positions > 0, "whisper: num_mel_bins must be a multiple of 8");
     SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "whisper: head_dim must be a multiple of 8");
     SSAK_REQUIRE(c.hidden_size % 8 == 0 && c.intermediate_size % 8 == 0 && c.vocab_size % 8 == 0, "whisper: d_model / ffn / vocab must be multiples of 8");
@@ -251,6 +253,7 @@ int check_config(const ssak_w2v2_config& c) {
     return SSAK_OK;
   }
   SSAK_REQUIRE(c.arch == 0, "w2v2: arch must be 0 (wav2vec2) or 1 (whisper encoder)");
+  SSAK_REQUIRE(!c.exact || c.freeze_feature_encoder, "w2v2: the fp32-exact mode is built for the frozen feature encoder");
   SSAK_REQUIRE(c.num_conv_layers >= 2 && c.num_conv_layers <= 8, "w2v2: num_conv_layers %d unsupported", c.num_conv_layers);
   SSAK_REQUIRE(c.feat_extract_norm == 0 || c.feat_extract_norm == 1, "w2v2: feat_extract_norm must be 0 (group) or 1 (layer)");
   SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "w2v2: head_dim must be a multiple of 8");
@@ -295,11 +298,13 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
   const long M = p.M;
   p.pg_rows = K / 2 + (long)B * (p.F + K) + K;
   Carver cv;
-  const size_t b2 = sizeof(bf16);
+  const size_t b2 = c.exact ? sizeof(float) : sizeof(bf16);  // activation element size
   if (whisper) {
     const long NM = c.num_mel_bins;
     p.melcl = cv.take(((size_t)B * p.RS1 + 8) * NM * b2);
-    p.h1pad = cv.take((size_t)B * p.RS1 * H * b2);
+    // (+ 8 zero rows: the stride-2 window of the last padding row of the weight-gradient GEMM reaches one row past B * RS1;
+    // its dy row is zero, but 0 x NaN from an unwritten neighbour buffer would still poison the sum)
+    p.h1pad = cv.take(((size_t)B * p.RS1 + 8) * H * b2);
     p.pre1 = cv.take((size_t)B * p.RS1 * H * b2);
     p.we = cv.take((size_t)M * H * b2);
     p.wpre2 = cv.take((size_t)M * H * b2);
@@ -350,7 +355,7 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
   p.h1 = cv.take((size_t)M * H * b2);
   p.stE = cv.take((size_t)2 * M * sizeof(float));
   p.tmpH = cv.take((size_t)M * H * b2);
-  p.fused_attn = k_attention_supported((int)H, (int)nh);
+  p.fused_attn = !c.exact && k_attention_supported((int)H, (int)nh);
   p.S = cv.take(p.fused_attn ? 256 : (size_t)B * nh * p.F * p.Fp * b2);
   p.xf = cv.take((size_t)M * H * b2);
   const int nl = c.num_layers;
@@ -422,7 +427,8 @@ struct Gemm {
   const float* bias = nullptr;
   const void* aux_in = nullptr;
   void* aux_out = nullptr;
-  Gemm(int M, int N, int K) {
+  bool f32 = false;  // fp32-exact mode: float operands through ssak_gemm_f32
+  Gemm(int M, int N, int K, bool exact = false) : f32(exact) {
     memset(&d, 0, sizeof(d));
     d.M = M;
     d.N = N;
@@ -489,6 +495,7 @@ struct Gemm {
     return *this;
   }
   int run(hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
+    if (f32) return ssak_gemm_f32(&d, A, B, C, bias, aux_in, aux_out, (void*)st);
     return ssak_gemm_bf16(&d, A, B, C, bias, aux_in, aux_out, ws, ws_bytes, (void*)st);
   }
   // weight-gradient form: long K, few output tiles -> deterministic split-K, sized by the library's cost model
@@ -496,6 +503,11 @@ struct Gemm {
     d.split_k = 0;
     return run(st, slab, slab_bytes);
   }
+};
+
+template <bool EXACT>
+struct GemmX : Gemm {
+  GemmX(int M, int N, int K) : Gemm(M, N, K, EXACT) {}
 };
 
 // Weight-gradient products are not on the critical path of the backward: they are queued and launched together (one or
@@ -507,6 +519,7 @@ struct WgradQueue {
   const void* B[8];
   void* C[8];
   int n = 0, layers = 0, tiles = 0;
+  bool f32 = false;
   // gradient ranges to announce once the queued products have been launched, in LAYER ORDER: a data-parallel caller
   // pairs the k-th announcement of every rank in one collective, and LayerDrop decisions differ between ranks, so a
   // dropped layer's (zero) range must not overtake the kept layers still waiting here
@@ -518,6 +531,7 @@ struct WgradQueue {
     A[n] = g.A;
     B[n] = g.B;
     C[n] = g.C;
+    f32 = g.f32;
     tiles += tiles_of(g.d);
     ++n;
   }
@@ -525,7 +539,9 @@ struct WgradQueue {
   int flush(hipStream_t st, void* slab, size_t slab_bytes) {
     int rc = SSAK_OK;
     if (n > 0) {
-      if (tiles >= 160) {
+      if (f32) {
+        for (int i = 0; i < n && rc == SSAK_OK; ++i) rc = ssak_gemm_f32(&d[i], A[i], B[i], C[i], nullptr, nullptr, nullptr, (void*)st);
+      } else if (tiles >= 160) {
         rc = ssak_gemm_bf16_grouped(d, n, A, B, C, (void*)st);
       } else {
         for (int i = 0; i < n && rc == SSAK_OK; ++i) {
@@ -577,12 +593,13 @@ extern "C" int ssak_w2v2_create(const ssak_w2v2_config* cfg, ssak_w2v2** out) {
     return SSAK_OK;
   }
   long cin = 1;
+  const size_t esz = c.exact ? sizeof(float) : sizeof(bf16);
   for (int i = 0; i < c.num_conv_layers; ++i) {
-    if (i > 0) SSAK_HIP(hipMalloc((void**)&e->conv_w[i], (size_t)c.conv_dim[i] * cin * c.conv_kernel[i] * sizeof(bf16)));
+    if (i > 0) SSAK_HIP(hipMalloc((void**)&e->conv_w[i], (size_t)c.conv_dim[i] * cin * c.conv_kernel[i] * esz));
     cin = c.conv_dim[i];
   }
-  SSAK_HIP(hipMalloc((void**)&e->pc_wf, (size_t)H * K * cg * sizeof(bf16)));
-  SSAK_HIP(hipMalloc((void**)&e->pc_wb, (size_t)H * K * cg * sizeof(bf16)));
+  SSAK_HIP(hipMalloc((void**)&e->pc_wf, (size_t)H * K * cg * esz));
+  SSAK_HIP(hipMalloc((void**)&e->pc_wb, (size_t)H * K * cg * esz));
   SSAK_HIP(hipMalloc((void**)&e->pc_norms, (size_t)(2 + c.hidden_size) * K * sizeof(float)));  // norms | dot | [H][K] partials
   *out = e;
   return SSAK_OK;
@@ -675,27 +692,34 @@ extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
   if (c.arch == 1) {
     if (full) TRY(k_cast_f32_bf16(e->P, e->W, e->n_total, st));
     // the conv weights are trainable here: their [Co][k][Ci] GEMM layouts follow every optimizer step
-    TRY(k_conv_weight_rearrange(e->P + e->p_c1w, e->conv_w[1], c.hidden_size, c.num_mel_bins, 3, st));
-    TRY(k_conv_weight_rearrange(e->P + e->p_c2w, e->conv_w[2], c.hidden_size, c.hidden_size, 3, st));
+    TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_c1w, (bf16*)e->conv_w[1], c.hidden_size, c.num_mel_bins, 3, st));
+    TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_c2w, (bf16*)e->conv_w[2], c.hidden_size, c.hidden_size, 3, st));
     return SSAK_OK;
   }
   if (full) {
     TRY(k_cast_f32_bf16(e->P, e->W, e->n_total, st));
     long cin = c.conv_dim[0];
     for (int i = 1; i < c.num_conv_layers; ++i) {
-      TRY(k_conv_weight_rearrange(e->P + e->p_conv_w[i], e->conv_w[i], c.conv_dim[i], (int)cin, c.conv_kernel[i], st));
+      if (c.exact)
+        TRY(k_conv_weight_rearrange_t<float>(e->P + e->p_conv_w[i], (float*)e->conv_w[i], c.conv_dim[i], (int)cin, c.conv_kernel[i], st));
+      else
+        TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_conv_w[i], (bf16*)e->conv_w[i], c.conv_dim[i], (int)cin, c.conv_kernel[i], st));
       cin = c.conv_dim[i];
     }
   }
   if (!full && !c.freeze_feature_encoder) {  // trainable feature encoder: the conv GEMM layouts follow the optimizer
     long cin2 = c.conv_dim[0];
     for (int i = 1; i < c.num_conv_layers; ++i) {
-      TRY(k_conv_weight_rearrange(e->P + e->p_conv_w[i], e->conv_w[i], c.conv_dim[i], (int)cin2, c.conv_kernel[i], st));
+      TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_conv_w[i], (bf16*)e->conv_w[i], c.conv_dim[i], (int)cin2, c.conv_kernel[i], st));
       cin2 = c.conv_dim[i];
     }
   }
-  TRY(k_posconv_prepare(e->P + e->p_pc_g, e->P + e->p_pc_v, e->pc_wf, e->pc_wb, e->pc_norms, c.hidden_size,
-                        c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
+  if (c.exact)
+    TRY(k_posconv_prepare_t<float>(e->P + e->p_pc_g, e->P + e->p_pc_v, (float*)e->pc_wf, (float*)e->pc_wb, e->pc_norms, c.hidden_size,
+                                   c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
+  else
+    TRY(k_posconv_prepare_t<bf16>(e->P + e->p_pc_g, e->P + e->p_pc_v, (bf16*)e->pc_wf, (bf16*)e->pc_wb, e->pc_norms, c.hidden_size,
+                                  c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
   return SSAK_OK;
 }
 
@@ -719,6 +743,7 @@ extern "C" int ssak_w2v2_num_frames(const ssak_w2v2* e, int T) {
 
 // logits != NULL: through final dropout + lm_head (Wav2Vec2ForCTC); hidden != NULL: the encoder's last hidden state
 // (Wav2Vec2Model()[0], what the SpeechBrain recipe's wav2vec2 module returns) and no head.
+template <typename AT>
 static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* lens, int B, int T, const uint8_t* spec_mask,
                         const uint8_t* layer_keep /*host*/, uint64_t seed, int training, float* logits, bf16* hidden,
                         int32_t* frame_lens, void* workspace, size_t workspace_bytes, void* stream) {
@@ -726,6 +751,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   SSAK_REQUIRE(e->P && e->W, "w2v2_forward: bind + sync_weights first");
   SSAK_REQUIRE(B > 0 && T > 0, "w2v2_forward: bad shape B=%d T=%d", B, T);
   SSAK_REQUIRE(((uintptr_t)workspace & 255) == 0, "w2v2_forward: workspace must be 256-byte aligned");
+  constexpr bool EXACT = sizeof(AT) == 4;  // fp32-exact verification mode (ssak_w2v2_config.exact)
   Plan& p = e->plan;
   e->have_fwd = false;
   TRY(make_plan(e, B, T, training, p));
@@ -733,7 +759,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   const ssak_w2v2_config& c = e->cfg;
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  auto BF = [&](size_t off) { return (bf16*)(ws + off); };
+  auto BF = [&](size_t off) { return (AT*)(ws + off); };
   auto FP = [&](size_t off) { return (float*)(ws + off); };
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads, hd = H / nh;
   const bool whisper = c.arch == 1;
@@ -741,7 +767,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   const int G = whisper ? 1 : c.num_conv_pos_embedding_groups, cg = H / G;
   const int F = p.F, M = p.M, Fp = p.Fp;
   const float* P = e->P;
-  const bf16* W = e->W;
+  const AT* W = EXACT ? (const AT*)e->P : (const AT*)e->W;  // exact mode: products read the fp32 master weights
   e->seed = seed;
   e->spec_mask = spec_mask;
   e->lens = lens;
@@ -771,22 +797,24 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   int32_t* flens = nullptr;
   const bool stable = whisper || c.do_stable_layer_norm != 0;
   if (whisper) {
+   if constexpr (!EXACT) {
     // ---- a14 front end: mel [B, NM, Tin] -> channels-last padded -> conv1+GELU -> conv2(s2)+GELU -> + positions
     const int NM = c.num_mel_bins, Tin = p.Tin, RS1 = p.RS1;
     SSAK_REQUIRE(!lens, "whisper: fixed-length windows, no attention mask (modeling_whisper.py:605-607)");
-    SSAK_HIP(hipMemsetAsync(ws + p.melcl, 0, ((size_t)B * RS1 + 8) * NM * sizeof(bf16), st));
-    SSAK_HIP(hipMemsetAsync(ws + p.h1pad, 0, (size_t)B * RS1 * H * sizeof(bf16), st));
+    SSAK_HIP(hipMemsetAsync(ws + p.melcl, 0, ((size_t)B * RS1 + 8) * NM * sizeof(AT), st));
+    SSAK_HIP(hipMemsetAsync(ws + p.h1pad, 0, ((size_t)B * RS1 + 8) * H * sizeof(AT), st));
     TRY(k_mel_to_cl(input_values, BF(p.melcl), B, NM, Tin, RS1, 1, st));
-    TRY(Gemm(Tin, H, 3 * NM).a(BF(p.melcl), NM).b(e->conv_w[1], 3 * NM).c(BF(p.h1pad) + H, H)
+    TRY(GemmX<EXACT>(Tin, H, 3 * NM).a(BF(p.melcl), NM).b(e->conv_w[1], 3 * NM).c(BF(p.h1pad) + H, H)
             .batch(B, 1, (long)RS1 * NM, 0, 0, 0, (long)RS1 * H, 0).with_bias(P + e->p_c1b)
             .epi(SSAK_EPI_GELU, nullptr, BF(p.pre1) + H).run(st));
-    TRY(Gemm(F, H, 3 * H).a(BF(p.h1pad), 2 * H).b(e->conv_w[2], 3 * H).c(BF(p.we), H)
+    TRY(GemmX<EXACT>(F, H, 3 * H).a(BF(p.h1pad), 2 * H).b(e->conv_w[2], 3 * H).c(BF(p.we), H)
             .batch(B, 1, (long)RS1 * H, 0, 0, 0, (long)F * H, 0).with_bias(P + e->p_c2b)
             .epi(SSAK_EPI_GELU, nullptr, BF(p.wpre2)).run(st));
     TRY(k_add_rowvec(BF(p.we), W + e->p_pos, BF(p.h1), B, F, H, st));
     // residual stream r = dropout(conv + pos); x0 = self_attn_layer_norm of layer 0
-    TRY(k_layernorm_fwd(BF(p.h1), nullptr, P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
+    TRY(k_layernorm_fwd_t<AT>(BF(p.h1), nullptr, P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
                         FP(p.stE) + M, M, H, c.layer_norm_eps, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
+   }
   } else {
   // frame lengths (attention / CTC masks) from sample lengths: integer floor-div chain (modeling_wav2vec2.py:997-1016)
   if (lens) {
@@ -805,33 +833,33 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   // ---- a3: feature encoder (frozen: forward only)
   const bool ln_fe = c.feat_extract_norm == 1;
   if (!ln_fe) {
-    TRY(k_conv0_gn_gelu(input_values, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0],
+    TRY(k_conv0_gn_gelu_t<AT>(input_values, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0],
                         p.fe_train ? BF(p.act[0]) : BF(p.bufA), (double*)(ws + p.stats0), B, T, p.Tl[0], c.conv_dim[0],
                         c.conv_kernel[0], c.conv_stride[0], st));
   } else {
     // layer-norm variant (XLSR, modeling_wav2vec2.py:275-299): conv + bias -> LayerNorm over channels -> GELU
     // (--no_freeze keeps the pre-LayerNorm conv output and the statistics of every layer for the backward)
-    bf16* pre0 = p.fe_train ? BF(p.cpre[0]) : BF(p.bufA);
-    TRY(k_conv0_bias(input_values, P + e->p_conv_w[0], c.conv_bias ? P + e->p_conv_b[0] : nullptr, pre0, B, T,
+    AT* pre0 = p.fe_train ? BF(p.cpre[0]) : BF(p.bufA);
+    TRY(k_conv0_bias_t<AT>(input_values, P + e->p_conv_w[0], c.conv_bias ? P + e->p_conv_b[0] : nullptr, pre0, B, T,
                      p.Tl[0], c.conv_dim[0], c.conv_kernel[0], c.conv_stride[0], st));
-    TRY(k_layernorm_fwd(pre0, nullptr, P + e->p_cln_w[0], P + e->p_cln_b[0], nullptr, p.fe_train ? BF(p.act[0]) : BF(p.bufA),
+    TRY(k_layernorm_fwd_t<AT>(pre0, nullptr, P + e->p_cln_w[0], P + e->p_cln_b[0], nullptr, p.fe_train ? BF(p.act[0]) : BF(p.bufA),
                         p.fe_train ? FP(p.fe_st[0]) : nullptr, p.fe_train ? FP(p.fe_st[0]) + (size_t)B * p.Tl[0] : nullptr,
                         B * p.Tl[0], c.conv_dim[0], 1e-5f, none, none, st, none, true));
   }
   {
-    bf16* src = p.fe_train ? BF(p.act[0]) : BF(p.bufA);
+    AT* src = p.fe_train ? BF(p.act[0]) : BF(p.bufA);
     for (int i = 1; i < nc; ++i) {
-      bf16* dst = (i == nc - 1) ? BF(p.feat) : (p.fe_train ? BF(p.act[i]) : ((i & 1) ? BF(p.bufB) : BF(p.bufA)));
+      AT* dst = (i == nc - 1) ? BF(p.feat) : (p.fe_train ? BF(p.act[i]) : ((i & 1) ? BF(p.bufB) : BF(p.bufA)));
       const int Ci = c.conv_dim[i - 1], Co = c.conv_dim[i], k = c.conv_kernel[i], s = c.conv_stride[i];
-      bf16* conv_out = (ln_fe && p.fe_train) ? BF(p.cpre[i]) : dst;  // layer-norm variant, training: pre-LN values are kept
-      Gemm g(p.Tl[i], Co, k * Ci);
+      AT* conv_out = (ln_fe && p.fe_train) ? BF(p.cpre[i]) : dst;  // layer-norm variant, training: pre-LN values are kept
+      GemmX<EXACT> g(p.Tl[i], Co, k * Ci);
       g.a(src, (long)s * Ci).b(e->conv_w[i], (long)k * Ci).c(conv_out, Co)
           .batch(B, 1, (long)p.Tl[i - 1] * Ci, 0, 0, 0, (long)p.Tl[i] * Co, 0);
       if (c.conv_bias) g.with_bias(P + e->p_conv_b[i]);
       if (!ln_fe) g.epi(SSAK_EPI_GELU, nullptr, p.fe_train ? BF(p.cpre[i]) : nullptr);
       TRY(g.run(st));
       if (ln_fe)
-        TRY(k_layernorm_fwd(conv_out, nullptr, P + e->p_cln_w[i], P + e->p_cln_b[i], nullptr, dst,
+        TRY(k_layernorm_fwd_t<AT>(conv_out, nullptr, P + e->p_cln_w[i], P + e->p_cln_b[i], nullptr, dst,
                             p.fe_train ? FP(p.fe_st[i]) : nullptr, p.fe_train ? FP(p.fe_st[i]) + (size_t)B * p.Tl[i] : nullptr,
                             B * p.Tl[i], Co, 1e-5f, none, none, st, none, true));
       src = dst;
@@ -839,18 +867,18 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   }
   // ---- a4: feature projection  LN -> Linear (+ feat_proj_dropout): the first read of trainable parameters
   TRY(wait_params());
-  TRY(k_layernorm_fwd(BF(p.feat), nullptr, P + e->p_fpln_w, P + e->p_fpln_b, nullptr, BF(p.ln0), FP(p.st0),
+  TRY(k_layernorm_fwd_t<AT>(BF(p.feat), nullptr, P + e->p_fpln_w, P + e->p_fpln_b, nullptr, BF(p.ln0), FP(p.st0),
                       FP(p.st0) + M, M, C, c.layer_norm_eps, none, none, st));
-  TRY(Gemm(M, H, C).a(BF(p.ln0), C).b(W + e->p_fp_w, C).c(BF(p.h0), H).with_bias(P + e->p_fp_b)
+  TRY(GemmX<EXACT>(M, H, C).a(BF(p.ln0), C).b(W + e->p_fp_w, C).c(BF(p.h0), H).with_bias(P + e->p_fp_b)
           .run(st));
     if (tr && c.feat_proj_dropout > 0.f)  // same row kernel (and mask generator) as its replay in the backward
-      TRY(k_layernorm_fwd(BF(p.h0), nullptr, nullptr, nullptr, BF(p.h0), nullptr, nullptr, nullptr, M, H, 0.f,
+      TRY(k_layernorm_fwd_t<AT>(BF(p.h0), nullptr, nullptr, nullptr, BF(p.h0), nullptr, nullptr, nullptr, M, H, 0.f,
                           DS(c.feat_proj_dropout, DS_FEATPROJ), none, st));
   // ---- a5: SpecAugment scatter + zeroing of padded frames
-  TRY(k_specaug_fwd(BF(p.h0), spec_mask, flens, P + e->p_mse, B, F, H, st));
+  TRY(k_specaug_fwd_t<AT>(BF(p.h0), spec_mask, flens, P + e->p_mse, B, F, H, st));
   // ---- a6: positional conv (grouped, weight-normed) + GELU, residual, LayerNorm, dropout
-  TRY(k_posconv_pack(BF(p.h0), BF(p.pgx), B, F, H, G, K, st));
-  TRY(Gemm(F, cg, K * cg)
+  TRY(k_posconv_pack_t<AT>(BF(p.h0), BF(p.pgx), B, F, H, G, K, st));
+  TRY(GemmX<EXACT>(F, cg, K * cg)
           .a(BF(p.pgx), cg)
           .b(e->pc_wf, (long)K * cg)
           .c(BF(p.pc), H)
@@ -860,11 +888,11 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
           .run(st));
   if (!stable) {
     // post-LN (base): x0 = dropout(LN(h0 + pos))                                       (modeling_wav2vec2.py:694-697)
-    TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->p_eln_w, P + e->p_eln_b, BF(p.h1), BF(p.x[0]), FP(p.stE), FP(p.stE) + M,
+    TRY(k_layernorm_fwd_t<AT>(BF(p.pc), BF(p.h0), P + e->p_eln_w, P + e->p_eln_b, BF(p.h1), BF(p.x[0]), FP(p.stE), FP(p.stE) + M,
                         M, H, c.layer_norm_eps, none, DS(c.hidden_dropout, DS_ENCIN), st));
   } else {
     // stable-LN (XLSR): residual stream r = dropout(h0 + pos); x0 = LN1 of layer 0 applied to r   (:763-771, :631-640)
-    TRY(k_layernorm_fwd(BF(p.pc), BF(p.h0), P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
+    TRY(k_layernorm_fwd_t<AT>(BF(p.pc), BF(p.h0), P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
                         FP(p.stE) + M, M, H, c.layer_norm_eps, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
   }
   }
@@ -883,54 +911,56 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
       e->keep[l] = 0;
       if (!stable) {
         // skipped layer: output = input (modeling_wav2vec2.py:701-712)
-        SSAK_HIP(hipMemcpyAsync(BF(p.x[l + 1]), BF(p.x[l]), (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
+        SSAK_HIP(hipMemcpyAsync(BF(p.x[l + 1]), BF(p.x[l]), (size_t)M * H * sizeof(AT), hipMemcpyDeviceToDevice, st));
       } else {
         // the residual stream passes through; the next LayerNorm still has to be applied to it
-        TRY(k_layernorm_fwd(BF(e->hres[l]), nullptr, nxt_w, nxt_b, nullptr, BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M, M, H,
+        TRY(k_layernorm_fwd_t<AT>(BF(e->hres[l]), nullptr, nxt_w, nxt_b, nullptr, BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M, M, H,
                             c.layer_norm_eps, none, none, st));
         e->hres[l + 1] = e->hres[l];
       }
       continue;
     }
-    const bf16* x = BF(p.x[l]);
-    bf16* qkv = BF(lb.qkv);
-    TRY(Gemm(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
+    const AT* x = BF(p.x[l]);
+    AT* qkv = BF(lb.qkv);
+    TRY(GemmX<EXACT>(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
     if (p.fused_attn) {
       // scores never leave the MFMA accumulators (attention.hip); only ctx and the per-row log-sum-exp are written
-      TRY(k_attention_fwd(qkv, BF(lb.ctx), FP(lb.lse), flens, B, F, nh, H, DS(c.attention_dropout, ds_attn(l)), st));
+      if constexpr (!EXACT)
+        TRY(k_attention_fwd(qkv, BF(lb.ctx), FP(lb.lse), flens, B, F, nh, H, DS(c.attention_dropout, ds_attn(l)), st));
     } else {
-      TRY(Gemm(F, F, hd).a(qkv, 3 * H).b(qkv + H, 3 * H).c(BF(p.S), Fp).alpha(scale)
+      TRY(GemmX<EXACT>(F, F, hd).a(qkv, 3 * H).b(qkv + H, 3 * H).c(BF(p.S), Fp).alpha(scale)
               .batch(B, nh, (long)F * 3 * H, hd, (long)F * 3 * H, hd, (long)nh * F * Fp, (long)F * Fp).run(st));
-      TRY(k_softmax_fwd(BF(p.S), BF(lb.P), lb.Pd != lb.P ? BF(lb.Pd) : nullptr, flens, B * nh * F, F, Fp, nh * F,
+      TRY(k_softmax_fwd_t<AT>(BF(p.S), BF(lb.P), lb.Pd != lb.P ? BF(lb.Pd) : nullptr, flens, B * nh * F, F, Fp, nh * F,
                         DS(c.attention_dropout, ds_attn(l)), st));
-      TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
+      TRY(GemmX<EXACT>(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
               .batch(B, nh, (long)nh * F * Fp, (long)F * Fp, (long)F * 3 * H, hd, (long)F * H, hd).run(st));
     }
-    TRY(Gemm(M, H, H).a(BF(lb.ctx), H).b(W + L.wo, H).c(BF(p.tmpH), H).with_bias(P + L.bo).run(st));
+    TRY(GemmX<EXACT>(M, H, H).a(BF(lb.ctx), H).b(W + L.wo, H).c(BF(p.tmpH), H).with_bias(P + L.bo).run(st));
     if (!stable) {
-      TRY(k_layernorm_fwd(BF(p.tmpH), x, P + L.ln1w, P + L.ln1b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
+      TRY(k_layernorm_fwd_t<AT>(BF(p.tmpH), x, P + L.ln1w, P + L.ln1b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
                           c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
     } else {
       // r1 = r + drop(attn);  x1 = final_layer_norm(r1)
-      TRY(k_layernorm_fwd(BF(p.tmpH), BF(e->hres[l]), P + L.ln2w, P + L.ln2b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
+      TRY(k_layernorm_fwd_t<AT>(BF(p.tmpH), BF(e->hres[l]), P + L.ln2w, P + L.ln2b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
                           c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
     }
-    TRY(Gemm(M, I, H).a(BF(lb.x1), H).b(W + L.w1, H).c(BF(lb.f1), I).with_bias(P + L.b1)
+    TRY(GemmX<EXACT>(M, I, H).a(BF(lb.x1), H).b(W + L.w1, H).c(BF(lb.f1), I).with_bias(P + L.b1)
             .epi(SSAK_EPI_GELU, nullptr, BF(lb.f1pre)).drop(tr ? c.activation_dropout : 0.f, ds_act(l), seed).run(st));
-    TRY(Gemm(M, H, I).a(BF(lb.f1), I).b(W + L.w2, I).c(BF(p.tmpH), H).with_bias(P + L.b2).run(st));
+    TRY(GemmX<EXACT>(M, H, I).a(BF(lb.f1), I).b(W + L.w2, I).c(BF(p.tmpH), H).with_bias(P + L.b2).run(st));
     if (!stable) {
-      TRY(k_layernorm_fwd(BF(p.tmpH), BF(lb.x1), P + L.ln2w, P + L.ln2b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M,
+      TRY(k_layernorm_fwd_t<AT>(BF(p.tmpH), BF(lb.x1), P + L.ln2w, P + L.ln2b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M,
                           M, H, c.layer_norm_eps, DS(c.hidden_dropout, ds_hid2(l)), none, st));
     } else {
       // r2 = r1 + drop(ffn);  x[l+1] = (next layer's LN1 | encoder LN)(r2)
-      TRY(k_layernorm_fwd(BF(p.tmpH), BF(lb.r1), nxt_w, nxt_b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M, M, H,
+      TRY(k_layernorm_fwd_t<AT>(BF(p.tmpH), BF(lb.r1), nxt_w, nxt_b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M, M, H,
                           c.layer_norm_eps, DS(c.hidden_dropout, ds_hid2(l)), none, st));
       e->hres[l + 1] = lb.r2;
     }
   }
   // ---- a8: final dropout + lm_head -> fp32 logits
-  const bf16* xl = BF(p.x[c.num_layers]);
+  const AT* xl = BF(p.x[c.num_layers]);
   if (hidden) {
+    SSAK_REQUIRE(!EXACT, "w2v2_forward_hidden: the hidden-state interface is bf16 (not built for the fp32-exact mode)");
     SSAK_HIP(hipMemcpyAsync(hidden, xl, (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
     e->have_fwd = tr;
     e->fwd_hidden = true;
@@ -938,11 +968,11 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   }
   e->fwd_hidden = false;
   if (tr && c.final_dropout > 0.f) {
-    TRY(k_layernorm_fwd(xl, nullptr, nullptr, nullptr, BF(p.xf), nullptr, nullptr, nullptr, M, H, 0.f,
+    TRY(k_layernorm_fwd_t<AT>(xl, nullptr, nullptr, nullptr, BF(p.xf), nullptr, nullptr, nullptr, M, H, 0.f,
                         DS(c.final_dropout, DS_FINAL), none, st));
     xl = BF(p.xf);
   }
-  TRY(Gemm(M, V, H).a(xl, H).b(W + e->p_lm_w, H).c(logits, V, true).with_bias(P + e->p_lm_b).run(st));
+  TRY(GemmX<EXACT>(M, V, H).a(xl, H).b(W + e->p_lm_w, H).c(logits, V, true).with_bias(P + e->p_lm_b).run(st));
   e->have_fwd = tr;
   return SSAK_OK;
 }
@@ -951,8 +981,11 @@ extern "C" int ssak_w2v2_forward(ssak_w2v2* e, const float* input_values, const 
                                  const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed,
                                  int training, float* logits, int32_t* frame_lens, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-  SSAK_REQUIRE(logits, "w2v2_forward: null pointer");
-  return forward_impl(e, input_values, lens, B, T, spec_mask, layer_keep, seed, training, logits, nullptr, frame_lens, workspace,
+  SSAK_REQUIRE(e && logits, "w2v2_forward: null pointer");
+  if (e->cfg.exact)
+    return forward_impl<float>(e, input_values, lens, B, T, spec_mask, layer_keep, seed, training, logits, nullptr, frame_lens, workspace,
+                               workspace_bytes, stream);
+  return forward_impl<bf16>(e, input_values, lens, B, T, spec_mask, layer_keep, seed, training, logits, nullptr, frame_lens, workspace,
                       workspace_bytes, stream);
 }
 
@@ -960,12 +993,14 @@ extern "C" int ssak_w2v2_forward_hidden(ssak_w2v2* e, const float* input_values,
                                         const uint8_t* spec_mask, const uint8_t* layer_keep /*host*/, uint64_t seed,
                                         int training, void* hidden_bf16, int32_t* frame_lens, void* workspace,
                                         size_t workspace_bytes, void* stream) {
-  SSAK_REQUIRE(hidden_bf16, "w2v2_forward_hidden: null pointer");
-  return forward_impl(e, input_values, lens, B, T, spec_mask, layer_keep, seed, training, nullptr, (bf16*)hidden_bf16, frame_lens,
+  SSAK_REQUIRE(e && hidden_bf16, "w2v2_forward_hidden: null pointer");
+  SSAK_REQUIRE(!e->cfg.exact, "w2v2_forward_hidden: not built for the fp32-exact mode");
+  return forward_impl<bf16>(e, input_values, lens, B, T, spec_mask, layer_keep, seed, training, nullptr, (bf16*)hidden_bf16, frame_lens,
                       workspace, workspace_bytes, stream);
 }
 
 // dlogits (after ssak_w2v2_forward) or dhidden (after ssak_w2v2_forward_hidden): exactly one is non-null
+template <typename AT>
 static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden, void* workspace, size_t workspace_bytes,
                          void* stream) {
   SSAK_REQUIRE(e && (dlogits || dhidden) && workspace, "w2v2_backward: null pointer");
@@ -973,13 +1008,14 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     ssak_set_error("w2v2_backward: no matching training-mode forward to differentiate");
     return SSAK_ERR_STATE;
   }
+  constexpr bool EXACT = sizeof(AT) == 4;
   SSAK_REQUIRE(e->G, "w2v2_backward: no gradient buffer bound");
   Plan& p = e->plan;
   SSAK_REQUIRE(workspace_bytes >= p.total, "w2v2_backward: workspace too small");
   const ssak_w2v2_config& c = e->cfg;
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  auto BF = [&](size_t off) { return (bf16*)(ws + off); };
+  auto BF = [&](size_t off) { return (AT*)(ws + off); };
   auto FP = [&](size_t off) { return (float*)(ws + off); };
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, nh = c.num_heads, hd = H / nh;
   const bool whisper = c.arch == 1;
@@ -988,7 +1024,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   const int B = p.B, F = p.F, M = p.M, Fp = p.Fp;
   const float* P = e->P;
   float* Gd = e->G;
-  const bf16* W = e->W;
+  const AT* W = EXACT ? (const AT*)e->P : (const AT*)e->W;  // exact mode: products read the fp32 master weights
   const uint64_t seed = e->seed;
   const int32_t* flens = e->lens ? (const int32_t*)(ws + p.flens) : nullptr;
   auto DS = [&](float prob, uint32_t stream_id) {
@@ -1022,36 +1058,39 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     }
   }
   // ---- lm_head (its gradient stays zero when the backward starts from the hidden state)
-  bf16* dlog = BF(p.dlog);
+  AT* dlog = BF(p.dlog);
   if (dlogits) {
-    TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
-    const bf16* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
-    TRY(Gemm(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
-    TRY(k_colsum(dlog, V, M, V, Gd + e->p_lm_b, st, FP(p.lnpart), cs_floats));
+    if constexpr (EXACT)
+      dlog = const_cast<float*>(dlogits);  // the CTC gradient is consumed in fp32 as it is
+    else
+      TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
+    const AT* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
+    TRY(GemmX<EXACT>(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
+    TRY(k_colsum_t<AT>(dlog, V, M, V, Gd + e->p_lm_b, st, FP(p.lnpart), cs_floats));
   }
   auto announce = [&](long off, long cnt) {
     if (e->on_ready && cnt > 0) e->on_ready(off, cnt, e->on_ready_user);
   };
   const long layer_span = (e->lp[0].w2 + (long)H * I) - e->lp[0].wqkv;  // wqkv|wo|w1|w2 of one layer are contiguous
   announce(e->p_lm_w, (long)V * H);
-  bf16* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
-  bf16* gB = nullptr;
+  AT* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
+  AT* gB = nullptr;
   if (dhidden)
     SSAK_HIP(hipMemcpyAsync(gA, dhidden, (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
   else
-    TRY(Gemm(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).run(st));
+    TRY(GemmX<EXACT>(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).run(st));
   if (dlogits && c.final_dropout > 0.f)  // replay the final-dropout mask with the kernel that applied it in the forward
-    TRY(k_layernorm_fwd(gA, nullptr, nullptr, nullptr, gA, nullptr, nullptr, nullptr, M, H, 0.f, DS(c.final_dropout, DS_FINAL),
+    TRY(k_layernorm_fwd_t<AT>(gA, nullptr, nullptr, nullptr, gA, nullptr, nullptr, nullptr, M, H, 0.f, DS(c.final_dropout, DS_FINAL),
                         none, st));
   // ---- encoder layers, last to first.  gA (+gB) = gradient w.r.t. x[l+1], the layer output (post-LN) or the
   // normalised input of the next layer (stable-LN); Gres = gradient of the residual stream (stable-LN only).
   const bool stable = whisper || c.do_stable_layer_norm != 0;
-  const bf16* Gres = nullptr;
-  auto free_buf = [&](const bf16* u1, const bf16* u2, const bf16* u3) {
-    bf16* cand[3] = {BF(p.dC), BF(p.dA), BF(p.scratchH)};
-    for (bf16* cnd : cand)
+  const AT* Gres = nullptr;
+  auto free_buf = [&](const AT* u1, const AT* u2, const AT* u3) {
+    AT* cand[3] = {BF(p.dC), BF(p.dA), BF(p.scratchH)};
+    for (AT* cnd : cand)
       if (cnd != u1 && cnd != u2 && cnd != u3) return cnd;
-    return (bf16*)nullptr;
+    return (AT*)nullptr;
   };
   WgradQueue wq;
   // second stages of the layers' column reductions: queued, launched together at every weight-gradient flush
@@ -1112,81 +1151,82 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
         announce(L.wqkv, layer_span);
       if (!stable) continue;  // identity layer: gradient passes through unchanged
       // x[l+1] = LN_next(r): its gradient joins the residual-stream gradient; nothing consumed x[l]
-      bf16* dr = free_buf(gA, gB, Gres);
-      TRY(k_layernorm_bwd(gA, gB, BF(e->hres[l]), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dr, nullptr, Gd + nxt_w, Gd + nxt_b,
+      AT* dr = free_buf(gA, gB, Gres);
+      TRY(k_layernorm_bwd_t<AT>(gA, gB, BF(e->hres[l]), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dr, nullptr, Gd + nxt_w, Gd + nxt_b,
                           ln_part, M, H, none, none, st));
       Gres = dr;
       gA = BF(p.dB);
       gB = nullptr;
-      SSAK_HIP(hipMemsetAsync(gA, 0, (size_t)M * H * sizeof(bf16), st));
+      SSAK_HIP(hipMemsetAsync(gA, 0, (size_t)M * H * sizeof(AT), st));
       continue;
     }
     TRY(red_get(ln_part_floats, &ln_part2));
     const size_t ffn_part_floats = (size_t)std::max(ssak_cdiv(M, 64), 64) * I;  // (>= 64 rows: the non-fused fallback's partials)
     TRY(red_get(ffn_part_floats, &ffn_part));
     TRY(red_get((size_t)64 * 3 * H, &qkv_part));
-    bf16* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
+    AT* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
     const int set = kept & 1;
     ++kept;
-    bf16* dY = BF(p.dYb[set]);     // dy of the feed-forward branch (dropout mask applied): dX and dW operand
-    bf16* dY1 = BF(p.dY1b[set]);   // dy of the attention branch
-    bf16* dI = BF(p.dIb[set]);
+    AT* dY = BF(p.dYb[set]);     // dy of the feed-forward branch (dropout mask applied): dX and dW operand
+    AT* dY1 = BF(p.dY1b[set]);   // dy of the attention branch
+    AT* dI = BF(p.dIb[set]);
     if (!stable) {
       // final_layer_norm backward: r2 = x1 + drop(ffn)
-      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, dY,
+      TRY(k_layernorm_bwd_t<AT>(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + L.ln2w, nullptr, dR, dY,
                           Gd + L.ln2w, Gd + L.ln2b, ln_part, M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
     } else {
       // (next LN) backward: x[l+1] = LN_next(r2), r2 = r1 + drop(ffn); the residual-stream gradient is added after it
-      TRY(k_layernorm_bwd(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dR, dY, Gd + nxt_w,
+      TRY(k_layernorm_bwd_t<AT>(gA, gB, BF(lb.r2), stl + 2 * M, stl + 3 * M, P + nxt_w, Gres, dR, dY, Gd + nxt_w,
                           Gd + nxt_b, ln_part, M, H, DS(c.hidden_dropout, ds_hid2(l)), none, st, none, Gd + L.b2));
     }
     // (the dy output is written even without hidden dropout -- a plain copy then -- so that the queued weight-gradient
     // products always read buffers of this layer's set, never the rotating residual-stream buffers)
-    const bf16* dy2 = dY;
-    wq.push(Gemm(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
-    TRY(Gemm(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
+    const AT* dy2 = dY;
+    wq.push(GemmX<EXACT>(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
+    TRY(GemmX<EXACT>(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
             .epi(SSAK_EPI_MUL_GELU_GRAD, BF(lb.f1pre)).drop(c.activation_dropout, ds_act(l), seed)
             .colsum(Gd + L.b1).run(st, ffn_part, ffn_part_floats * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
-    wq.push(Gemm(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
-    bf16* dX = BF(p.dB);
-    TRY(Gemm(M, H, I).a(dI, I).b(W + L.w1, H, true).c(dX, H).run(st));
-    bf16* dR1;
+    wq.push(GemmX<EXACT>(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
+    AT* dX = BF(p.dB);
+    TRY(GemmX<EXACT>(M, H, I).a(dI, I).b(W + L.w1, H, true).c(dX, H).run(st));
+    AT* dR1;
     if (!stable) {
       // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
       dR1 = BF(p.dA);  // gA was consumed by the final_layer_norm backward above
-      TRY(k_layernorm_bwd(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, dY1, Gd + L.ln1w,
+      TRY(k_layernorm_bwd_t<AT>(dR, dX, BF(lb.r1), stl, stl + M, P + L.ln1w, nullptr, dR1, dY1, Gd + L.ln1w,
                           Gd + L.ln1b, ln_part2, M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
     } else {
       // final_layer_norm backward: x1 = LN(r1), r1 = r + drop(attn_out); residual gradient dR is added after it
       dR1 = free_buf(dR, dX, nullptr);
-      TRY(k_layernorm_bwd(dX, nullptr, BF(lb.r1), stl, stl + M, P + L.ln2w, dR, dR1, dY1, Gd + L.ln2w,
+      TRY(k_layernorm_bwd_t<AT>(dX, nullptr, BF(lb.r1), stl, stl + M, P + L.ln2w, dR, dR1, dY1, Gd + L.ln2w,
                           Gd + L.ln2b, ln_part2, M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
     }
-    const bf16* dy1 = dY1;
-    wq.push(Gemm(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));  // (bo's gradient: summed by the LN backward)
-    bf16* dctx = free_buf(dR1, dX, nullptr);
-    TRY(Gemm(M, H, H).a(dy1, H).b(W + L.wo, H, true).c(dctx, H).run(st));
+    const AT* dy1 = dY1;
+    wq.push(GemmX<EXACT>(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));  // (bo's gradient: summed by the LN backward)
+    AT* dctx = free_buf(dR1, dX, nullptr);
+    TRY(GemmX<EXACT>(M, H, H).a(dy1, H).b(W + L.wo, H, true).c(dctx, H).run(st));
     // attention backward per (utterance, head)
-    bf16* qkv = BF(lb.qkv);
-    bf16* dqkv = BF(p.dqkvb[set]);
+    AT* qkv = BF(lb.qkv);
+    AT* dqkv = BF(p.dqkvb[set]);
     const long sq1 = (long)F * 3 * H, sp1 = (long)nh * F * Fp, sp2 = (long)F * Fp, sh1 = (long)F * H;
     if (p.fused_attn) {
-      TRY(k_attention_bwd(qkv, BF(lb.ctx), FP(lb.lse), flens, dctx, FP(p.delta), dqkv, B, F, nh, H,
-                          DS(c.attention_dropout, ds_attn(l)), st));
+      if constexpr (!EXACT)
+        TRY(k_attention_bwd(qkv, BF(lb.ctx), FP(lb.lse), flens, dctx, FP(p.delta), dqkv, B, F, nh, H,
+                            DS(c.attention_dropout, ds_attn(l)), st));
     } else {
-      TRY(Gemm(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
+      TRY(GemmX<EXACT>(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
               .batch(B, nh, sp1, sp2, sh1, hd, sq1, hd).run(st));  // dV = Pd^T dctx
-      TRY(Gemm(F, F, hd).a(dctx, H).b(qkv + 2 * H, 3 * H).c(BF(p.S), Fp)
+      TRY(GemmX<EXACT>(F, F, hd).a(dctx, H).b(qkv + 2 * H, 3 * H).c(BF(p.S), Fp)
               .batch(B, nh, sh1, hd, sq1, hd, sp1, sp2).run(st));  // dPd = dctx V^T
-      TRY(k_softmax_bwd(BF(p.S), BF(lb.P), BF(p.dSb), B * nh * F, F, Fp, DS(c.attention_dropout, ds_attn(l)), st));
-      TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp).b(qkv + H, 3 * H, true).c(dqkv, 3 * H).alpha(scale)
+      TRY(k_softmax_bwd_t<AT>(BF(p.S), BF(lb.P), BF(p.dSb), B * nh * F, F, Fp, DS(c.attention_dropout, ds_attn(l)), st));
+      TRY(GemmX<EXACT>(F, hd, F).a(BF(p.dSb), Fp).b(qkv + H, 3 * H, true).c(dqkv, 3 * H).alpha(scale)
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dQ = scale dS K
-      TRY(Gemm(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
+      TRY(GemmX<EXACT>(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
     }
-    wq.push(Gemm(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
-    TRY(k_colsum(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
-    TRY(Gemm(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
+    wq.push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
+    TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
+    TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
     wq.ann_off[wq.n_ann++] = L.wqkv;
     ++wq.layers;
     // launch when a second layer is queued, or when another layer would spill into a second round of workgroups
@@ -1204,47 +1244,49 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   TRY(flush_wgrads());
   g_reduce_sink = nullptr;  // the rest of the backward launches its second stages directly
   // ---- encoder input
-  bf16* dh1 = free_buf(gA, gB, Gres);
+  AT* dh1 = free_buf(gA, gB, Gres);
   if (!stable) {
     // x0 = drop(LN(h1)), h1 = h0 + gelu(posconv(h0))
-    TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->p_eln_w, nullptr, dh1, nullptr, Gd + e->p_eln_w,
+    TRY(k_layernorm_bwd_t<AT>(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->p_eln_w, nullptr, dh1, nullptr, Gd + e->p_eln_w,
                         Gd + e->p_eln_b, FP(p.lnpart), M, H, none, DS(c.hidden_dropout, DS_ENCIN), st));
   } else {
     // x0 = LN1_0(r), r = drop(h0 + gelu(posconv(h0))): LN backward + residual-stream gradient, then the dropout mask
-    TRY(k_layernorm_bwd(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->lp[0].ln1w, Gres, dh1, nullptr, Gd + e->lp[0].ln1w,
+    TRY(k_layernorm_bwd_t<AT>(gA, gB, BF(p.h1), FP(p.stE), FP(p.stE) + M, P + e->lp[0].ln1w, Gres, dh1, nullptr, Gd + e->lp[0].ln1w,
                         Gd + e->lp[0].ln1b, FP(p.lnpart), M, H, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
   }
   if (whisper) {
+   if constexpr (!EXACT) {
     // ---- a14 front end backward: r = dropout(gelu(conv2(gelu(conv1(mel)))) + pos); positions are fixed
     const int NM = c.num_mel_bins, Tin = p.Tin, RS1 = p.RS1, RS2 = p.RS2;
-    bf16* dpre2 = BF(p.dY);
-    TRY(k_gelu_grad_mul(dh1, BF(p.wpre2), dpre2, (long)M * H, st));
-    TRY(k_colsum(dpre2, H, M, H, Gd + e->p_c2b, st, FP(p.lnpart), cs_floats));
+    AT* dpre2 = BF(p.dY);
+    TRY(k_gelu_grad_mul_t<AT>(dh1, BF(p.wpre2), dpre2, (long)M * H, st));
+    TRY(k_colsum_t<AT>(dpre2, H, M, H, Gd + e->p_c2b, st, FP(p.lnpart), cs_floats));
     TRY(k_copy_rows_padded(dpre2, BF(p.dpre2pad), B, F, RS2, H, st));
     // dW2[n][tap*H + c] = sum over rows kk = b*RS2 + t of dy[kk][n] * h1pad[2*kk + tap][c]   (one long-K GEMM)
-    TRY(Gemm(H, 3 * H, B * RS2).a(BF(p.dpre2pad), H, true).b(BF(p.h1pad), 2 * H, true).c(FP(p.dwr), 3 * H, true)
+    TRY(GemmX<EXACT>(H, 3 * H, B * RS2).a(BF(p.dpre2pad), H, true).b(BF(p.h1pad), 2 * H, true).c(FP(p.dwr), 3 * H, true)
             .run_wgrad(st, slab, p.slab_bytes));
     TRY(k_conv_wgrad_unrearrange(FP(p.dwr), Gd + e->p_c2w, H, H, 3, st));
     // input gradient in column form, then col2im (+ GELU' of conv1's pre-activation)
-    TRY(Gemm(M, 3 * H, H).a(dpre2, H).b(e->conv_w[2], 3 * H, true).c(BF(p.dxcol), 3 * H).run(st));
+    TRY(GemmX<EXACT>(M, 3 * H, H).a(dpre2, H).b(e->conv_w[2], 3 * H, true).c(BF(p.dxcol), 3 * H).run(st));
     TRY(k_col2im_k3s2(BF(p.dxcol), BF(p.pre1), BF(p.dpre1pad), B, F, Tin, RS1, H, st));
-    TRY(k_colsum(BF(p.dpre1pad), H, B * RS1, H, Gd + e->p_c1b, st, FP(p.lnpart), cs_floats));
-    TRY(Gemm(H, 3 * NM, B * RS1).a(BF(p.dpre1pad), H, true).b(BF(p.melcl), NM, true).c(FP(p.dwr), 3 * NM, true)
+    TRY(k_colsum_t<AT>(BF(p.dpre1pad), H, B * RS1, H, Gd + e->p_c1b, st, FP(p.lnpart), cs_floats));
+    TRY(GemmX<EXACT>(H, 3 * NM, B * RS1).a(BF(p.dpre1pad), H, true).b(BF(p.melcl), NM, true).c(FP(p.dwr), 3 * NM, true)
             .run_wgrad(st, slab, p.slab_bytes));
     TRY(k_conv_wgrad_unrearrange(FP(p.dwr), Gd + e->p_c1w, H, NM, 3, st));
     for (int l = 0; l < c.num_layers; ++l)  // k_proj has no bias in Whisper: keep its slot out of the optimizer
       SSAK_HIP(hipMemsetAsync(Gd + e->lp[l].bqkv + H, 0, (size_t)H * sizeof(float), st));
+   }
   } else {
-  bf16* dpre = BF(p.dY);
-  TRY(k_gelu_grad_mul(dh1, BF(p.pc_pre), dpre, (long)M * H, st));
-  TRY(k_colsum(dpre, H, M, H, Gd + e->p_pc_b, st, FP(p.lnpart), cs_floats));
-  TRY(k_posconv_pack(dpre, BF(p.pgdy), B, F, H, G, K, st));
+  AT* dpre = BF(p.dY);
+  TRY(k_gelu_grad_mul_t<AT>(dh1, BF(p.pc_pre), dpre, (long)M * H, st));
+  TRY(k_colsum_t<AT>(dpre, H, M, H, Gd + e->p_pc_b, st, FP(p.lnpart), cs_floats));
+  TRY(k_posconv_pack_t<AT>(dpre, BF(p.pgdy), B, F, H, G, K, st));
   {
     const int lead = K / 2, RS = F + K;
     // dW^T[g][tap*cg + c][n] = sum over packed rows of x[row + tap][c] * dy[row][n]: one long-K GEMM per group, with the
     // 48 output channels of a group on the N side (128x64 tiles, 75 % useful) -- on the M side they sat in 128-row tiles
     // (37 % useful) and this product was the slowest launch of the backward
-    TRY(Gemm(K * cg, cg, B * RS)
+    TRY(GemmX<EXACT>(K * cg, cg, B * RS)
             .a(BF(p.pgx), cg, true)
             .b(BF(p.pgdy) + (long)lead * cg, cg, true)
             .c(FP(p.dwf), cg, true)
@@ -1253,31 +1295,31 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     TRY(k_posconv_weight_bwd(FP(p.dwf), P + e->p_pc_g, P + e->p_pc_v, e->pc_norms, Gd + e->p_pc_g, Gd + e->p_pc_v, H, G, K, st));
     // input gradient: correlation of dy with the flipped, transposed taps
     const int shift = 2 * (K / 2) - K + 1;  // 1 for even K (SamePad drops the last frame), 0 for odd
-    TRY(Gemm(F, cg, K * cg)
+    TRY(GemmX<EXACT>(F, cg, K * cg)
             .a(BF(p.pgdy) + (long)shift * cg, cg)
             .b(e->pc_wb, (long)K * cg)
             .c(BF(p.dB), H)
             .batch(B, G, (long)RS * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
             .run(st));
   }
-  bf16* dh0 = (dh1 == BF(p.dA)) ? BF(p.dC) : BF(p.dA);
-  TRY(k_add_bf16(dh1, BF(p.dB), dh0, (long)M * H, st));
-  TRY(k_specaug_bwd(dh0, e->spec_mask, flens, Gd + e->p_mse, B, F, H, st, FP(p.lnpart), cs_floats));
+  AT* dh0 = (dh1 == BF(p.dA)) ? BF(p.dC) : BF(p.dA);
+  TRY(k_add_t<AT>(dh1, BF(p.dB), dh0, (long)M * H, st));
+  TRY(k_specaug_bwd_t<AT>(dh0, e->spec_mask, flens, Gd + e->p_mse, B, F, H, st, FP(p.lnpart), cs_floats));
   // ---- feature projection
-  const bf16* dh0d = dh0;
+  const AT* dh0d = dh0;
   if (c.feat_proj_dropout > 0.f) {
     // replay the projection-output dropout mask on the gradient
-    TRY(k_layernorm_fwd(dh0, nullptr, nullptr, nullptr, BF(p.scratchH), nullptr, nullptr, nullptr, M, H, 0.f,
+    TRY(k_layernorm_fwd_t<AT>(dh0, nullptr, nullptr, nullptr, BF(p.scratchH), nullptr, nullptr, nullptr, M, H, 0.f,
                         DS(c.feat_proj_dropout, DS_FEATPROJ), none, st));
     dh0d = BF(p.scratchH);
   }
-  TRY(Gemm(H, C, M).a(dh0d, H, true).b(BF(p.ln0), C, true).c(Gd + e->p_fp_w, C, true).run_wgrad(st, slab, p.slab_bytes));
-  TRY(k_colsum(dh0d, H, M, H, Gd + e->p_fp_b, st, FP(p.lnpart), cs_floats));
-  TRY(Gemm(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
-  bf16* dfeat = p.fe_train ? (((nc - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da)) : BF(p.ln0);  // frozen: scratch, never read
-  TRY(k_layernorm_bwd(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, dfeat, nullptr,
+  TRY(GemmX<EXACT>(H, C, M).a(dh0d, H, true).b(BF(p.ln0), C, true).c(Gd + e->p_fp_w, C, true).run_wgrad(st, slab, p.slab_bytes));
+  TRY(k_colsum_t<AT>(dh0d, H, M, H, Gd + e->p_fp_b, st, FP(p.lnpart), cs_floats));
+  TRY(GemmX<EXACT>(M, C, H).a(dh0d, H).b(W + e->p_fp_w, C, true).c(BF(p.dln0), C).run(st));
+  AT* dfeat = p.fe_train ? (((nc - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da)) : BF(p.ln0);  // frozen: scratch, never read
+  TRY(k_layernorm_bwd_t<AT>(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, dfeat, nullptr,
                       Gd + e->p_fpln_w, Gd + e->p_fpln_b, FP(p.lnpart), M, C, none, none, st));
-  if (p.fe_train) {
+  if constexpr (!EXACT) if (p.fe_train) {
     const bool ln_fe = c.feat_extract_norm == 1;
     // ---- a3 backward (--no_freeze): conv stack in reverse.  Per layer: GELU', weight gradient as per-utterance
     // K-major GEMMs on the overlapping-row operand (slabs summed in a fixed order), input gradient in column form
@@ -1285,29 +1327,29 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     for (int i = nc - 1; i >= 1; --i) {
       const int Ci = c.conv_dim[i - 1], Co = c.conv_dim[i], k = c.conv_kernel[i], s = c.conv_stride[i];
       const int Ti = p.Tl[i], Tp = p.Tl[i - 1];
-      const bf16* dact = (i & 1) ? BF(p.fe_db) : BF(p.fe_da);
-      bf16* dprev = ((i - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da);
-      const bf16* act_prev = BF(p.act[i - 1]);
+      const AT* dact = (i & 1) ? BF(p.fe_db) : BF(p.fe_da);
+      AT* dprev = ((i - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da);
+      const AT* act_prev = BF(p.act[i - 1]);
       if (ln_fe) {
         // layer-norm variant: act = gelu(LN(conv + bias)); one kernel takes d act through GELU' and the LayerNorm
         // (recomputed from the kept pre-LN values + statistics) and sums d gamma / d beta and the conv bias gradient
-        TRY(k_layernorm_bwd(dact, nullptr, BF(p.cpre[i]), FP(p.fe_st[i]), FP(p.fe_st[i]) + (size_t)B * Ti, P + e->p_cln_w[i], nullptr,
+        TRY(k_layernorm_bwd_t<AT>(dact, nullptr, BF(p.cpre[i]), FP(p.fe_st[i]), FP(p.fe_st[i]) + (size_t)B * Ti, P + e->p_cln_w[i], nullptr,
                             BF(p.fe_dp), BF(p.fe_dp), Gd + e->p_cln_w[i], Gd + e->p_cln_b[i], FP(p.lnpart), B * Ti, Co, none, none, st, none,
                             c.conv_bias ? Gd + e->p_conv_b[i] : nullptr, P + e->p_cln_b[i]));
       } else {
-        TRY(k_gelu_grad_mul(dact, BF(p.cpre[i]), BF(p.fe_dp), (long)B * Ti * Co, st));
+        TRY(k_gelu_grad_mul_t<AT>(dact, BF(p.cpre[i]), BF(p.fe_dp), (long)B * Ti * Co, st));
       }
-      TRY(Gemm(Co, k * Ci, Ti).a(BF(p.fe_dp), Co, true).b(act_prev, (long)s * Ci, true).c(FP(p.fe_slab), (long)k * Ci, true)
+      TRY(GemmX<EXACT>(Co, k * Ci, Ti).a(BF(p.fe_dp), Co, true).b(act_prev, (long)s * Ci, true).c(FP(p.fe_slab), (long)k * Ci, true)
               .batch(B, 1, (long)Ti * Co, 0, (long)Tp * Ci, 0, (long)Co * k * Ci, 0).run(st));
       TRY(k_sum_slabs(FP(p.fe_slab), B, (long)Co * k * Ci, FP(p.fe_dwr), st));
       TRY(k_conv_wgrad_unrearrange(FP(p.fe_dwr), Gd + e->p_conv_w[i], Co, Ci, k, st));
-      TRY(Gemm(Ti, k * Ci, Co).a(BF(p.fe_dp), Co).b(e->conv_w[i], (long)k * Ci, true).c(BF(p.fe_dxcol), (long)k * Ci)
+      TRY(GemmX<EXACT>(Ti, k * Ci, Co).a(BF(p.fe_dp), Co).b(e->conv_w[i], (long)k * Ci, true).c(BF(p.fe_dxcol), (long)k * Ci)
               .batch(B, 1, (long)Ti * Co, 0, 0, 0, (long)Ti * k * Ci, 0).run(st));
       TRY(k_col2im(BF(p.fe_dxcol), dprev, B, Tp, Ti, Ci, k, s, st));
     }
     if (ln_fe) {
       const int C0 = c.conv_dim[0], T0 = p.Tl[0];
-      TRY(k_layernorm_bwd(BF(p.fe_da), nullptr, BF(p.cpre[0]), FP(p.fe_st[0]), FP(p.fe_st[0]) + (size_t)B * T0, P + e->p_cln_w[0], nullptr,
+      TRY(k_layernorm_bwd_t<AT>(BF(p.fe_da), nullptr, BF(p.cpre[0]), FP(p.fe_st[0]), FP(p.fe_st[0]) + (size_t)B * T0, P + e->p_cln_w[0], nullptr,
                           BF(p.fe_dp), BF(p.fe_dp), Gd + e->p_cln_w[0], Gd + e->p_cln_b[0], FP(p.lnpart), B * T0, C0, none, none, st, none,
                           c.conv_bias ? Gd + e->p_conv_b[0] : nullptr, P + e->p_cln_b[0]));
       TRY(k_conv0_wgrad(BF(p.fe_dp), e->last_input, Gd + e->p_conv_w[0], FP(p.fe_c0), B, p.T, T0, C0, c.conv_kernel[0],
@@ -1327,12 +1369,14 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
 }
 
 extern "C" int ssak_w2v2_backward(ssak_w2v2* e, const float* dlogits, void* workspace, size_t workspace_bytes, void* stream) {
-  SSAK_REQUIRE(dlogits, "w2v2_backward: null pointer");
-  return backward_impl(e, dlogits, nullptr, workspace, workspace_bytes, stream);
+  SSAK_REQUIRE(e && dlogits, "w2v2_backward: null pointer");
+  if (e->cfg.exact) return backward_impl<float>(e, dlogits, nullptr, workspace, workspace_bytes, stream);
+  return backward_impl<bf16>(e, dlogits, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ssak_w2v2_backward_hidden(ssak_w2v2* e, const void* dhidden_bf16, void* workspace, size_t workspace_bytes,
                                          void* stream) {
-  SSAK_REQUIRE(dhidden_bf16, "w2v2_backward_hidden: null pointer");
-  return backward_impl(e, nullptr, (const bf16*)dhidden_bf16, workspace, workspace_bytes, stream);
+  SSAK_REQUIRE(e && dhidden_bf16, "w2v2_backward_hidden: null pointer");
+  SSAK_REQUIRE(!e->cfg.exact, "w2v2_backward_hidden: not built for the fp32-exact mode");
+  return backward_impl<bf16>(e, nullptr, (const bf16*)dhidden_bf16, workspace, workspace_bytes, stream);
 }

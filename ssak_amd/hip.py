@@ -32,7 +32,7 @@ class W2V2Config(C.Structure):
                 ("layer_norm_eps", C.c_float), ("attention_dropout", C.c_float), ("hidden_dropout", C.c_float),
                 ("activation_dropout", C.c_float), ("feat_proj_dropout", C.c_float), ("final_dropout", C.c_float),
                 ("freeze_feature_encoder", C.c_int), ("arch", C.c_int), ("num_mel_bins", C.c_int),
-                ("max_source_positions", C.c_int)]
+                ("max_source_positions", C.c_int), ("exact", C.c_int)]
 
 
 class ProfEntry(C.Structure):
@@ -70,6 +70,7 @@ def _load():
         "ssak_ctc_align_workspace_bytes": (sz, [i32, i32]),
         "ssak_ctc_forced_align": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "ssak_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp]),
         "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "ssak_gemm_tile_order": (i32, [i32]),
         "ssak_prof_enable": (i32, [i32]),
@@ -249,6 +250,19 @@ def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=
         ws = _ws(((M + 63) // 64) * N * 4, A.device)
     check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
                              0 if ws is None else ws.numel(), stream()))
+    return C_out
+
+
+def gemm_f32(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
+             sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
+             accumulate=False, drop_p=0.0, drop_stream=0, drop_seed=0, colsum_out=None, bias_s2=0):
+    """The fp32 GEMM of the exact mode (``ssak_gemm_f32``): same descriptor as :func:`gemm`, float tensors."""
+    d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
+                 sc[1], float(alpha), epilogue, 1, int(accumulate), 1, float(drop_p), drop_stream, drop_seed, bias_s2, 0,
+                 int(colsum_out is not None))
+    if colsum_out is not None:
+        aux_out = colsum_out
+    check(lib.ssak_gemm_f32(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), stream()))
     return C_out
 
 

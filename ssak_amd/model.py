@@ -71,14 +71,19 @@ def compute_mask_indices(shape, mask_prob, mask_length, lengths=None, min_masks=
 
 class Wav2Vec2ForCTC:
     def __init__(self, config: Wav2Vec2Config, device: str = "cuda:0", freeze_feature_encoder: bool = True,
-                 seed: int = 69):
+                 seed: int = 69, exact: Optional[bool] = None):
+        """``exact`` (default: environment SSAK_EXACT=1): the fp32-exact VERIFICATION mode of the engine -- float activations,
+        fp32 matrix products on the master weights, exact erf GELU -- comparable with the fp32 reference at 1e-4; slow."""
         if not torch.cuda.is_available():
             raise RuntimeError("ssak_amd needs an MI355X: there is no CPU fallback for the acoustic model")
         self.config = config
         self.device = torch.device(device)
         self.training = False
         self.freeze = freeze_feature_encoder
+        import os
+        self.exact = bool(int(os.environ.get("SSAK_EXACT", "0"))) if exact is None else bool(exact)
         c = self._c_config(config, freeze_feature_encoder)
+        c.exact = int(self.exact)
         self._finish_init(c, seed)
 
     @staticmethod
