@@ -132,6 +132,12 @@ int ssak_ctc_forced_align(const float* emission, const int32_t* tokens, int F, i
 #define SSAK_EPI_NONE 0
 #define SSAK_EPI_GELU 1
 #define SSAK_EPI_MUL_GELU_GRAD 2
+/* The feed-forward pair of the encoder layers (Wav2Vec2FeedForward, modeling_wav2vec2.py:565-572, and its autograd): the
+ * forward GEMM computes y = dropout(gelu(x)) and, instead of the pre-activation x, saves the backward's whole elementwise
+ * factor f = gelu'(x) * keep / (1 - p) to `aux_out` (same element offsets as C); the backward GEMM then only multiplies,
+ * C *= aux_in -- no exp, no reciprocal and no mask hash in the epilogue that used to be the slowest of the layer. */
+#define SSAK_EPI_GELU_SAVE_GRAD 3
+#define SSAK_EPI_MUL_AUX 4
 typedef struct {
   int M, N, K;
   int a_kmajor, b_kmajor;
@@ -177,9 +183,9 @@ int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs /*host*/, int n, const vo
 int ssak_gemm_tile_order(int dynamic);
 
 /* Per-launch timing for the roofline report (measurement aid, not on the reference's path): while enabled, launches are
- * bracketed by HIP events on their own stream; ssak_prof_collect waits for them and returns one entry per slot: the GEMM
- * instantiations (slots 0..32, named as rocprofv3 prints them) and the other kernel classes of the train step (attention,
- * LayerNorm, conv0, AdamW, CTC, ...), each with launches / summed ms / ALGORITHMIC work -- flops for SSAK_BOUND_MFMA slots,
+ * bracketed by HIP events on their own stream; ssak_prof_collect waits for them and returns one entry per slot: the kernel
+ * classes of the train step (attention, LayerNorm, conv0, AdamW, CTC, ...) and every GEMM instantiation launched so far
+ * (named as rocprofv3 prints it), each with launches / summed ms / ALGORITHMIC work -- flops for SSAK_BOUND_MFMA slots,
  * bytes for SSAK_BOUND_HBM / SSAK_BOUND_LATENCY slots.  ssak_prof_enable(0) = off, (1) = every launch, (2 + i) = only slot i:
  * an event pair keeps consecutive kernels from overlapping head to tail, and bracketing all launches of a train step costs
  * a few per cent of it, so a benchmark surveys all slots in warm-up steps and times only the slot it reports on inside its
@@ -195,7 +201,7 @@ typedef struct {
   int bound;
 } ssak_prof_entry;
 int ssak_prof_enable(int on);
-int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 64; returns the number of entries */
+int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 128; returns the number of entries */
 
 /* ---- a7 (part): fused self-attention, head_dim 64 --------------------------------------------
  * Replaces Wav2Vec2Attention's softmax(QK^T d^-0.5 + key mask) -> dropout -> .V and its autograd

@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <string.h>
+
+#include <mutex>
 #include <vector>
 
 #include "kernels.h"
@@ -19,8 +22,8 @@ extern "C" int ssak_version(void) { return 100; }
 extern "C" const char* ssak_last_error(void) { return g_err; }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around launches, on the launch's own stream ----
-// Slots 0..32 are the GEMM instantiations (named as rocprofv3 prints them); the slots after them are the other kernel
-// classes of the train step (kernels.h: PROF_*).  An event pair keeps consecutive kernels from overlapping head to tail, so
+// The first slots are the kernel classes of the train step (kernels.h: PROF_*); every GEMM instantiation registers a slot
+// under its own name (as rocprofv3 prints it) at its first launch.  An event pair keeps consecutive kernels from overlapping head to tail, so
 // bracketing everything costs a few per cent of a step: benchmarks survey all slots in warm-up steps and bracket one slot
 // inside their timed region (ssak_prof_enable(2 + slot)).
 namespace {
@@ -42,28 +45,49 @@ hipEvent_t prof_event() {
   (void)hipEventCreate(&e);
   return e;
 }
-const char* kLayoutNames[8] = {"128, 128, 2, 2, false, false", "128, 128, 2, 2, false, true", "128, 128, 2, 2, true, false",
-                               "128, 128, 2, 2, true, true",   "128, 64, 2, 2, false, false",  "128, 64, 2, 2, false, true",
-                               "128, 64, 2, 2, true, false",   "128, 64, 2, 2, true, true"};
-struct ClassInfo {
-  const char* name;
-  int bound;  // SSAK_BOUND_*
+struct SlotInfo {
+  char name[112];
+  int bound;
 };
-const ClassInfo kClasses[PROF_SLOTS - PROF_GEMM_SLOTS] = {
-    {"attn_fwd_kernel (fused attention forward)", SSAK_BOUND_MFMA},
-    {"attn_bwd_dq_kernel + attn_bwd_dkv_kernel (fused attention backward)", SSAK_BOUND_MFMA},
-    {"ln_fwd_kernel (residual + dropout + LayerNorm)", SSAK_BOUND_HBM},
-    {"ln_bwd_kernel (LayerNorm backward + column partials)", SSAK_BOUND_HBM},
-    {"conv0_moments + conv0_channel_stats + conv0_kernel (conv0 + GroupNorm + GELU)", SSAK_BOUND_HBM},
-    {"adamw_kernel (clip + AdamW + bf16 shadow)", SSAK_BOUND_HBM},
-    {"sumsq_kernel (gradient norm)", SSAK_BOUND_HBM},
-    {"ctc_lsm + ctc_lat + ctc_grad (CTC loss + gradient)", SSAK_BOUND_LATENCY},
-    {"norm_stats + norm_apply (waveform normalise)", SSAK_BOUND_HBM},
-    {"row / element-wise helpers (pack, SpecAugment, casts, column sums, GELU', adds, reductions)", SSAK_BOUND_HBM},
-    {"positional-conv weight-norm prepare / backward", SSAK_BOUND_HBM},
-    {"softmax fwd / bwd (unfused attention fallback)", SSAK_BOUND_HBM},
-};
+SlotInfo g_slots[PROF_MAX_SLOTS];
+int g_nslots = 0;
+std::mutex g_slot_mu;
+int register_locked(const char* name, int bound) {
+  for (int i = 0; i < g_nslots; ++i)
+    if (!strcmp(g_slots[i].name, name)) return i;
+  if (g_nslots >= PROF_MAX_SLOTS) return PROF_MAX_SLOTS - 1;  // (overflow: share the last slot)
+  snprintf(g_slots[g_nslots].name, sizeof(g_slots[g_nslots].name), "%s", name);
+  g_slots[g_nslots].bound = bound;
+  return g_nslots++;
+}
+void register_classes() {
+  static const struct {
+    const char* name;
+    int bound;
+  } kClasses[PROF_CLASS_SLOTS] = {
+      {"attn_fwd_kernel (fused attention forward)", SSAK_BOUND_MFMA},
+      {"attn_bwd_dq_kernel + attn_bwd_dkv_kernel (fused attention backward)", SSAK_BOUND_MFMA},
+      {"ln_fwd_kernel (residual + dropout + LayerNorm)", SSAK_BOUND_HBM},
+      {"ln_bwd_kernel (LayerNorm backward + column partials)", SSAK_BOUND_HBM},
+      {"conv0_moments + conv0_channel_stats + conv0_kernel (conv0 + GroupNorm + GELU)", SSAK_BOUND_HBM},
+      {"adamw_kernel (clip + AdamW + bf16 shadow)", SSAK_BOUND_HBM},
+      {"sumsq_kernel (gradient norm)", SSAK_BOUND_HBM},
+      {"ctc_lsm + ctc_lat + ctc_grad (CTC loss + gradient)", SSAK_BOUND_LATENCY},
+      {"norm_stats + norm_apply (waveform normalise)", SSAK_BOUND_HBM},
+      {"row / element-wise helpers (pack, SpecAugment, casts, column sums, GELU', adds, reductions)", SSAK_BOUND_HBM},
+      {"positional-conv weight-norm prepare / backward", SSAK_BOUND_HBM},
+      {"softmax fwd / bwd (unfused attention fallback)", SSAK_BOUND_HBM},
+  };
+  if (g_nslots == 0)
+    for (int i = 0; i < PROF_CLASS_SLOTS; ++i) register_locked(kClasses[i].name, kClasses[i].bound);
+}
 }  // namespace
+
+int ssak_prof_register(const char* name, int bound) {
+  std::lock_guard<std::mutex> lock(g_slot_mu);
+  register_classes();
+  return register_locked(name, bound);
+}
 
 bool ssak_prof_wanted(int slot) { return g_prof_mode == 1 || g_prof_mode == slot + 2; }
 
@@ -87,24 +111,19 @@ extern "C" int ssak_prof_enable(int on) {
 }
 
 extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
-  SSAK_REQUIRE(out && cap >= PROF_SLOTS, "prof_collect: need room for %d entries", PROF_SLOTS);
-  for (int i = 0; i < PROF_SLOTS; ++i) {
-    out[i].bound = SSAK_BOUND_MFMA;
-    if (i < 16)
-      snprintf(out[i].name, sizeof(out[i].name), "%s<%s>", i < 8 ? "gemm_dma_kernel" : "gemm_kernel", kLayoutNames[i & 7]);
-    else if (i < 20)
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
-    else if (i < 32)
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<%d, %s, %s, false>", (i - 20) / 4 + 2, (i & 2) ? "true" : "false", (i & 1) ? "true" : "false");
-    else if (i == 32)
-      snprintf(out[i].name, sizeof(out[i].name), "gemm_p8_kernel<4, true, true, true>");  // grouped weight gradients
-    else {
-      snprintf(out[i].name, sizeof(out[i].name), "%s", kClasses[i - PROF_GEMM_SLOTS].name);
-      out[i].bound = kClasses[i - PROF_GEMM_SLOTS].bound;
+  SSAK_REQUIRE(out && cap >= PROF_MAX_SLOTS, "prof_collect: need room for %d entries", PROF_MAX_SLOTS);
+  int n;
+  {
+    std::lock_guard<std::mutex> lock(g_slot_mu);
+    register_classes();
+    n = g_nslots;
+    for (int i = 0; i < n; ++i) {
+      snprintf(out[i].name, sizeof(out[i].name), "%s", g_slots[i].name);
+      out[i].bound = g_slots[i].bound;
+      out[i].launches = 0;
+      out[i].total_ms = 0.0;
+      out[i].total_flops = 0.0;
     }
-    out[i].launches = 0;
-    out[i].total_ms = 0.0;
-    out[i].total_flops = 0.0;
   }
   for (ProfRec& r : g_prof) {
     SSAK_HIP(hipEventSynchronize(r.e1));
@@ -117,5 +136,5 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
     g_event_pool.push_back(r.e1);
   }
   g_prof.clear();
-  return PROF_SLOTS;
+  return n;
 }

@@ -639,7 +639,14 @@ int launch(const GemmParams& p, bool dma, hipStream_t st) {
     }
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
-  ProfScope prof_scope((dma ? 0 : 8) + (BN == 128 ? 0 : 4) + (A_KM ? 2 : 0) + (B_KM ? 1 : 0), 2.0 * p.M * p.N * (double)p.K * p.nz, st);
+  static int slots[2] = {-1, -1};
+  if (slots[dma] < 0) {
+    char nm[112];
+    snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d, %s, %s%s>", dma ? "gemm_dma_kernel" : "gemm_kernel", BM, BN, WM, WN, A_KM ? "true" : "false",
+             B_KM ? "true" : "false", dma ? ", 64" : "");
+    slots[dma] = ssak_prof_register(nm, SSAK_BOUND_MFMA);
+  }
+  ProfScope prof_scope(slots[dma], 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)nblk), NTHREADS, lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -655,7 +662,13 @@ int launch_big(const GemmParams& p, hipStream_t st) {
     attr_done = true;
   }
   const long nblk = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
-  ProfScope prof_scope(16 + (A_KM ? 2 : 0) + (B_KM ? 1 : 0), 2.0 * p.M * p.N * (double)p.K * p.nz, st);
+  static int slot = -1;
+  if (slot < 0) {
+    char nm[112];
+    snprintf(nm, sizeof(nm), "gemm_dma3_kernel<256, 128, 4, 2, %s, %s>", A_KM ? "true" : "false", B_KM ? "true" : "false");
+    slot = ssak_prof_register(nm, SSAK_BOUND_MFMA);
+  }
+  ProfScope prof_scope(slot, 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)nblk), 512, lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -726,7 +739,11 @@ GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
     s_lo = 1;
     s_hi = (d->epilogue == SSAK_EPI_NONE && !(d->drop_p > 0.f)) ? std::max(1, std::min(32, nkt / 4)) : 1;
   }
-  const bool p8_ok = dma && d->M >= 256 && d->N >= 256 && g_env_p8 != 0;
+  // (the feed-forward epilogue pair exists on the persistent kernel only for the layouts the encoder uses: other layouts take
+  // the 128 x 128 kernels, whose LDS-staged epilogue handles every mode)
+  const bool p8_layout_ok = (d->epilogue != SSAK_EPI_GELU_SAVE_GRAD || (!d->a_kmajor && !d->b_kmajor)) &&
+                            (d->epilogue != SSAK_EPI_MUL_AUX || (!d->a_kmajor && d->b_kmajor));
+  const bool p8_ok = dma && d->M >= 256 && d->N >= 256 && g_env_p8 != 0 && p8_layout_ok;
   GemmPlan best_def{false, 0, s_lo, 1e30}, best_p8{true, 256, s_lo, 1e30};
   for (int s = s_lo; s <= s_hi; ++s) {
     if (d->split_k == 0 && s > 1 && (size_t)s * nz * (size_t)d->M * d->N * sizeof(float) > workspace_bytes) break;
@@ -762,8 +779,8 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   SSAK_REQUIRE(((d->sa1 | d->sa2 | d->sb1 | d->sb2) & 7) == 0 && ((d->sc1 | d->sc2) & 3) == 0 &&
                    !(d->drop_p > 0.f && ((d->sc1 | d->sc2 | d->ldc) & 3)), "gemm: batch strides must keep 16-byte (A,B) / 8-byte (C) alignment");
   SSAK_REQUIRE(d->nb1 > 0 && d->nb2 > 0, "gemm: batch counts must be >= 1");
-  SSAK_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2, "gemm: bad epilogue %d", d->epilogue);
-  SSAK_REQUIRE(d->epilogue != SSAK_EPI_MUL_GELU_GRAD || aux_in, "gemm: MUL_GELU_GRAD needs aux_in");
+  SSAK_REQUIRE(d->epilogue >= 0 && d->epilogue <= SSAK_EPI_MUL_AUX, "gemm: bad epilogue %d", d->epilogue);
+  SSAK_REQUIRE((d->epilogue != SSAK_EPI_MUL_GELU_GRAD && d->epilogue != SSAK_EPI_MUL_AUX) || aux_in, "gemm: MUL_GELU_GRAD / MUL_AUX need aux_in");
   SSAK_REQUIRE(!d->accumulate || d->out_f32, "gemm: accumulate needs fp32 output");
   SSAK_REQUIRE(d->split_k >= 0, "gemm: split_k must be >= 0 (0 = choose)");
   SSAK_REQUIRE(d->split_k <= 1 || d->epilogue == SSAK_EPI_NONE, "gemm: split_k supports the plain epilogue only");
@@ -783,7 +800,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   float* colsum_out = nullptr;
   bool colsum_fused = false;
   if (d->colsum) {
-    SSAK_REQUIRE(aux_out && d->epilogue != SSAK_EPI_GELU && d->nb1 == 1 && d->nb2 == 1 && d->split_k <= 1 && !d->out_f32,
+    SSAK_REQUIRE(aux_out && d->epilogue != SSAK_EPI_GELU && d->epilogue != SSAK_EPI_GELU_SAVE_GRAD && d->nb1 == 1 && d->nb2 == 1 && d->split_k <= 1 && !d->out_f32,
                  "gemm: colsum needs aux_out = float[N], a bf16 C, no batches / split_k / GELU side output");
     colsum_out = reinterpret_cast<float*>(aux_out);
     aux_out = nullptr;
@@ -852,7 +869,6 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   if (plan.p8) {
     p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
-    ProfScope prof_scope(20 + (p8_bm / 64 - 2) * 4 + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0), 2.0 * p.M * p.N * (double)p.K * p.nz, st);
     rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
   } else if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
     p.tiles_m = ssak_cdiv(d->M, 256);
@@ -943,7 +959,6 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
   p.drop_scale = 1.f;
   p.kt_per_split = ssak_cdiv(d0.K, BK);
   hipStream_t st = (hipStream_t)stream;
-  ProfScope prof_scope(32, flops, st);
   const int rc = ssak_gemm_p8_launch_grouped(&p, n, A, B, C, Ms, Ns, lda, ldb, ldc, ea, eb, d0.a_kmajor, d0.b_kmajor, st);
   return rc;
 }

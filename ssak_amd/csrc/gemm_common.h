@@ -127,8 +127,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         *reinterpret_cast<f32x4*>(S + o + 4) = t1;
         continue;
       }
-      if (p.epilogue == SSAK_EPI_GELU) {
-        if (p.aux_out) {
+      float gd[8];
+      const bool save_grad = p.epilogue == SSAK_EPI_GELU_SAVE_GRAD;
+      if (p.epilogue == SSAK_EPI_GELU || save_grad) {
+        if (!save_grad && p.aux_out) {
           bf16x8 q;
 #pragma unroll
           for (int r = 0; r < 8; ++r) q[r] = (bf16)v[r];
@@ -136,10 +138,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
-          const f32x2 y = gelu2((f32x2){v[r], v[r + 1]});
+          const f32x2 x = {v[r], v[r + 1]};
+          if (save_grad) {
+            const f32x2 d = gelu_grad2(x);
+            gd[r] = d[0];
+            gd[r + 1] = d[1];
+          }
+          const f32x2 y = gelu2(x);
           v[r] = y[0];
           v[r + 1] = y[1];
         }
+      } else if (p.epilogue == SSAK_EPI_MUL_AUX) {
+        const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(p.aux_in + o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= (float)a8[r];
       } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
         const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(p.aux_in + o);
 #pragma unroll
@@ -155,7 +167,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           const uint32_t w = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o + 2 * h);
           v[2 * h] = ((w & 0xffffu) >= p.drop_thresh) ? v[2 * h] * p.drop_scale : 0.f;
           v[2 * h + 1] = ((w >> 16) >= p.drop_thresh) ? v[2 * h + 1] * p.drop_scale : 0.f;
+          if (save_grad) {
+            gd[2 * h] = ((w & 0xffffu) >= p.drop_thresh) ? gd[2 * h] * p.drop_scale : 0.f;
+            gd[2 * h + 1] = ((w >> 16) >= p.drop_thresh) ? gd[2 * h + 1] * p.drop_scale : 0.f;
+          }
         }
+      }
+      if (save_grad && p.aux_out) {
+        bf16x8 q;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) q[r] = (bf16)gd[r];
+        *reinterpret_cast<bf16x8*>(p.aux_out + o) = q;
       }
       if (p.out_f32) {
         float* dst = reinterpret_cast<float*>(p.C) + o;
@@ -204,8 +226,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     const long o = coff + (long)m * p.ldc + n;
     float v[4] = {t[0], t[1], t[2], t[3]};
-    if (p.epilogue == SSAK_EPI_GELU) {
-      if (p.aux_out) {
+    float gd[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool save_grad = p.epilogue == SSAK_EPI_GELU_SAVE_GRAD;
+    if (p.epilogue == SSAK_EPI_GELU || save_grad) {
+      if (!save_grad && p.aux_out) {
         if (full) {
           bf16x4 q = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
           *reinterpret_cast<bf16x4*>(p.aux_out + o) = q;
@@ -216,7 +240,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      for (int r = 0; r < 4; ++r) {
+        if (save_grad) gd[r] = gelu_grad_f(v[r]);
+        v[r] = gelu_f(v[r]);
+      }
+    } else if (p.epilogue == SSAK_EPI_MUL_AUX) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) v[r] *= (float)p.aux_in[o + r];
     } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
       if (full) {
         const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux_in + o);
@@ -236,6 +267,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       v[1] = ((w0 >> 16) >= p.drop_thresh) ? v[1] * p.drop_scale : 0.f;
       v[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[2] * p.drop_scale : 0.f;
       v[3] = ((w1 >> 16) >= p.drop_thresh) ? v[3] * p.drop_scale : 0.f;
+      if (save_grad) {
+        gd[0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[0] * p.drop_scale : 0.f;
+        gd[1] = ((w0 >> 16) >= p.drop_thresh) ? gd[1] * p.drop_scale : 0.f;
+        gd[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[2] * p.drop_scale : 0.f;
+        gd[3] = ((w1 >> 16) >= p.drop_thresh) ? gd[3] * p.drop_scale : 0.f;
+      }
+    }
+    if (save_grad && p.aux_out) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) p.aux_out[o + r] = (bf16)gd[r];
     }
     if (p.out_f32) {
       float* dst = reinterpret_cast<float*>(p.C) + o;
@@ -316,12 +358,22 @@ __device__ __forceinline__ bool epilogue_direct_ok(const GemmParams& p, int bm0,
   return bn0 + wn0 + 64 <= p.N && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (coff & 7) == 0 &&
          (((uintptr_t)p.aux_in | (uintptr_t)p.aux_out | (uintptr_t)p.C) & 15) == 0;
 }
-template <int MI>
+// EPI: -1 = the general-purpose form (epilogue mode read from the parameters: NONE / GELU / MUL_GELU_GRAD); SSAK_EPI_GELU_SAVE_GRAD
+// or SSAK_EPI_MUL_AUX = a form specialised for the feed-forward pair.  The two are separate instantiations because the modes
+// are compiled into one body otherwise and the widest of them sets the register allocation of ALL (the saved-gradient forward
+// keeps 16 more values live than the rest: compiled in, it pushed every 256-row instantiation of the persistent kernel from
+// 36-60 to 80-144 bytes of scratch per lane and the 192-row ones from none to 12-48, and slowed every launch by 2-14 %).
+// Further specialisations (internal codes, chosen by the launcher when the descriptor qualifies): the plain bf16 store
+// (bias / alpha only -- the qkv, output and feed-forward-down projections and every plain dX product), the plain fp32 store
+// (weight gradients, optionally accumulating) and GELU without a saved pre-activation (the frozen conv stack).
+constexpr int P8_EPI_PLAIN_BF16 = 100, P8_EPI_PLAIN_F32 = 101, P8_EPI_GELU_ONLY = 102;
+template <int MI, int EPI = -1>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 (&acc)[MI][4], const BiasRegs<4>& br, int bm0,
                                                      int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split) {
+  constexpr bool GENERAL = EPI < 0;
   const int lm = lane & 15, lq = lane >> 4;
   const int rows_valid = p.M - (bm0 + wm0 + lm);  // this lane's row 16 * i + lm exists iff 16 * i < rows_valid
-  if (p.split_k > 1) {  // raw partial sums into this split's slab
+  if (GENERAL && p.split_k > 1) {  // raw partial sums into this split's slab
     float* S = p.slab + ((long)split * p.nz + z) * (long)p.M * p.N + (long)(bm0 + wm0 + lm) * p.N + bn0 + wn0 + 4 * lq;
     const long step = 16L * p.N;
 #pragma unroll
@@ -334,8 +386,8 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
   }
   long orow = z1 * p.sc1 + z2 * p.sc2 + (long)(bm0 + wm0 + lm) * p.ldc + bn0 + wn0;  // row lm of the 16-row group, column 0
   const long step = 16L * p.ldc;
-  const bool plain = p.epilogue == SSAK_EPI_NONE && !p.drop_thresh && !p.colsum;
-  if (plain && !p.out_f32) {
+  const bool plain = EPI == P8_EPI_PLAIN_BF16 || (GENERAL && p.epilogue == SSAK_EPI_NONE && !p.drop_thresh && !p.colsum && !p.out_f32);
+  if (plain) {
 #pragma unroll
     for (int i = 0; i < MI; ++i, orow += step) {
       float v[4][4];
@@ -348,6 +400,26 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
     }
     return;
   }
+  if constexpr (EPI == P8_EPI_PLAIN_BF16) return;
+  if constexpr (EPI == P8_EPI_PLAIN_F32) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i, orow += step) {
+      if (16 * i < rows_valid) {
+        float* dst = reinterpret_cast<float*>(p.C) + orow + 4 * lq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 t = acc[i][j] * p.alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] += br.v[j][r];
+          if (p.accumulate) t += *reinterpret_cast<const f32x4*>(dst + 16 * j);
+          *reinterpret_cast<f32x4*>(dst + 16 * j) = t;
+        }
+      }
+    }
+    return;
+  }
+  constexpr bool WITH_COLSUM = GENERAL || EPI == SSAK_EPI_MUL_AUX;
+  constexpr bool WITH_DROP = GENERAL || EPI == SSAK_EPI_GELU_SAVE_GRAD;
   float cs[4][4];  // column sums over this lane's rows (p.colsum)
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -363,17 +435,33 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] * p.alpha + br.v[j][r];
-    if (p.epilogue == SSAK_EPI_GELU) {
-      if (p.aux_out) store_bf16_rows(p.aux_out + orow + 16 * lq, v, rowok);
+    float gd[4][4];  // SSAK_EPI_GELU_SAVE_GRAD: gelu'(pre), masked and scaled like the output -- the backward's factor
+    constexpr bool save_grad = EPI == SSAK_EPI_GELU_SAVE_GRAD;
+    if ((GENERAL && p.epilogue == SSAK_EPI_GELU) || save_grad || EPI == P8_EPI_GELU_ONLY) {
+      if (GENERAL && p.aux_out) store_bf16_rows(p.aux_out + orow + 16 * lq, v, rowok);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
-          const f32x2 y = gelu2((f32x2){v[j][r], v[j][r + 1]});
+          const f32x2 x = {v[j][r], v[j][r + 1]};
+          if (save_grad) {
+            const f32x2 d = gelu_grad2(x);
+            gd[j][r] = d[0];
+            gd[j][r + 1] = d[1];
+          }
+          const f32x2 y = gelu2(x);
           v[j][r] = y[0];
           v[j][r + 1] = y[1];
         }
-    } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
+    } else if (EPI == SSAK_EPI_MUL_AUX) {
+      bf16x4 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = rowok ? *reinterpret_cast<const bf16x4*>(p.aux_in + oa + 16 * j) : (bf16x4){};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] *= (float)a[j][r];
+    } else if (GENERAL && p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
       bf16x4 a[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[j] = rowok ? *reinterpret_cast<const bf16x4*>(p.aux_in + oa + 16 * j) : (bf16x4){};
@@ -386,7 +474,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
           v[j][r + 1] *= y[1];
         }
     }
-    if (p.drop_thresh) {
+    if (WITH_DROP && p.drop_thresh) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t w0 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)(oa + 16 * j));
@@ -395,15 +483,22 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
         v[j][1] = ((w0 >> 16) >= p.drop_thresh) ? v[j][1] * p.drop_scale : 0.f;
         v[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[j][2] * p.drop_scale : 0.f;
         v[j][3] = ((w1 >> 16) >= p.drop_thresh) ? v[j][3] * p.drop_scale : 0.f;
+        if (save_grad) {
+          gd[j][0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[j][0] * p.drop_scale : 0.f;
+          gd[j][1] = ((w0 >> 16) >= p.drop_thresh) ? gd[j][1] * p.drop_scale : 0.f;
+          gd[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[j][2] * p.drop_scale : 0.f;
+          gd[j][3] = ((w1 >> 16) >= p.drop_thresh) ? gd[j][3] * p.drop_scale : 0.f;
+        }
       }
     }
-    if (p.colsum) {
+    if (save_grad && p.aux_out) store_bf16_rows(p.aux_out + orow + 16 * lq, gd, rowok);
+    if (WITH_COLSUM && p.colsum) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cs[j][r] += rowok ? v[j][r] : 0.f;
     }
-    if (p.out_f32) {
+    if (GENERAL && p.out_f32) {
       float* dst = reinterpret_cast<float*>(p.C) + oa;
       if (rowok) {
 #pragma unroll
@@ -417,7 +512,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
       store_bf16_rows(reinterpret_cast<bf16*>(p.C) + orow + 16 * lq, v, rowok);
     }
   }
-  if (p.colsum) {
+  if (WITH_COLSUM && p.colsum) {
     // sum over the 16 lanes of a row group (the wave tile's rows), fixed order; lane lm == 0 of each group writes the
     // 16 columns 16 * j + 4 * lq .. of its slot = (tile row, wave row); a small kernel adds the slots up afterwards
 #pragma unroll

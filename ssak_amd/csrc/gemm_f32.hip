@@ -106,8 +106,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Params p) {
       v = gelu_s<float>(v);
     } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
       v *= gelu_grad_s<float>(p.aux_in[o]);
+    } else if (p.epilogue == SSAK_EPI_MUL_AUX) {
+      v *= p.aux_in[o];
     }
-    if (p.drop_thresh) v = keep_bit(p.drop_seed, p.drop_stream, (uint64_t)o, p.drop_thresh) ? v * p.drop_scale : 0.f;
+    float gd = 0.f;
+    if (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) {
+      gd = gelu_grad_s<float>(v);
+      v = gelu_s<float>(v);
+    }
+    if (p.drop_thresh) {
+      const bool keep = keep_bit(p.drop_seed, p.drop_stream, (uint64_t)o, p.drop_thresh);
+      v = keep ? v * p.drop_scale : 0.f;
+      gd = keep ? gd * p.drop_scale : 0.f;
+    }
+    if (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD && p.aux_out) p.aux_out[o] = gd;
     cs += v;
     p.C[o] = p.accumulate ? p.C[o] + v : v;
   }
@@ -122,7 +134,7 @@ extern "C" int ssak_gemm_f32(const ssak_gemm_desc* d, const void* A, const void*
                              void* aux_out, void* stream) {
   SSAK_REQUIRE(d && A && B && C, "gemm_f32: null pointer");
   SSAK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->nb1 >= 1 && d->nb2 >= 1, "gemm_f32: bad shape %d x %d x %d", d->M, d->N, d->K);
-  SSAK_REQUIRE(d->epilogue != SSAK_EPI_MUL_GELU_GRAD || aux_in, "gemm_f32: MUL_GELU_GRAD needs aux_in");
+  SSAK_REQUIRE((d->epilogue != SSAK_EPI_MUL_GELU_GRAD && d->epilogue != SSAK_EPI_MUL_AUX) || aux_in, "gemm_f32: this epilogue needs aux_in");
   SSAK_REQUIRE(!d->colsum || (aux_out && d->epilogue != SSAK_EPI_GELU && d->nb1 * d->nb2 == 1), "gemm_f32: colsum needs aux_out [N], no GELU, no batches");
   F32Params p;
   p.A = (const float*)A;

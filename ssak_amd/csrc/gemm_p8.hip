@@ -195,7 +195,9 @@ struct P8Group {
   P8Problem pr[8];
 };
 
-template <int MH, bool A_KM, bool B_KM, bool GROUPED = false>
+// EPI: -1 = every epilogue mode of the general-purpose form; SSAK_EPI_GELU_SAVE_GRAD / SSAK_EPI_MUL_AUX = the feed-forward pair
+// (gemm_common.h: gemm_epilogue_direct), instantiated for the layouts the encoder uses them with.
+template <int MH, bool A_KM, bool B_KM, bool GROUPED = false, int EPI = -1>
 __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p, const P8Group grp) {
   constexpr int BM = 64 * MH, SEGA = 16 * MH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -277,8 +279,9 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     sa.template issue<1>(buf1 + 1 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
   };
   // vector-memory instructions the LDS-free epilogue issues per wave (stores only; vmcnt counts them like the DMA)
-  const int epi_vm = (p.split_k > 1 || p.out_f32 || (p.epilogue == SSAK_EPI_GELU && p.aux_out)) ? 8 * MH : 4 * MH;
-  const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD && !p.colsum;  // epilogues that only store (a fixed count)
+  const int epi_vm = (p.split_k > 1 || p.out_f32 || ((p.epilogue == SSAK_EPI_GELU || p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) && p.aux_out)) ? 8 * MH : 4 * MH;
+  static_assert(EPI != P8_EPI_PLAIN_F32 || GROUPED, "the fp32 form is instantiated for the grouped weight gradients");
+  const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD && p.epilogue != SSAK_EPI_MUL_AUX && !p.colsum;  // epilogues that only store (a fixed count)
 
   // Persistent over tiles (the host launches one workgroup per CU).  The next tile's first two K tiles are put in
   // flight BEFORE the current tile's epilogue, and the epilogue's stores are left to drain under the next main loop:
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
       }
     }
     if (interior) {
-      gemm_epilogue_direct<2 * MH>(pe, acc, bias_regs, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
+      gemm_epilogue_direct<2 * MH, EPI>(pe, acc, bias_regs, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
     } else {
       char* const lds_wave = smem + wave * 16384;
       gemm_epilogue<MH, 4>(pe, reinterpret_cast<f32x4(&)[MH][4]>(acc[0]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, c.split);
@@ -494,9 +497,9 @@ bool p8_dynamic() {
   return g_p8_dynamic == 1;
 }
 
-template <int MH, bool A_KM, bool B_KM>
+template <int MH, bool A_KM, bool B_KM, int EPI = -1>
 int launch_p8(const GemmParams& p, hipStream_t st) {
-  auto kern = gemm_p8_kernel<MH, A_KM, B_KM, false>;
+  auto kern = gemm_p8_kernel<MH, A_KM, B_KM, false, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
@@ -512,6 +515,13 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
   q.tile_ctr = nullptr;
   if (ntiles > n_cu && n_cu % 8 == 0 && p8_dynamic())
     if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
+  static int slot = -1;
+  if (slot < 0) {
+    char nm[112];
+    snprintf(nm, sizeof(nm), "gemm_p8_kernel<%d, %s, %s, false, %d>", MH, A_KM ? "true" : "false", B_KM ? "true" : "false", EPI);
+    slot = ssak_prof_register(nm, SSAK_BOUND_MFMA);
+  }
+  ProfScope prof_scope(slot, 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q, none);  // one persistent workgroup per CU
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -519,15 +529,34 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
 
 template <int MH>
 int dispatch_p8(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
+  // the feed-forward pair: specialised instantiations for the layouts the encoder layers run them with (forward: both
+  // operands K-contiguous; backward dX: the weight read K-major); ssak_gemm_bf16 keeps other layouts off this kernel
+  if (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) {
+    if (!a_km && !b_km) return launch_p8<MH, false, false, SSAK_EPI_GELU_SAVE_GRAD>(p, st);
+    ssak_set_error("gemm_p8: GELU_SAVE_GRAD is built for K-contiguous operands");
+    return SSAK_ERR_INVALID;
+  }
+  if (p.epilogue == SSAK_EPI_MUL_AUX) {
+    if (!a_km && b_km) return launch_p8<MH, false, true, SSAK_EPI_MUL_AUX>(p, st);
+    ssak_set_error("gemm_p8: MUL_AUX is built for a K-contiguous A and a K-major B");
+    return SSAK_ERR_INVALID;
+  }
+  // lean forms of the common modes (gemm_common.h): no dropout, no column sums, no split-K slabs
+  const bool no_extras = !p.drop_thresh && !p.colsum && p.split_k <= 1;
+  if (MH >= 3 && no_extras && !a_km) {
+    if (p.epilogue == SSAK_EPI_NONE && !p.out_f32 && !p.accumulate)
+      return b_km ? launch_p8<MH, false, true, P8_EPI_PLAIN_BF16>(p, st) : launch_p8<MH, false, false, P8_EPI_PLAIN_BF16>(p, st);
+    if (p.epilogue == SSAK_EPI_GELU && !p.aux_out && !p.out_f32 && !b_km) return launch_p8<MH, false, false, P8_EPI_GELU_ONLY>(p, st);
+  }
   if (!a_km && !b_km) return launch_p8<MH, false, false>(p, st);
   if (!a_km && b_km) return launch_p8<MH, false, true>(p, st);
   if (a_km && b_km) return launch_p8<MH, true, true>(p, st);
   return launch_p8<MH, true, false>(p, st);
 }
 
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, int EPI = -1>
 int launch_p8_grouped(const GemmParams& p, const P8Group& grp, hipStream_t st) {
-  auto kern = gemm_p8_kernel<4, A_KM, B_KM, true>;
+  auto kern = gemm_p8_kernel<4, A_KM, B_KM, true, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
@@ -539,6 +568,15 @@ int launch_p8_grouped(const GemmParams& p, const P8Group& grp, hipStream_t st) {
   q.tile_ctr = nullptr;
   if (grp.total_tiles > n_cu && n_cu % 8 == 0 && p8_dynamic())
     if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
+  static int slot = -1;
+  if (slot < 0) {
+    char nm[112];
+    snprintf(nm, sizeof(nm), "gemm_p8_kernel<4, %s, %s, true, %d>", A_KM ? "true" : "false", B_KM ? "true" : "false", EPI);
+    slot = ssak_prof_register(nm, SSAK_BOUND_MFMA);
+  }
+  double flops = 0.0;
+  for (int i = 0; i < grp.n; ++i) flops += 2.0 * grp.pr[i].M * grp.pr[i].N * (double)p.K;
+  ProfScope prof_scope(slot, flops, st);
   kern<<<dim3((unsigned)std::min(grp.total_tiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q, grp);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -587,6 +625,9 @@ int ssak_gemm_p8_launch_grouped(const void* params, int n, const void* const* A,
   grp.total_tiles = t0;
   if (!a_km && !b_km) return launch_p8_grouped<false, false>(p, grp, st);
   if (!a_km && b_km) return launch_p8_grouped<false, true>(p, grp, st);
-  if (a_km && b_km) return launch_p8_grouped<true, true>(p, grp, st);
+  if (a_km && b_km) {
+    if (p.out_f32 && p.epilogue == SSAK_EPI_NONE) return launch_p8_grouped<true, true, P8_EPI_PLAIN_F32>(p, grp, st);  // weight gradients
+    return launch_p8_grouped<true, true>(p, grp, st);
+  }
   return launch_p8_grouped<true, false>(p, grp, st);
 }

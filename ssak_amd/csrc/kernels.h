@@ -2,13 +2,15 @@
 #pragma once
 #include "common.h"
 
-// Per-launch timing slots (api.cpp; include/ssak_hip.h: ssak_prof_*).  GEMM instantiations own 0..32.
+// Per-launch timing slots (api.cpp; include/ssak_hip.h: ssak_prof_*).  The kernel classes below own the first slots; every
+// GEMM instantiation registers a slot under its own name (as rocprofv3 prints it) the first time it is launched.
 enum : int {
-  PROF_GEMM_SLOTS = 33,
-  PROF_ATTN_FWD = 33, PROF_ATTN_BWD, PROF_LN_FWD, PROF_LN_BWD, PROF_CONV0, PROF_ADAMW, PROF_SUMSQ, PROF_CTC, PROF_WAVE_NORM,
+  PROF_ATTN_FWD = 0, PROF_ATTN_BWD, PROF_LN_FWD, PROF_LN_BWD, PROF_CONV0, PROF_ADAMW, PROF_SUMSQ, PROF_CTC, PROF_WAVE_NORM,
   PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX,
-  PROF_SLOTS
+  PROF_CLASS_SLOTS
 };
+constexpr int PROF_MAX_SLOTS = 128;
+int ssak_prof_register(const char* name, int bound);  // -> slot id (idempotent per name); thread-safe
 bool ssak_prof_wanted(int slot);
 // Brackets everything launched on `st` during its lifetime when the slot is being profiled; `work` = the ALGORITHMIC flops
 // (MFMA-bound slots) or bytes (HBM / latency-bound slots) of what it covers.

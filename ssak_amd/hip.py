@@ -121,7 +121,7 @@ def _load():
 
 lib = _load()
 SSAK_OK, SSAK_ERR_INVALID, SSAK_ERR_LAUNCH, SSAK_ERR_STATE = 0, -1, -2, -3
-EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_GELU_SAVE_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4
 REDUCTION = {"sum": 0, "mean": 1}
 
 
@@ -290,8 +290,8 @@ BOUNDS = {0: "mfma", 1: "hbm", 2: "latency"}
 def prof_collect():
     """[(kernel name, launches, total ms, total algorithmic work, bound)] since the last collect; work = flops for "mfma"
     slots, bytes for "hbm" / "latency" slots."""
-    arr = (ProfEntry * 64)()
-    n = lib.ssak_prof_collect(arr, 64)
+    arr = (ProfEntry * 128)()
+    n = lib.ssak_prof_collect(arr, 128)
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops, BOUNDS[arr[i].bound]) for i in range(n)]

@@ -525,3 +525,49 @@ def test_cast_and_colsum_helpers(hip):
         out2 = torch.empty_like(out)
         hip.check(hip.lib.ssak_colsum_bf16(hip.ptr(X), N, M, N, hip.ptr(out2), hip.ptr(ws), ws.numel(), hip.stream()))
         assert torch.equal(out, out2)  # fixed summation order
+
+
+@pytest.mark.parametrize("M,N,K", [(15968, 3072, 768), (1000, 512, 256), (300, 200, 136)])
+def test_gemm_feed_forward_epilogue_pair(hip, M, N, K):
+    """SSAK_EPI_GELU_SAVE_GRAD / SSAK_EPI_MUL_AUX (the feed-forward pair of the encoder layers): the forward GEMM returns
+    dropout(gelu(x)) -- bit-identical to SSAK_EPI_GELU with the same dropout stream -- and saves f = gelu'(x) * keep / (1 - p)
+    instead of x; the backward GEMM multiplies by f and sums its columns.  Against torch on the fp32 pre-activation, and
+    against the older pair (saved x -> SSAK_EPI_MUL_GELU_GRAD + mask replay) within bf16 rounding of the factor.  Shapes: the
+    FFN-up product of the headline config (direct LDS-free epilogue), a 256-column tiling with an M edge, the small-tile kernel."""
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    B = (torch.randn(N, K, generator=g) * (2.0 / K ** 0.5)).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    kw = dict(lda=K, ldb=K, ldc=N, bias=bias, drop_p=0.1, drop_stream=9, drop_seed=1234)
+    y_old = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    pre = torch.empty_like(y_old)
+    hip.gemm(A, B, y_old, M, N, K, epilogue=hip.EPI_GELU, aux_out=pre, **kw)
+    y = torch.empty_like(y_old)
+    f = torch.empty_like(y_old)
+    hip.gemm(A, B, y, M, N, K, epilogue=hip.EPI_GELU_SAVE_GRAD, aux_out=f, **kw)
+    assert torch.equal(y, y_old)
+    x = (A.float() @ B.float().T + bias).requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    keep = (y != 0) | (x.detach().abs() < 1e-3)  # (an output that is exactly zero was dropped, tiny |gelu| aside)
+    assert 0.85 < float((y != 0).float().mean()) < 0.95
+    want_f = torch.where(y != 0, x.grad / 0.9, torch.zeros_like(x.grad))
+    ok = (f.float() - want_f).abs() <= 1.5e-2 + 8e-3 * want_f.abs()  # bf16 factor; x itself carries the bf16 GEMM's rounding
+    assert float(ok[keep].float().mean()) > 0.9999
+    assert bool((f[y == 0].float().abs() < 0.6).all())  # dropped (or |gelu| underflowed) positions: factor 0 or a tiny-|x| value
+    # backward: dI = (dY W) * f with column sums, against the older epilogue on the saved pre-activation
+    Kb = 256
+    dY = torch.randn(M, Kb, generator=g).to(torch.bfloat16).cuda()
+    W2 = (torch.randn(N, Kb, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    d_new = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    cs = torch.zeros(N, dtype=torch.float32).cuda()
+    hip.gemm(dY, W2, d_new, M, N, Kb, lda=Kb, ldb=Kb, ldc=N, epilogue=hip.EPI_MUL_AUX, aux_in=f, colsum_out=cs)
+    d_old = torch.empty_like(d_new)
+    hip.gemm(dY, W2, d_old, M, N, Kb, lda=Kb, ldb=Kb, ldc=N, epilogue=hip.EPI_MUL_GELU_GRAD, aux_in=pre, drop_p=0.1, drop_stream=9,
+             drop_seed=1234)
+    ref = (dY.float() @ W2.float().T) * want_f
+    e_new = float((d_new.float() - ref).norm() / ref.norm())
+    e_old = float((d_old.float() - ref).norm() / ref.norm())
+    print("feed-forward backward epilogue rel-L2 vs fp32: new", e_new, "old", e_old)
+    assert e_new < 6e-3 and e_new < 1.5 * e_old + 1e-3
+    want_cs = d_new.float().sum(0)
+    assert bool(((cs - want_cs).abs() <= 2e-3 * d_new.float().abs().sum(0) + 1e-3).all())

@@ -1,7 +1,11 @@
 #!/bin/bash
-# A/B of two builds on the same box: alternates bench.py runs of libssak_hip.so and libssak_hip_alt.so
-for i in 1 2 3; do
-  a=$(python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
-  b=$(SSAK_HIP_LIB=$PWD/ssak_amd/lib/libssak_hip_alt.so python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
-  echo "current $a   alt $b"
+# A/B of two builds on the SAME box (the pool's boxes differ by several per cent): alternates bench.py runs of the current
+# libssak_hip.so and of ssak_amd/lib/ab_base.so (SSAK_HIP_LIB override), printing utt/s, ms/step and the top kernel slots.
+N=${1:-3}
+show='import json,sys
+d=json.loads(sys.stdin.read()); r=d["roofline"]
+print(sys.argv[1], d["value"], d["ms_per_step"], " | ".join("%s %.0f" % (k["kernel"].split("(")[0][:34], k["us_per_step"]) for k in r["kernels"][:9]))'
+for i in $(seq $N); do
+  python bench.py --steps 60 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$show" "new "
+  SSAK_HIP_LIB=$PWD/ssak_amd/lib/ab_base.so python bench.py --steps 60 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$show" "base"
 done
