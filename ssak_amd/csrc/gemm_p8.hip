@@ -9,17 +9,20 @@
 //   * a 64-deep K tile is staged as FOUR 16 KB pieces, cut along what one phase consumes:
 //       AT/AB = the top / bottom 64 rows of both wave rows' A panels, BL/BR = the left / right 32 columns of all
 //       four wave columns' B panels;
-//   * a K tile is four phases, one output quadrant (64x32 per wave, 16 MFMAs) each:
-//       P1: read AT,BL  -> C(top,left)      DMA BR(t+1)   wait for BR(t)
-//       P2: read BR     -> C(top,right)     DMA AB(t+1)   wait for AB(t)
-//       P3: read AB     -> C(bottom,right)  DMA BL(t+2)
-//       P4: (BL kept)   -> C(bottom,left)   DMA AT(t+2)   wait for BL(t+1), AT(t+1)
-//     every wait is a counted `s_waitcnt vmcnt(8)`: four pieces (64 KB per CU) stay in flight across the raw
-//     s_barriers and each piece has about four phases (>= 1000 MFMA cycles) to land; vmcnt never drains in the loop;
-//   * the two wave rows run staggered by one barrier: while one does its 16 MFMAs the other issues its ds_reads and
-//     DMA, so the matrix pipe of each SIMD alternates between its two resident waves instead of idling on LDS.
+//   * a K tile is TWO load / matrix phase pairs, one output half (64 x 64 per wave, 8 * MH MFMAs) each:
+//       LA: read AT,BL,BR -> C(top, left | right)      DMA AB(t+1)                    wait for AB(t)
+//       LB: read AB       -> C(bottom, left | right)   DMA AT(t+2), BL(t+2), BR(t+2)  wait for AT(t+1), BL(t+1), BR(t+1)
+//     every wait is a counted `s_waitcnt vmcnt(8)`: four pieces (64 KB per CU) stay in flight across the raw s_barriers and
+//     each piece has two phases (>= 1000 MFMA cycles) to land; vmcnt never drains in the loop.  (Round 1 ran FOUR pairs per K
+//     tile, a quadrant each; tools/probes/p8_loop.hip showed that loop bound by its load phases -- 2 LDS-DMA instructions queueing
+//     behind the CU's one address unit + up to 12 fragment reads + two barriers took 300-380 cycles against the partner's 256
+//     cycles of MFMAs (the loop without its DMA: +32 %; without its barriers: -11 %).  With half as many, twice as long phases
+//     the fixed costs are paid half as often and a ~450-cycle load phase hides under 512 cycles of MFMAs: +4 % (conv1) to
+//     +13 % (K = 3072 feed-forward) on the train step's shapes, bit-identical results.)
 // Hazards (G0 = wave row 0, G1 = wave row 1, one barrier behind): a piece waited for in phase w (before the phase's
-// first barrier) is read in phase >= w+1; a slot last read in phase r is re-staged in phase >= r+2.  Past the last K
+// first barrier) is read in phase >= w+1; a slot last read in load phase r is re-staged in load phase r+1 -- the fragment
+// reads are drained (lgkmcnt(0)) BEFORE the barrier that closes a load phase, so the lagging wave row has finished with the
+// slot when the leading one issues the DMA.  Past the last K
 // tile the same DMA instructions are issued with out-of-range offsets (the DMA then writes zeros into slots nobody
 // reads any more), which keeps the vmcnt arithmetic uniform.
 //
@@ -92,6 +95,9 @@ struct P8Stager {
   // stage piece `h` of k-tile kt (absolute index; kt >= kt_end: zero-writing dummies) and advance that piece's offsets
   template <int H>
   __device__ __forceinline__ void issue(char* lds_piece, int kt, int kt_end, int K) {
+#if defined(P8_ABL) && (P8_ABL & 1)
+    if (kt >= 2) return;  // ablation: no LDS-DMA inside the main loop
+#endif
     // k-rows / k-chunks of this tile that exist (uniform): all 64, a K tail, or none (dummy past the last tile)
     const int klim = kt < kt_end ? min(K - kt * BK, BK) : 0;
 #pragma unroll
@@ -122,6 +128,9 @@ struct P8Frag {
     }
   }
   __device__ __forceinline__ bf16x8 read(const char* piece, int i, int kk) const {
+#if defined(P8_ABL) && (P8_ABL & 2)
+    return __builtin_bit_cast(bf16x8, (f32x4){(float)i, (float)kk, 1.f, 2.f});  // ablation: no fragment reads
+#endif
     if (!KM) {
       return *reinterpret_cast<const bf16x8*>(piece + ((off[0] ^ (kk << 6)) + i * 2048));
     } else {
@@ -159,16 +168,27 @@ struct P8Frag {
     P8_FENCE();                     \
   } while (0)
 // the 4 * MH MFMAs of one output quadrant: 16-row groups I0..I0+MH-1 x column groups J0, J0+1, both 32-deep halves
-#define P8_MFMA(I0, J0, FB)                                                                                   \
-  do {                                                                                                        \
-    P8_BARRIER();                                                                                             \
-    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                                            \
+#if defined(P8_ABL) && (P8_ABL & 4)
+#define P8_MFMA_BODY(I0, J0, FB) acc[(I0)][(J0)] += (f32x4){(float)FB[0][0][0], (float)fa[0][0][0], 0.f, 0.f}; /* ablation: no MFMAs */
+#else
+#define P8_MFMA_BODY(I0, J0, FB)                                                                              \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < MH; ++i)           \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] =                               \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(I0) + i][(J0) + j], 0, 0, 0);  \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kk], fa[i][kk], acc[(I0) + i][(J0) + j], 0, 0, 0);
+#endif
+#if defined(P8_ABL) && (P8_ABL & 8)
+#define P8_LOOP_BARRIER() P8_FENCE() /* ablation: no barriers inside the main loop */
+#else
+#define P8_LOOP_BARRIER() P8_BARRIER()
+#endif
+#define P8_MFMA(I0, J0, FB)                                                                                   \
+  do {                                                                                                        \
+    P8_LOOP_BARRIER();                                                                                        \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    P8_MFMA_BODY(I0, J0, FB)                                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                            \
-    P8_BARRIER();                                                                                             \
+    P8_LOOP_BARRIER();                                                                                        \
   } while (0)
 
 // MH = 16-row groups per quadrant: the tile is (64 * MH) x 256, i.e. 256 / 192 / 128 rows -- picked by the host so
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     const bool was_primed = primed;
     if (!primed) {
       prime(c);
-      wait_vmcnt<12>();  // BL(0), AT(0) landed (this wave's share)
+      wait_vmcnt<10>();  // BL(0), AT(0), BR(0) landed (this wave's share): the first load phase reads all three
     } else if (epi_vm == 8 * MH) {
       wait_vmcnt<8 * MH>();  // everything older than the previous epilogue's stores: the eight primed pieces
     } else {
@@ -341,43 +361,63 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     for (int kt = kt0; kt < kt1; ++kt) {
       char* const cur = ((kt - kt0) & 1) ? buf1 : buf0;
       char* const nxt = ((kt - kt0) & 1) ? buf0 : buf1;
-      const bool first = kt == kt0;                  // BR(1), AB(1) were staged by prime()
-      const bool settled = was_primed && kt - kt0 < 2;  // every piece this K tile waits for landed before the loop
-      // ---- P1
+      const bool first = kt == kt0;
+      const bool settled = was_primed && kt - kt0 < 2;
+      // ---- LA
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fbl[j][kk] = frb.read(cur + 2 * P8_PIECE, j, kk);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fbr[j][kk] = frb.read(cur + 3 * P8_PIECE, j, kk);
       P8_FENCE();
 #pragma unroll
       for (int i = 0; i < MH; ++i)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 0 * P8_PIECE, i, kk);
       P8_FENCE();
-      if (!first) sb.template issue<1>(nxt + 3 * P8_PIECE, kt + 1, kt1, p.K);  // BR(t+1)
-      if (!settled) wait_vmcnt<8>();                                           // BR(t)
-      P8_MFMA(0, 0, fbl);
-      // ---- P2
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fbr[j][kk] = frb.read(cur + 3 * P8_PIECE, j, kk);
-      P8_FENCE();
       if (!first) sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K);  // AB(t+1)
       if (!settled) wait_vmcnt<8>();                                           // AB(t)
-      P8_MFMA(0, 2, fbr);
-      // ---- P3
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                      // this wave's fragment reads are done
+      P8_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbl[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbr[j][kk], fa[i][kk], acc[i][2 + j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      P8_BARRIER();
+      // ---- LB
 #pragma unroll
       for (int i = 0; i < MH; ++i)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 1 * P8_PIECE, i, kk);
       P8_FENCE();
-      sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K);  // BL(t+2)
-      P8_MFMA(MH, 2, fbr);
-      // ---- P4
       sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K);  // AT(t+2)
-      if (!(was_primed && first)) wait_vmcnt<8>();                 // BL(t+1), AT(t+1)
-      P8_MFMA(MH, 0, fbl);
+      sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K);  // BL(t+2)
+      sb.template issue<1>(cur + 3 * P8_PIECE, kt + 2, kt1, p.K);  // BR(t+2)
+      if (!(was_primed && first)) wait_vmcnt<8>();                 // AT(t+1), BL(t+1), BR(t+1)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      P8_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbl[j][kk], fa[i][kk], acc[MH + i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[MH + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbr[j][kk], fa[i][kk], acc[MH + i][2 + j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      P8_BARRIER();
     }
     if (wr == 0) P8_BARRIER();
     wait_vmcnt<0>();  // drain the trailing dummies before LDS is released

@@ -1,0 +1,67 @@
+// Development probe: the persistent 256 x 256 GEMM kernel (lean bf16 epilogue) timed on the train step's shapes, for A/B runs
+// of main-loop variants selected with -D flags in gemm_p8.hip.  Prints us, TFLOP/s and an order-independent checksum of C
+// (two builds that compute the same thing print the same checksum).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Issak_amd/csrc -mllvm -amdgpu-mfma-vgpr-form [-DP8_VARIANT=n]
+//         -x hip tools/probes/p8_loop.hip ssak_amd/csrc/api.cpp -o tools/probes/p8_loop_<tag>.bin
+#include "../../ssak_amd/csrc/gemm_p8.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__global__ void checksum_kernel(const unsigned short* c, long n, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += (unsigned long long)c[i] * (unsigned long long)((i % 8191) + 1);
+  atomicAdd(out, s);
+}
+
+static void run(const char* name, int M, int N, int K, int nb) {
+  bf16 *A, *B, *C;
+  hipMalloc(&A, (size_t)nb * M * K * 2);
+  hipMalloc(&B, (size_t)N * K * 2);
+  hipMalloc(&C, (size_t)nb * M * N * 2);
+  std::vector<unsigned short> h((size_t)std::max((size_t)nb * M, (size_t)N) * K);
+  srand(1);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (unsigned short)(0x3c00 + (rand() & 0x1ff) + ((rand() & 1) << 15));  // random mantissas and signs
+  hipMemcpy(A, h.data(), (size_t)nb * M * K * 2, hipMemcpyHostToDevice);
+  hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
+  p.nb2 = 1; p.alpha = 1.f; p.split_k = 1; p.nz = nb;
+  p.sa1 = (long)M * K; p.sc1 = (long)M * N;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  p.kt_per_split = (K + 63) / 64;
+  p.ext_a = (uint32_t)std::min<size_t>((size_t)nb * M * K * 2, 0xffffffffu); p.ext_b = (uint32_t)((size_t)N * K * 2);
+  if (nb > 1) p.ext_a = (uint32_t)((size_t)M * K * 2);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = 0; it < 3; ++it) launch_p8<4, false, false, P8_EPI_PLAIN_BF16>(p, 0);
+  hipDeviceSynchronize();
+  const int iters = 30;
+  hipEventRecord(e0);
+  for (int it = 0; it < iters; ++it) launch_p8<4, false, false, P8_EPI_PLAIN_BF16>(p, 0);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  ms /= iters;
+  unsigned long long* cs;
+  hipMalloc(&cs, 8);
+  hipMemset(cs, 0, 8);
+  checksum_kernel<<<1024, 256>>>((const unsigned short*)C, (long)nb * M * N, cs);
+  unsigned long long hcs = 0;
+  hipMemcpy(&hcs, cs, 8, hipMemcpyDeviceToHost);
+  printf("%-10s M=%6d N=%5d K=%5d nb=%3d  %8.1f us  %7.1f TF/s  checksum %016llx\n", name, M, N, K, nb, ms * 1e3, 2.0 * nb * M * N * (double)K / ms / 1e9, hcs);
+  hipFree(A); hipFree(B); hipFree(C); hipFree(cs);
+}
+
+int main() {
+  run("ffn_up", 15968, 3072, 768, 1);
+  run("qkv", 15968, 2304, 768, 1);
+  run("ffn_down", 15968, 768, 3072, 1);
+  run("conv1", 15999, 512, 1536, 32);
+  run("4096^3", 4096, 4096, 4096, 1);
+  run("8192^3", 8192, 8192, 8192, 1);
+  return 0;
+}
