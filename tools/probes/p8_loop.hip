@@ -16,6 +16,52 @@ __global__ void checksum_kernel(const unsigned short* c, long n, unsigned long l
   atomicAdd(out, s);
 }
 
+template <int EPI, bool B_KM>
+static void run_epi(const char* name, int M, int N, int K) {
+  bf16 *A, *B, *C, *AUX;
+  float* CS;
+  hipMalloc(&A, (size_t)M * K * 2);
+  hipMalloc(&B, (size_t)N * K * 2);
+  hipMalloc(&C, (size_t)M * N * 2);
+  hipMalloc(&AUX, (size_t)M * N * 2);
+  hipMalloc(&CS, (size_t)((M + 63) / 64) * N * 4);
+  std::vector<unsigned short> h((size_t)std::max(M, N) * K);
+  srand(1);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (unsigned short)(0x3c00 + (rand() & 0x1ff) + ((rand() & 1) << 15));
+  hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
+  hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+  hipMemset(AUX, 0x3c, (size_t)M * N * 2);
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = B_KM ? N : K; p.ldc = N;
+  p.nb2 = 1; p.alpha = 0.01f; p.split_k = 1; p.nz = 1;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  p.kt_per_split = (K + 63) / 64;
+  p.ext_a = (uint32_t)((size_t)M * K * 2); p.ext_b = (uint32_t)((size_t)N * K * 2);
+  p.epilogue = EPI == 3 ? SSAK_EPI_GELU_SAVE_GRAD : EPI == 4 ? SSAK_EPI_MUL_AUX : SSAK_EPI_NONE;
+  if (EPI == 3) { p.aux_out = AUX; p.drop_thresh = 6554; p.drop_scale = 1.f / 0.9f; p.drop_seed = 1234; p.drop_stream = 3; }
+  if (EPI == 4) { p.aux_in = AUX; p.colsum = CS; }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = 0; it < 3; ++it) launch_p8<4, false, B_KM, EPI>(p, 0);
+  hipDeviceSynchronize();
+  const int iters = 30;
+  hipEventRecord(e0);
+  for (int it = 0; it < iters; ++it) launch_p8<4, false, B_KM, EPI>(p, 0);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  ms /= iters;
+  unsigned long long* cs;
+  hipMalloc(&cs, 8);
+  hipMemset(cs, 0, 8);
+  checksum_kernel<<<1024, 256>>>((const unsigned short*)C, (long)M * N, cs);
+  unsigned long long hcs = 0;
+  hipMemcpy(&hcs, cs, 8, hipMemcpyDeviceToHost);
+  printf("%-18s M=%6d N=%5d K=%5d          %8.1f us  %7.1f TF/s  checksum %016llx\n", name, M, N, K, ms * 1e3, 2.0 * M * N * (double)K / ms / 1e9, hcs);
+  hipFree(A); hipFree(B); hipFree(C); hipFree(AUX); hipFree(CS); hipFree(cs);
+}
+
 static void run(const char* name, int M, int N, int K, int nb) {
   bf16 *A, *B, *C;
   hipMalloc(&A, (size_t)nb * M * K * 2);
@@ -57,6 +103,10 @@ static void run(const char* name, int M, int N, int K, int nb) {
 }
 
 int main() {
+  run_epi<P8_EPI_PLAIN_BF16, false>("ffn_up plain", 15968, 3072, 768);
+  run_epi<SSAK_EPI_GELU_SAVE_GRAD, false>("ffn_up save_grad", 15968, 3072, 768);
+  run_epi<P8_EPI_PLAIN_BF16, true>("ffn_dx plain", 15968, 3072, 768);
+  run_epi<SSAK_EPI_MUL_AUX, true>("ffn_dx mul_aux", 15968, 3072, 768);
   run("ffn_up", 15968, 3072, 768, 1);
   run("qkv", 15968, 2304, 768, 1);
   run("ffn_down", 15968, 768, 3072, 1);
