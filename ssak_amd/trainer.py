@@ -124,7 +124,7 @@ class AdamW:
 class Trainer:
     """One optimizer step per call; data-parallel when a process group is initialised.
 
-    The optimizer tail runs on a SIDE STREAM (``optimizer_stream=True``, or environment SSAK_OPT_STREAM=0 to disable): as each
+    Under data parallelism the optimizer tail runs on a SIDE STREAM (``optimizer_stream``; environment SSAK_OPT_STREAM=0/1): as each
     gradient bucket's all-reduce completes, its share of the clip norm is summed there (the norm partials ride with the
     buckets); after the last one the clip coefficient is known and AdamW sweeps the buffers, still on the side stream.  The
     compute stream meanwhile starts the next step -- waveform normalisation and the (frozen) conv feature encoder, a third of
@@ -154,7 +154,12 @@ class Trainer:
         self._works = []  # (work, offset, count) of this step's bucket all-reduces, in announcement order
         self.bucket_log = []  # [(offset, count)] of the last step (bench: bucket sizes)
         if optimizer_stream is None:
-            optimizer_stream = os.environ.get("SSAK_OPT_STREAM", "1") != "0"
+            # default: on under data parallelism (it hides the exchange tail + the update under the next step's conv stack),
+            # off on one GPU, where there is no exchange to hide and the HBM-bound AdamW sweep only competes with the equally
+            # HBM-bound conv0 of the next step (measured: 17.40 vs 17.35 ms in line, profiles/r02_ab_optimizer_stream.log; the
+            # small conv0 statistics kernels also queue behind AdamW's 4096 workgroups).  SSAK_OPT_STREAM=0/1 overrides.
+            env = os.environ.get("SSAK_OPT_STREAM")
+            optimizer_stream = (env != "0") if env is not None else (self.dist and self.world > 1)
         self.opt_stream = None
         self._stall = None
         if optimizer_stream:

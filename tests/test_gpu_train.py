@@ -395,3 +395,31 @@ def test_torch_autograd_loop_matches_native_trainer():
     (ref * 2.0).backward()
     assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
     assert rel_l2(lg.grad.cpu(), lg2.grad) < 1e-3 and rel_l2(w.grad.cpu(), w2.grad) < 1e-3
+
+
+def test_optimizer_side_stream_equals_inline():
+    """The optimizer tail on its own HIP stream (the data-parallel default: norm partials per bucket, clip + AdamW after the last
+    one, the next forward waiting for the update only at the feature projection, ssak_w2v2_set_param_event) gives the same
+    parameters, bit for bit, as the in-line tail after several steps -- forward / backward of step n+1 never see a half-applied
+    update, and host reads of model.params right after train_step are ordered behind it."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    oc = R.W2V2Config.tiny()  # regularisers ON: masks, LayerDrop and SpecAugment draws must line up too
+    p0 = R.init_params(oc, 8)
+    rng = np.random.default_rng(2)
+    x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(9000).astype(np.float32) for _ in range(4)])).cuda()
+    labels = torch.tensor(R.pad_labels([list(rng.integers(1, 32, 5)) for _ in range(4)])).cuda()
+    outs = []
+    for side in (False, True):
+        model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc), seed=4).train()
+        model.load_state_dict(p0)
+        tr = Trainer(model, AdamW(model, lr=1e-3, warmup_steps=1, total_steps=100, weight_decay=0.01), optimizer_stream=side,
+                     measure_stall=side)
+        losses = [tr.train_step(x, None, labels, raw=False) for _ in range(5)]
+        params = model.params.clone()  # no explicit synchronisation: the property orders this read behind the update
+        outs.append((torch.stack(losses).cpu(), params.cpu(), tr.opt.grad_norm()))
+        if side:
+            assert tr.opt_stream is not None and tr.stall_ms() >= 0.0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
