@@ -73,6 +73,7 @@ def _load():
         "ssak_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp]),
         "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "ssak_gemm_tile_order": (i32, [i32]),
+        "ssak_attention_bwd_mode": (i32, [i32]),
         "ssak_prof_enable": (i32, [i32]),
         "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
@@ -308,9 +309,14 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
     return ctx, lse
 
 
+def attention_bwd_mode(split: bool):
+    """True (the default): two-kernel backward (dQ; dK + dV); False: the fused single-pass kernel."""
+    check(lib.ssak_attention_bwd_mode(1 if split else 0))
+
+
 def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0):
     H = qkv.shape[1] // 3
-    dqkv = torch.zeros_like(qkv)
+    dqkv = torch.full_like(qkv, float("nan"))  # poisoned: the kernels write every element
     delta = torch.empty((B, nh, F), dtype=torch.float32, device=qkv.device)
     if klens is not None:
         klens = klens.to(device=qkv.device, dtype=torch.int32).contiguous()

@@ -355,6 +355,37 @@ def test_fused_attention_dropout_consistency(hip):
     assert pred > 0 and abs(got - pred) < 0.25 * pred, (got, pred)
 
 
+@pytest.mark.parametrize("B,F,nh,ragged,p", [(2, 499, 12, False, 0.1), (3, 200, 4, True, 0.0), (3, 500, 2, True, 0.25),
+                                              (1, 64, 2, False, 0.3), (2, 512, 3, False, 0.1), (1, 257, 1, False, 0.0),
+                                              (2, 33, 8, True, 0.1), (2, 1500, 2, False, 0.1), (3, 749, 16, True, 0.05)])
+def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, p):
+    """The single-pass backward (dQ, dK, dV from one evaluation of P / the dropout words / dS; a workgroup per head walks the
+    keys in blocks of 256 and adds each block's dQ tiles onto what it stored for the previous blocks) against the two-kernel
+    form on the same inputs and the same dropout stream: same mask, so the results differ by bf16 rounding only (<= 1e-2
+    relative L2 per block of columns, the distance either sits from the fp32 reference).  The output buffer is poisoned
+    (NaN): every element of dqkv must be written and the first key block must not read it.  Two fused runs are bit-identical."""
+    g = torch.Generator().manual_seed(F * 7 + nh)
+    H = nh * 64
+    qkv = (torch.randn(B * F, 3 * H, generator=g) * 0.8).to(torch.bfloat16).cuda()
+    dctx = (torch.randn(B * F, H, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    klens = torch.tensor([F, max(1, F // 3), F - 7][:B]) if ragged else None
+    kw = dict(drop_p=p, seed=99, stream_id=5) if p else {}
+    ctx, lse = hip.attention_fwd(qkv, B, F, nh, klens, **kw)
+    try:
+        hip.attention_bwd_mode(True)
+        ref = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
+        hip.attention_bwd_mode(False)
+        got = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
+        again = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
+    finally:
+        hip.attention_bwd_mode(True)  # the default form
+    assert torch.isfinite(got.float()).all() and torch.isfinite(ref.float()).all()
+    assert torch.equal(got, again)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel(got[:, sl], ref[:, sl]) < 1e-2, (name, rel(got[:, sl], ref[:, sl]))
+
+
 # ------------------------------------------------------------------ evaluation metric on the device (f3)
 def test_device_wer_vs_oracle(hip):
     """Random "recognitions" of random transcripts (apostrophes, <unk>, repeats, blanks, empty hypotheses) through greedy

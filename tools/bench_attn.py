@@ -1,5 +1,6 @@
 """Fused attention kernels on the train-step shape (B x 12 heads x 499 frames, head_dim 64): time per launch with and
-without dropout.  usage: PYTHONPATH=. python tools/bench_attn.py [B=32] [F=499] [nh=12]"""
+without dropout, backward in both forms (fused single pass / two kernels).  Buffers are allocated once and the library is
+called directly, so the figures are kernel time + launch.  usage: PYTHONPATH=. python tools/bench_attn.py [B=32] [F=499] [nh=12]"""
 import sys
 import torch
 import ssak_amd.hip as h
@@ -11,10 +12,15 @@ H = nh * 64
 g = torch.Generator().manual_seed(0)
 qkv = (torch.randn(B * F, 3 * H, generator=g) * 0.8).to(torch.bfloat16).cuda()
 dctx = (torch.randn(B * F, H, generator=g) * 0.5).to(torch.bfloat16).cuda()
+ctx = torch.empty((B * F, H), dtype=torch.bfloat16, device="cuda")
+lse = torch.empty((B, nh, F), dtype=torch.float32, device="cuda")
+delta = torch.empty((B, nh, F), dtype=torch.float32, device="cuda")
+dqkv = torch.empty_like(qkv)
+lib, ptr, st = h.lib, h.ptr, h.stream
 
 
-def timeit(fn, n=20):
-    for _ in range(3):
+def timeit(fn, n=50):
+    for _ in range(5):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,8 +34,13 @@ def timeit(fn, n=20):
 
 fl = 4.0 * B * nh * F * F * 64
 for p in (0.0, 0.1):
-    kw = dict(drop_p=p, seed=1, stream_id=3) if p else {}
-    ctx, lse = h.attention_fwd(qkv, B, F, nh, **kw)
-    tf = timeit(lambda: h.attention_fwd(qkv, B, F, nh, **kw))
-    tb = timeit(lambda: h.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, **kw))
-    print(f"p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s)   bwd (delta+dq+dkv) {tb:7.1f} us ({3.5 * fl / tb / 1e6:6.1f} TF/s of executed flops)")
+    fwd = lambda: h.check(lib.ssak_attention_fwd(ptr(qkv), ptr(ctx), ptr(lse), None, B, F, nh, H, p, 1, 3, st()))
+    bwd = lambda: h.check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), None, ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H, p, 1, 3, st()))
+    tf = timeit(fwd)
+    out = [f"p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s)"]
+    for split in (False, True):
+        h.attention_bwd_mode(split)
+        tb = timeit(bwd)
+        out.append(f"bwd {'two-kernel' if split else 'fused':10s} {tb:7.1f} us ({2 * fl / tb / 1e6:6.1f} TF/s algorithmic)")
+    h.attention_bwd_mode(True)
+    print("   ".join(out))
