@@ -50,6 +50,19 @@ struct AttnParams {
 };
 
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+// max of three without the canonicalising v_max x, x that fmaxf puts in front of every MFMA result in IEEE mode (the scores
+// are never NaN): 8 instructions for 16 values instead of 31
+__device__ __forceinline__ float max3_nc(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// a value the compiler cannot hoist across the branch it is used under (keeps the per-key comparisons of the one tile that
+// crosses the key length out of every other tile's instruction stream)
+__device__ __forceinline__ int opaque_s(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
 
 // Dropout bits.  Every (utterance, head, query) row has a seed = hash(seed, stream, row index), computed once per row and
 // kernel; the 32-bit word of key pair kp of that row is one multiply-xorshift round of (row seed + kp * golden ratio):
@@ -151,6 +164,11 @@ __device__ __forceinline__ AttnBlock attn_block() {
 }
 
 // ================================================================================================ forward
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// DROP is a template parameter: as a run-time test it put a branch (and two register copies to merge its sides) around every
+// key pair's dropout words -- sixteen per query sub-tile and key tile -- which also kept the exp / hash / MFMA streams apart.
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K | V)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -220,39 +238,49 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
       if (edge) {
+        const int klo = opaque_s(kl);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (k0 + 16 * ks + 4 * g + r >= kl) s[qs][ks][r] = -INFINITY;
+            if (k0 + 16 * ks + 4 * g + r >= klo) s[qs][ks][r] = -INFINITY;
       }
-      float mx = fmaxf(fmaxf(s[qs][0][0], s[qs][0][1]), fmaxf(s[qs][0][2], s[qs][0][3]));
+      float mx = max3_nc(s[qs][0][0], s[qs][0][1], s[qs][0][2]);
+      mx = max3_nc(mx, s[qs][0][3], s[qs][1][0]);
 #pragma unroll
-      for (int ks = 1; ks < 4; ++ks) mx = fmaxf(mx, fmaxf(fmaxf(s[qs][ks][0], s[qs][ks][1]), fmaxf(s[qs][ks][2], s[qs][ks][3])));
+      for (int ks = 1; ks < 4; ++ks) {
+        mx = max3_nc(mx, s[qs][ks][1], s[qs][ks][2]);
+        if (ks < 3)
+          mx = max3_nc(mx, s[qs][ks][3], s[qs][ks + 1][0]);
+        else
+          mx = fmaxf(mx, s[qs][ks][3]);
+      }
       mx = fmaxf(mx, shfl_xor_f(mx, 16));
       mx = fmaxf(mx, shfl_xor_f(mx, 32));
       // key 0 is never masked (kl >= 1 whenever a tile is processed), so the running maximum is finite from the first tile on
       const float m_new = fmaxf(m_run[qs], mx);
       const float mc = m_new * c2;
       const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qs], c2, -mc));  // first tile: exp2(-inf) = 0 on a zero accumulator
-      float rs = 0.f;
+      f32x2 rs2 = {0.f, 0.f};  // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): the pair's two exponent arguments and the row sum
+      const f32x2 c2v = {c2, c2}, mcv = {-mc, -mc};
       const uint32_t xrow = rowseed[qs] + (uint32_t)((k0 >> 1) + 2 * g) * DROP_PHI;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int r2 = 0; r2 < 4; r2 += 2) {
-          float e0 = __builtin_amdgcn_exp2f(fmaf(s[qs][ks][r2], c2, -mc));
-          float e1 = __builtin_amdgcn_exp2f(fmaf(s[qs][ks][r2 + 1], c2, -mc));
-          rs += e0 + e1;
-          if (p.thresh16) {
+          const f32x2 a = (f32x2){s[qs][ks][r2], s[qs][ks][r2 + 1]} * c2v + mcv;
+          f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          rs2 += e;
+          if (DROP) {
             const uint32_t w = drop_word(xrow + (uint32_t)(8 * ks + (r2 >> 1)) * DROP_PHI);
-            e0 = drop_keep_even(w, thi) ? e0 : 0.f;
-            e1 = drop_keep_odd(w, thi) ? e1 : 0.f;
+            e[0] = drop_keep_even(w, thi) ? e[0] : 0.f;
+            e[1] = drop_keep_odd(w, thi) ? e[1] : 0.f;
           }
-          s[qs][ks][r2] = e0;
-          s[qs][ks][r2 + 1] = e1;
+          s[qs][ks][r2] = e[0];
+          s[qs][ks][r2 + 1] = e[1];
         }
       }
+      float rs = rs2[0] + rs2[1];
       rs += shfl_xor_f(rs, 16);
       rs += shfl_xor_f(rs, 32);
       l_run[qs] = l_run[qs] * alpha + rs;
@@ -310,6 +338,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 
 // dQ: workgroup = 128 queries of one (b, h); sweeps the keys.  Same orientation as the forward:
 //   S^T[key][q], dP^T[key][q] = V dO^T, dS^T = P^T * (dP^T * mask/(1-p) - delta[q]); dQ^T[d][q] += K^T[d][key] dS^T[key][q].
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K rows | K transpose | V rows)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -335,7 +364,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     rowbase[qs] = drop_rowseed(p, b, h, qrow[qs]);
     const int qc = min(qrow[qs], F - 1);
     lse[qs] = p.lse[((long)b * p.nh + h) * F + qc];
-    lse2[qs] = lse[qs] > -INFINITY ? fmaf(lse[qs], 1.4426950408889634f, -__log2f(p.scale)) : INFINITY;
+    // exponent offset: lse in log2 units, minus log2 (scale / (1 - p)): P comes out multiplied by the softmax scale and the
+    // dropout scale, and dS = P'' (keep ? dP : 0 - delta (1 - p)) needs neither multiply (delta is rescaled once per row)
+    lse2[qs] = lse[qs] > -INFINITY ? fmaf(lse[qs], 1.4426950408889634f, -__log2f(p.scale * p.drop_scale)) : INFINITY;
     // delta[q] = sum_d dO[q,d] * O[q,d], computed here from the dO fragments the kernel holds anyway (it used to be a
     // separate pass over dO and O) and written out for the dK/dV kernel, which runs after this one
     float part = 0.f;
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     }
     part += shfl_xor_f(part, 16);
     part += shfl_xor_f(part, 32);
-    dl[qs] = part;
+    dl[qs] = part / p.drop_scale;
     if (g == 0 && qrow[qs] < F) p.delta[((long)b * p.nh + h) * F + qrow[qs]] = part;
   }
   f32x4 dq[2][4];
@@ -395,31 +426,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
             dp[qs][kh] = c;
           }
         }
+        if (edge) {  // keys beyond the key length: -inf before the exponent (only the tile that crosses it pays)
+          const int klo = opaque_s(kl);
+#pragma unroll
+          for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (k0 + 16 * (2 * t2 + kh) + 4 * g + r >= klo) s[qs][kh][r] = -INFINITY;
+        }
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-          // P = exp2(s * c2 - lse * log2 e); the softmax scale of dS = P (dP keep / (1-p) - delta) scale rides in the
-          // exponent too (lsc = lse * log2 e - log2 scale).  Rows without any valid key have lse = -inf -> +inf here -> P = 0.
-          const float lsc = lse2[qs];
+          // P'' = exp2(s * c2 - lsc) = P * scale / (1 - p); dS = P'' (keep ? dP : 0 - delta (1 - p)).  Rows without any valid
+          // key have lse = -inf -> lsc = +inf -> P'' = 0.  Packed fp32 over the key pair.
+          const f32x2 c2v = {c2, c2}, lscv = {-lse2[qs], -lse2[qs]}, dlv = {dl[qs], dl[qs]};
           const uint32_t xrow = rowbase[qs] + (uint32_t)((k0 >> 1) + 2 * g) * DROP_PHI;
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int r2 = 0; r2 < 4; r2 += 2) {
-              const int key = k0 + 16 * (2 * t2 + kh) + 4 * g + r2;
-              float d0 = dp[qs][kh][r2], d1 = dp[qs][kh][r2 + 1];
-              if (p.thresh16) {
+              f32x2 d = {dp[qs][kh][r2], dp[qs][kh][r2 + 1]};
+              if (DROP) {
                 const uint32_t w = drop_word(xrow + (uint32_t)(8 * (2 * t2 + kh) + (r2 >> 1)) * DROP_PHI);
-                d0 = drop_keep_even(w, thi) ? d0 * p.drop_scale : 0.f;
-                d1 = drop_keep_odd(w, thi) ? d1 * p.drop_scale : 0.f;
+                d[0] = drop_keep_even(w, thi) ? d[0] : 0.f;
+                d[1] = drop_keep_odd(w, thi) ? d[1] : 0.f;
               }
-              float p0 = __builtin_amdgcn_exp2f(fmaf(s[qs][kh][r2], c2, -lsc));
-              float p1 = __builtin_amdgcn_exp2f(fmaf(s[qs][kh][r2 + 1], c2, -lsc));
-              if (edge) {
-                p0 = key < kl ? p0 : 0.f;
-                p1 = key + 1 < kl ? p1 : 0.f;
-              }
-              s[qs][kh][r2] = p0 * (d0 - dl[qs]);
-              s[qs][kh][r2 + 1] = p1 * (d1 - dl[qs]);
+              const f32x2 a = (f32x2){s[qs][kh][r2], s[qs][kh][r2 + 1]} * c2v + lscv;
+              const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+              const f32x2 ds2 = pv * (d - dlv);
+              s[qs][kh][r2] = ds2[0];
+              s[qs][kh][r2 + 1] = ds2[1];
             }
           dsb[qs] = pack_p(s[qs][0], s[qs][1]);
         }
@@ -449,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 //   S[q][key] = Q K^T (query on the accumulator row, key on the lane), dP[q][key] = dO V^T,
 //   Pd = P * mask/(1-p), dS = P * (dP * mask/(1-p) - delta[q]) * scale,
 //   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key].
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q rows|Q tr|dO rows|dO tr), then lse|delta per stage
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -476,9 +514,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     }
   }
   const float c2 = p.scale * 1.4426950408889634f;
+  const float log2scale = __log2f(p.scale);
   const uint32_t thi = p.thresh16 << 16;
   const uint32_t kphi[2] = {(uint32_t)(krow[0] >> 1) * DROP_PHI, (uint32_t)(krow[1] >> 1) * DROP_PHI};
-  const bool kvalid[2] = {krow[0] < kl, krow[1] < kl};
+  // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
+  f32x4 sinit[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const float v = krow[ks] < kl ? 0.f : -3.0e38f;
+    sinit[ks] = (f32x4){v, v, v, v};
+  }
   f32x4 dk[2][4], dv[2][4];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -497,8 +542,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       const int q = qt * KT + threadIdx.x;
       const long o = ((long)b * p.nh + h) * F + min(q, F - 1);
       const float ls = q < F ? p.lse[o] : -INFINITY;
-      // rows beyond F or without a valid key: +inf here makes P = exp2(.. - inf) = 0 without a select per element
-      stat[stage * 3 * KT + threadIdx.x] = ls > -INFINITY ? ls * 1.4426950408889634f : INFINITY;
+      // rows beyond F or without a valid key: +inf here makes P = exp2(.. - inf) = 0 without a select per element; the softmax
+      // scale rides in the exponent (P' = P * scale: dS needs no multiply, dV is rescaled once at the end)
+      stat[stage * 3 * KT + threadIdx.x] = ls > -INFINITY ? fmaf(ls, 1.4426950408889634f, -log2scale) : INFINITY;
       stat[stage * 3 * KT + KT + threadIdx.x] = q < F ? p.delta[o] : 0.f;
       reinterpret_cast<uint32_t*>(stat)[stage * 3 * KT + 2 * KT + threadIdx.x] = drop_rowseed(p, b, h, q);
     }
@@ -528,7 +574,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
           const bf16x8 da = frag_rows(do_rows, qsb, 0, lane), db = frag_rows(do_rows, qsb, 1, lane);
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+            // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
+            f32x4 a = sinit[ks], c = {0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf[ks][1], a, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks][0], c, 0, 0, 0);
@@ -542,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
           // Dropout words of this lane's 4 queries x 2 keys.  A word covers a key PAIR and the pair sits in two adjacent
           // lanes, so each lane mixes two of the four query rows and takes the other two from its partner by DPP.
           uint32_t W[2][4];
-          if (p.thresh16) {
+          if (DROP) {
             const int par = lane & 1;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -557,22 +604,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
             }
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < 4; r += 2) {  // packed fp32 over the row pair
             const int ql = 16 * (2 * t2 + qh) + 4 * g + r;  // query inside the tile
-            const float lsc = lse_s[ql], dl = dl_s[ql];
+            const f32x2 c2v = {c2, c2}, lscv = {-lse_s[ql], -lse_s[ql + 1]}, dlv = {dl_s[ql], dl_s[ql + 1]};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-              float keep = 1.f;
-              if (p.thresh16) {
-                const uint32_t w = W[ks][r];
-                const bool k = (krow[ks] & 1) ? drop_keep_odd(w, thi) : drop_keep_even(w, thi);
-                keep = k ? p.drop_scale : 0.f;
+              const f32x2 a = (f32x2){s[ks][qh][r], s[ks][qh][r + 1]} * c2v + lscv;
+              f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};  // P * scale
+              f32x2 dpv = {dp[ks][qh][r], dp[ks][qh][r + 1]}, pd = pr;
+              if (DROP) {
+                f32x2 keep;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  const uint32_t w = W[ks][r + e];
+                  const bool k = (krow[ks] & 1) ? drop_keep_odd(w, thi) : drop_keep_even(w, thi);
+                  keep[e] = k ? p.drop_scale : 0.f;
+                }
+                dpv *= keep;
+                pd *= keep;
               }
-              float pr = __builtin_amdgcn_exp2f(fmaf(s[ks][qh][r], c2, -lsc));
-              pr = kvalid[ks] ? pr : 0.f;  // keys beyond the key length (a per-lane constant)
-              const float dpv = dp[ks][qh][r] * keep;
-              s[ks][qh][r] = pr * keep;                    // Pd
-              dp[ks][qh][r] = pr * (dpv - dl) * p.scale;   // dS
+              const f32x2 ds2 = pr * (dpv - dlv);  // dS (scale included)
+              s[ks][qh][r] = pd[0];                 // Pd * scale
+              s[ks][qh][r + 1] = pd[1];
+              dp[ks][qh][r] = ds2[0];
+              dp[ks][qh][r + 1] = ds2[1];
             }
           }
         }
@@ -594,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       }
     }
   }
+  const float inv_scale = 1.f / p.scale;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int key = krow[ks];
@@ -603,7 +659,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bf16x4 a = {(bf16)dk[ks][i][0], (bf16)dk[ks][i][1], (bf16)dk[ks][i][2], (bf16)dk[ks][i][3]};
-      const bf16x4 c = {(bf16)dv[ks][i][0], (bf16)dv[ks][i][1], (bf16)dv[ks][i][2], (bf16)dv[ks][i][3]};
+      const bf16x4 c = {(bf16)(dv[ks][i][0] * inv_scale), (bf16)(dv[ks][i][1] * inv_scale), (bf16)(dv[ks][i][2] * inv_scale),
+                        (bf16)(dv[ks][i][3] * inv_scale)};  // accumulated from P * scale
       *reinterpret_cast<bf16x4*>(dkd + 16 * i) = a;
       *reinterpret_cast<bf16x4*>(dvd + 16 * i) = c;
     }
@@ -1076,7 +1133,10 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens
   SSAK_REQUIRE((long)F * 3 * H * 2 < 2000000000L, "attention: one utterance of q|k|v must span < 2 GB");
   const AttnParams p = make_params(qkv, ctx, lse, klens, nullptr, nullptr, nullptr, B, F, nh, H, drop);
   ProfScope prof_scope(PROF_ATTN_FWD, 4.0 * B * nh * (double)F * F * HD, st);  // S = Q K^T and O = P V
-  attn_fwd_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p);
+  if (p.thresh16)
+    attn_fwd_kernel<true><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p);
+  else
+    attn_fwd_kernel<false><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -1100,15 +1160,22 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
     SSAK_LAUNCH_CHECK();
     return SSAK_OK;
   }
-  attn_bwd_dq_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
+  if (p.thresh16)
+    attn_bwd_dq_kernel<true><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
+  else
+    attn_bwd_dq_kernel<false><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
   SSAK_LAUNCH_CHECK();
   constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 3 * KT * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
     attr_done = true;
   }
-  attn_bwd_dkv_kernel<<<dim3(ssak_cdiv(F, QB), nh, B), 256, dkv_lds, st>>>(p);
+  if (p.thresh16)
+    attn_bwd_dkv_kernel<true><<<dim3(ssak_cdiv(F, QB), nh, B), 256, dkv_lds, st>>>(p);
+  else
+    attn_bwd_dkv_kernel<false><<<dim3(ssak_cdiv(F, QB), nh, B), 256, dkv_lds, st>>>(p);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
