@@ -17,6 +17,7 @@
 // Dropout bits come from a counter hash of (seed, stream, row, key pair): 16-bit uniforms, two per hash; the
 // forward and both backward kernels regenerate identical masks.  Key-padding masks (ragged batches) are applied as
 // -inf before the softmax, as create_bidirectional_mask does.
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 
@@ -25,9 +26,10 @@
 namespace {
 
 int attn_bwd_mode();
+int attn_tile(int which);  // 16-row sub-tiles per wave: 0 forward (queries), 1 dQ kernel (queries), 2 dK/dV kernel (keys)
 
 constexpr int HD = 64;    // head dim
-constexpr int QB = 128;   // queries (or keys in dkv) per workgroup
+constexpr int QB = 128;   // queries per workgroup of the unfused paths that still use the constant
 constexpr int KT = 64;    // keys (or queries in dkv) per streamed tile
 constexpr int TILE_BYTES = KT * HD * 2;  // 8 KiB
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -168,12 +170,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // DROP is a template parameter: as a run-time test it put a branch (and two register copies to merge its sides) around every
 // key pair's dropout words -- sixteen per query sub-tile and key tile -- which also kept the exp / hash / MFMA streams apart.
-template <bool DROP>
+// NQS = 16-query sub-tiles per wave (workgroup = 4 waves x 16 NQS queries).
+template <bool DROP, int NQS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K | V)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const AttnBlock ab = attn_block();
-  const int b = ab.b, h = ab.h, q0 = ab.blk * QB;
+  const int b = ab.b, h = ab.h, q0 = ab.blk * (64 * NQS);
   const int F = p.F, H = p.H;
   const long ld = 3L * H;
   const bf16* base = p.qkv + (long)b * F * ld;
@@ -183,21 +186,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const uint32_t kcol = (uint32_t)((H + h * HD) * 2), vcol = (uint32_t)((2 * H + h * HD) * 2);
 
   // this lane's two query rows (one per 16-row sub-tile) and their Q fragments
-  int qrow[2];
-  bf16x8 qf[2][2];
+  int qrow[NQS];
+  bf16x8 qf[NQS][2];
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
-    qrow[qs] = q0 + 32 * wave + 16 * qs + (lane & 15);
+  for (int qs = 0; qs < NQS; ++qs) {
+    qrow[qs] = q0 + 16 * NQS * wave + 16 * qs + (lane & 15);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) qf[qs][kk] = load_row_frag(base + h * HD, ld, qrow[qs], F, kk, lane);
   }
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float m_run[NQS], l_run[NQS];
+#pragma unroll
+  for (int qs = 0; qs < NQS; ++qs) {
+    m_run[qs] = -INFINITY;
+    l_run[qs] = 0.f;
+  }
   const float c2 = p.scale * 1.4426950408889634f;  // softmax scale x log2(e)
   const uint32_t thi = p.thresh16 << 16;
-  const uint32_t rowseed[2] = {drop_rowseed(p, b, h, qrow[0]), drop_rowseed(p, b, h, qrow[1])};
-  f32x4 oacc[2][4];
+  uint32_t rowseed[NQS];
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs)
+  for (int qs = 0; qs < NQS; ++qs) rowseed[qs] = drop_rowseed(p, b, h, qrow[qs]);
+  f32x4 oacc[NQS][4];
+#pragma unroll
+  for (int qs = 0; qs < NQS; ++qs)
 #pragma unroll
     for (int i = 0; i < 4; ++i) oacc[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -218,12 +228,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const char* vt_lds = kt_lds + TILE_BYTES;
     const int k0 = kt * KT;
     // ---- S^T = K Q^T : rows = keys (16*ks + 4g + r), column = this lane's query
-    f32x4 s[2][4];
+    f32x4 s[NQS][4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 ka = frag_rows(kt_lds, ks, 0, lane), kb = frag_rows(kt_lds, ks, 1, lane);
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
+      for (int qs = 0; qs < NQS; ++qs) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qs][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[qs][1], a, 0, 0, 0);
@@ -233,10 +243,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     // ---- online softmax per query (lane-local column), dropout, pack P^T as the B operand of the PV product.
     // Scores stay raw: the softmax scale and log2(e) are folded into one fma in front of v_exp_f32; keys are masked only
     // in the tile that crosses the key length; the dropout scale is applied once, to O, at the end.
-    bf16x8 pb[2][2];
+    bf16x8 pb[NQS][2];
     const bool edge = k0 + KT > kl;  // uniform
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < NQS; ++qs) {
       if (edge) {
         const int klo = opaque_s(kl);
 #pragma unroll
@@ -299,12 +309,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       for (int i = 0; i < 4; ++i) {
         const bf16x8 va = frag_cols_perm(vt_lds, i, 32 * t2, lane);
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) oacc[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qs][t2], oacc[qs][i], 0, 0, 0);
+        for (int qs = 0; qs < NQS; ++qs) oacc[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qs][t2], oacc[qs][i], 0, 0, 0);
       }
   }
   // ---- epilogue: O = acc / l, log-sum-exp for the backward
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
+  for (int qs = 0; qs < NQS; ++qs) {
     const int q = qrow[qs];
     if (q >= F) continue;
     const float inv = l_run[qs] > 0.f ? p.drop_scale / l_run[qs] : 0.f;
@@ -338,12 +348,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 
 // dQ: workgroup = 128 queries of one (b, h); sweeps the keys.  Same orientation as the forward:
 //   S^T[key][q], dP^T[key][q] = V dO^T, dS^T = P^T * (dP^T * mask/(1-p) - delta[q]); dQ^T[d][q] += K^T[d][key] dS^T[key][q].
-template <bool DROP>
+template <bool DROP, int NQS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K rows | K transpose | V rows)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const AttnBlock ab = attn_block();
-  const int b = ab.b, h = ab.h, q0 = ab.blk * QB;
+  const int b = ab.b, h = ab.h, q0 = ab.blk * (64 * NQS);
   const int F = p.F, H = p.H;
   const long ld = 3L * H;
   const bf16* base = p.qkv + (long)b * F * ld;
@@ -352,15 +362,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
   const uint32_t kcol = (uint32_t)((H + h * HD) * 2), vcol = (uint32_t)((2 * H + h * HD) * 2);
   const int g = lane >> 4;
-  int qrow[2];
-  bf16x8 qf[2][2], dof[2][2];
-  float lse[2], dl[2], lse2[2];
-  uint32_t rowbase[2];  // dropout row seeds
+  int qrow[NQS];
+  bf16x8 qf[NQS][2], dof[NQS][2];
+  float lse[NQS], dl[NQS], lse2[NQS];
+  uint32_t rowbase[NQS];  // dropout row seeds
   const float c2 = p.scale * 1.4426950408889634f;
   const uint32_t thi = p.thresh16 << 16;
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
-    qrow[qs] = q0 + 32 * wave + 16 * qs + (lane & 15);
+  for (int qs = 0; qs < NQS; ++qs) {
+    qrow[qs] = q0 + 16 * NQS * wave + 16 * qs + (lane & 15);
     rowbase[qs] = drop_rowseed(p, b, h, qrow[qs]);
     const int qc = min(qrow[qs], F - 1);
     lse[qs] = p.lse[((long)b * p.nh + h) * F + qc];
@@ -383,9 +393,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     dl[qs] = part / p.drop_scale;
     if (g == 0 && qrow[qs] < F) p.delta[((long)b * p.nh + h) * F + qrow[qs]] = part;
   }
-  f32x4 dq[2][4];
+  f32x4 dq[NQS][4];
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs)
+  for (int qs = 0; qs < NQS; ++qs)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto issue = [&](int kt, int stage) {
@@ -407,16 +417,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     const bool edge = k0 + KT > kl;  // uniform: only this tile needs the key-length mask
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-      bf16x8 dsb[2];
+      bf16x8 dsb[NQS];
       {
-        f32x4 s[2][2], dp[2][2];  // [query sub-tile][key sub-tile of this half]
+        f32x4 s[NQS][2], dp[NQS][2];  // [query sub-tile][key sub-tile of this half]
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
           const int ks = 2 * t2 + kh;
           const bf16x8 ka = frag_rows(k_rows, ks, 0, lane), kb = frag_rows(k_rows, ks, 1, lane);
           const bf16x8 va = frag_rows(v_rows, ks, 0, lane), vb = frag_rows(v_rows, ks, 1, lane);
 #pragma unroll
-          for (int qs = 0; qs < 2; ++qs) {
+          for (int qs = 0; qs < NQS; ++qs) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qs][0], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[qs][1], a, 0, 0, 0);
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         if (edge) {  // keys beyond the key length: -inf before the exponent (only the tile that crosses it pays)
           const int klo = opaque_s(kl);
 #pragma unroll
-          for (int qs = 0; qs < 2; ++qs)
+          for (int qs = 0; qs < NQS; ++qs)
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
                 if (k0 + 16 * (2 * t2 + kh) + 4 * g + r >= klo) s[qs][kh][r] = -INFINITY;
         }
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
+        for (int qs = 0; qs < NQS; ++qs) {
           // P'' = exp2(s * c2 - lsc) = P * scale / (1 - p); dS = P'' (keep ? dP : 0 - delta (1 - p)).  Rows without any valid
           // key have lse = -inf -> lsc = +inf -> P'' = 0.  Packed fp32 over the key pair.
           const f32x2 c2v = {c2, c2}, lscv = {-lse2[qs], -lse2[qs]}, dlv = {dl[qs], dl[qs]};
@@ -465,12 +475,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
       for (int i = 0; i < 4; ++i) {
         const bf16x8 ka = frag_cols_perm(k_tr, i, 32 * t2, lane);
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) dq[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb[qs], dq[qs][i], 0, 0, 0);
+        for (int qs = 0; qs < NQS; ++qs) dq[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb[qs], dq[qs][i], 0, 0, 0);
       }
     }
   }
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
+  for (int qs = 0; qs < NQS; ++qs) {
     const int q = qrow[qs];
     if (q >= F) continue;
     bf16* dst = p.dqkv + ((long)b * F + q) * ld + h * HD + 4 * g;
@@ -486,12 +496,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 //   S[q][key] = Q K^T (query on the accumulator row, key on the lane), dP[q][key] = dO V^T,
 //   Pd = P * mask/(1-p), dS = P * (dP * mask/(1-p) - delta[q]) * scale,
 //   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key].
-template <bool DROP>
+template <bool DROP, int NKS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q rows|Q tr|dO rows|dO tr), then lse|delta per stage
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const AttnBlock ab = attn_block();
-  const int b = ab.b, h = ab.h, key0 = ab.blk * QB;
+  const int b = ab.b, h = ab.h, key0 = ab.blk * (64 * NKS);
   const int F = p.F, H = p.H;
   const long ld = 3L * H;
   const bf16* base = p.qkv + (long)b * F * ld;
@@ -502,11 +512,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
   const uint32_t qcol = (uint32_t)(h * HD * 2);
   const int g = lane >> 4;
   float* stat = reinterpret_cast<float*>(smem + 2 * 4 * TILE_BYTES);  // [stage][lse * log2 e KT | delta KT | dropout row seed KT]
-  int krow[2];
-  bf16x8 kf[2][2], vf[2][2];
+  int krow[NKS];
+  bf16x8 kf[NKS][2], vf[NKS][2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    krow[ks] = key0 + 32 * wave + 16 * ks + (lane & 15);
+  for (int ks = 0; ks < NKS; ++ks) {
+    krow[ks] = key0 + 16 * NKS * wave + 16 * ks + (lane & 15);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       kf[ks][kk] = load_row_frag(base + H + h * HD, ld, krow[ks], F, kk, lane);
@@ -516,17 +526,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
   const float c2 = p.scale * 1.4426950408889634f;
   const float log2scale = __log2f(p.scale);
   const uint32_t thi = p.thresh16 << 16;
-  const uint32_t kphi[2] = {(uint32_t)(krow[0] >> 1) * DROP_PHI, (uint32_t)(krow[1] >> 1) * DROP_PHI};
-  // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
-  f32x4 sinit[2];
+  uint32_t kphi[NKS];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < NKS; ++ks) kphi[ks] = (uint32_t)(krow[ks] >> 1) * DROP_PHI;
+  // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
+  f32x4 sinit[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
     const float v = krow[ks] < kl ? 0.f : -3.0e38f;
     sinit[ks] = (f32x4){v, v, v, v};
   }
-  f32x4 dk[2][4], dv[2][4];
+  f32x4 dk[NKS][4], dv[NKS][4];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       dk[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -564,16 +576,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const uint32_t* seed_s = reinterpret_cast<const uint32_t*>(lse_s + 2 * KT);
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-      bf16x8 pdb[2], dsb[2];  // per key sub-tile, for the 32 queries of this half
+      bf16x8 pdb[NKS], dsb[NKS];  // per key sub-tile, for the 32 queries of this half
       {
-        f32x4 s[2][2], dp[2][2];  // [key sub-tile][query sub-tile of this half]: rows = queries, column = key
+        f32x4 s[NKS][2], dp[NKS][2];  // [key sub-tile][query sub-tile of this half]: rows = queries, column = key
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
           const int qsb = 2 * t2 + qh;
           const bf16x8 qa = frag_rows(q_rows, qsb, 0, lane), qb = frag_rows(q_rows, qsb, 1, lane);
           const bf16x8 da = frag_rows(do_rows, qsb, 0, lane), db = frag_rows(do_rows, qsb, 1, lane);
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
+          for (int ks = 0; ks < NKS; ++ks) {
             // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
             f32x4 a = sinit[ks], c = {0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
@@ -588,14 +600,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
         for (int qh = 0; qh < 2; ++qh) {
           // Dropout words of this lane's 4 queries x 2 keys.  A word covers a key PAIR and the pair sits in two adjacent
           // lanes, so each lane mixes two of the four query rows and takes the other two from its partner by DPP.
-          uint32_t W[2][4];
+          uint32_t W[NKS][4];
           if (DROP) {
             const int par = lane & 1;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const uint32_t rs = seed_s[16 * (2 * t2 + qh) + 4 * g + par + 2 * i];  // row par + 2i of this lane's four
 #pragma unroll
-              for (int ks = 0; ks < 2; ++ks) {
+              for (int ks = 0; ks < NKS; ++ks) {
                 const uint32_t mine = drop_word(rs + kphi[ks]);
                 const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);  // row 1 - par + 2i
                 W[ks][2 * i] = par ? other : mine;
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
             const int ql = 16 * (2 * t2 + qh) + 4 * g + r;  // query inside the tile
             const f32x2 c2v = {c2, c2}, lscv = {-lse_s[ql], -lse_s[ql + 1]}, dlv = {dl_s[ql], dl_s[ql + 1]};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
               const f32x2 a = (f32x2){s[ks][qh][r], s[ks][qh][r + 1]} * c2v + lscv;
               f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};  // P * scale
               f32x2 dpv = {dp[ks][qh][r], dp[ks][qh][r + 1]}, pd = pr;
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
           }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
           pdb[ks] = pack_p(s[ks][0], s[ks][1]);
           dsb[ks] = pack_p(dp[ks][0], dp[ks][1]);
         }
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
         const bf16x8 doa = frag_cols_perm(do_tr, i, 32 * t2, lane);
         const bf16x8 qa = frag_cols_perm(q_tr, i, 32 * t2, lane);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
           dv[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa, pdb[ks], dv[ks][i], 0, 0, 0);
           dk[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, dsb[ks], dk[ks][i], 0, 0, 0);
         }
@@ -651,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
   }
   const float inv_scale = 1.f / p.scale;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < NKS; ++ks) {
     const int key = krow[ks];
     if (key >= F) continue;
     bf16* dkd = p.dqkv + ((long)b * F + key) * ld + H + h * HD + 4 * g;
@@ -1118,6 +1130,19 @@ int attn_bwd_mode() {
   return g_attn_bwd_mode;
 }
 
+// Per-wave tile of the three kernels (SSAK_ATTN_TILE="f,q,k", each 1 or 2; development switch).  The kernels are bound by
+// how many waves per SIMD are in their VALU phase at once (tools/probes/valu_rate.hip: one wave issues a VALU instruction
+// every ~6 cycles, the SIMD takes one every 3-4), so the smaller per-wave state of a 16-row tile can pay for its extra LDS reads.
+int attn_tile(int which) {
+  static int t[3] = {-1, -1, -1};
+  if (t[0] < 0) {
+    int v[3] = {2, 2, 2};
+    if (const char* e = getenv("SSAK_ATTN_TILE")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+    for (int i = 0; i < 3; ++i) t[i] = v[i] == 1 ? 1 : 2;
+  }
+  return t[which];
+}
+
 }  // namespace
 
 extern "C" int ssak_attention_bwd_mode(int split) {
@@ -1133,10 +1158,14 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens
   SSAK_REQUIRE((long)F * 3 * H * 2 < 2000000000L, "attention: one utterance of q|k|v must span < 2 GB");
   const AttnParams p = make_params(qkv, ctx, lse, klens, nullptr, nullptr, nullptr, B, F, nh, H, drop);
   ProfScope prof_scope(PROF_ATTN_FWD, 4.0 * B * nh * (double)F * F * HD, st);  // S = Q K^T and O = P V
-  if (p.thresh16)
-    attn_fwd_kernel<true><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p);
-  else
-    attn_fwd_kernel<false><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p);
+  const int nqs = attn_tile(0);
+#define ATT_LAUNCH_FWD(D, N) attn_fwd_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p)
+  if (p.thresh16) {
+    if (nqs == 1) ATT_LAUNCH_FWD(true, 1); else ATT_LAUNCH_FWD(true, 2);
+  } else {
+    if (nqs == 1) ATT_LAUNCH_FWD(false, 1); else ATT_LAUNCH_FWD(false, 2);
+  }
+#undef ATT_LAUNCH_FWD
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -1160,22 +1189,31 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
     SSAK_LAUNCH_CHECK();
     return SSAK_OK;
   }
-  if (p.thresh16)
-    attn_bwd_dq_kernel<true><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
-  else
-    attn_bwd_dq_kernel<false><<<dim3(ssak_cdiv(F, QB), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p);
+  const int nqs = attn_tile(1), nks = attn_tile(2);
+#define ATT_LAUNCH_DQ(D, N) attn_bwd_dq_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p)
+  if (p.thresh16) {
+    if (nqs == 1) ATT_LAUNCH_DQ(true, 1); else ATT_LAUNCH_DQ(true, 2);
+  } else {
+    if (nqs == 1) ATT_LAUNCH_DQ(false, 1); else ATT_LAUNCH_DQ(false, 2);
+  }
+#undef ATT_LAUNCH_DQ
   SSAK_LAUNCH_CHECK();
   constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 3 * KT * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
-    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
     attr_done = true;
   }
-  if (p.thresh16)
-    attn_bwd_dkv_kernel<true><<<dim3(ssak_cdiv(F, QB), nh, B), 256, dkv_lds, st>>>(p);
-  else
-    attn_bwd_dkv_kernel<false><<<dim3(ssak_cdiv(F, QB), nh, B), 256, dkv_lds, st>>>(p);
+#define ATT_LAUNCH_DKV(D, N) attn_bwd_dkv_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, dkv_lds, st>>>(p)
+  if (p.thresh16) {
+    if (nks == 1) ATT_LAUNCH_DKV(true, 1); else ATT_LAUNCH_DKV(true, 2);
+  } else {
+    if (nks == 1) ATT_LAUNCH_DKV(false, 1); else ATT_LAUNCH_DKV(false, 2);
+  }
+#undef ATT_LAUNCH_DKV
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }

@@ -866,9 +866,23 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
   const int p8_bm = plan.bm;
   if (colsum_fused) p.colsum = (float*)workspace;
+  p.kperm_p = p.kperm_n2 = 0;
   if (plan.p8) {
     p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
+    // Toeplitz A (conv as GEMM, rows overlap: lda < K): visit the K tiles so that the two reads of the same bytes -- tap t + s of
+    // row i is tap t of row i + 1 -- are one K step apart instead of lda / BK steps (gemm_common.h: kperm_*)
+    static const bool env_no_perm = [] {
+      const char* e = getenv("SSAK_GEMM_NO_KPERM");
+      return e && e[0] == '1';
+    }();
+    if (!d->a_kmajor && split == 1 && d->K % BK == 0 && d->lda % BK == 0 && d->lda < d->K && !env_no_perm) {
+      const int pp = (int)(d->lda / BK), n2 = nkt - pp;
+      if (n2 > 0 && n2 <= pp) {
+        p.kperm_p = pp;
+        p.kperm_n2 = n2;
+      }
+    }
     rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
   } else if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
     p.tiles_m = ssak_cdiv(d->M, 256);

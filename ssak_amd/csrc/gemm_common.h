@@ -30,6 +30,11 @@ struct GemmParams {
   uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
   float* colsum;          // [wave-tile rows][N] column sums of the stored values (bias gradient of the producing Linear) or null
   int* tile_ctr;          // persistent kernels: [0] = tickets handed out past the first round, [1] = workgroups done (or null: static)
+  // K-tile visiting order of the persistent kernel for a Toeplitz A (conv as GEMM: lda = stride * C < K = k * C, so K tile kt
+  // of row i + 1 IS K tile kt + kperm_p of row i): the first 2 * kperm_n2 steps visit (c, c + kperm_p) pairs, so the second
+  // read of the same bytes follows the first one K step later and hits the L2 instead of going back to the Infinity Cache /
+  // HBM 16 steps later (0 / 0 = natural order).  Both operands follow the same order; only the summation order changes.
+  int kperm_p, kperm_n2;
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {

@@ -94,17 +94,22 @@ struct P8Stager {
   }
   // stage piece `h` of k-tile kt (absolute index; kt >= kt_end: zero-writing dummies) and advance that piece's offsets
   template <int H>
-  __device__ __forceinline__ void issue(char* lds_piece, int kt, int kt_end, int K) {
+  __device__ __forceinline__ void issue(char* lds_piece, int kt, int kt_end, int K, int perm_p = 0, int perm_n2 = 0) {
 #if defined(P8_ABL) && (P8_ABL & 1)
     if (kt >= 2) return;  // ablation: no LDS-DMA inside the main loop
 #endif
     // k-rows / k-chunks of this tile that exist (uniform): all 64, a K tail, or none (dummy past the last tile)
     const int klim = kt < kt_end ? min(K - kt * BK, BK) : 0;
+    // advance to the next K tile of the visiting order: step kt -> kt + 1 moves by + p (even step of a pair), 1 - p (odd) or 1
+    // tile (past the pairs).  An offset that starts out of range (OOB = 2^31) stays there: the moves never sum below zero and
+    // the total advance is < 2 GB.
+    const int dkt = kt < 2 * perm_n2 ? ((kt & 1) ? 1 - perm_p : perm_p) : 1;
+    const uint32_t adv = (uint32_t)dkt * kstep;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint32_t o = kofs[j] < klim ? off[H][j] : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_piece + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
-      off[H][j] += kstep;  // an OOB offset stays >= 2^31 (total advance < 2 GB), i.e. out of range
+      off[H][j] += adv;
     }
   }
 };
@@ -259,6 +264,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     return c;
   };
 
+  const int kpp = GROUPED ? 0 : p.kperm_p, kpn = GROUPED ? 0 : p.kperm_n2;  // K-tile visiting order (gemm_common.h)
   P8Stager<A_KM, SEGA, 2 * SEGA, A_KM ? 16 : 4 * MH, 2> sa;
   P8Stager<B_KM, 32, 64, 16, 4> sb;
   P8Frag<A_KM, MH> fra;
@@ -289,14 +295,14 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
       sa.init(p.A + c.z1 * p.sa1 + c.z2 * p.sa2, p.lda, c.bm0, p.M, c.kt0, p.ext_a);
       sb.init(p.B + c.z1 * p.sb1 + c.z2 * p.sb2, p.ldb, c.bn0, p.N, c.kt0, p.ext_b);
     }
-    sb.template issue<0>(buf0 + 2 * P8_PIECE, c.kt0, c.kt1, p.K);
-    sa.template issue<0>(buf0 + 0 * P8_PIECE, c.kt0, c.kt1, p.K);
-    sb.template issue<1>(buf0 + 3 * P8_PIECE, c.kt0, c.kt1, p.K);
-    sa.template issue<1>(buf0 + 1 * P8_PIECE, c.kt0, c.kt1, p.K);
-    sb.template issue<0>(buf1 + 2 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
-    sa.template issue<0>(buf1 + 0 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
-    sb.template issue<1>(buf1 + 3 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
-    sa.template issue<1>(buf1 + 1 * P8_PIECE, c.kt0 + 1, c.kt1, p.K);
+    sb.template issue<0>(buf0 + 2 * P8_PIECE, c.kt0, c.kt1, p.K, kpp, kpn);
+    sa.template issue<0>(buf0 + 0 * P8_PIECE, c.kt0, c.kt1, p.K, kpp, kpn);
+    sb.template issue<1>(buf0 + 3 * P8_PIECE, c.kt0, c.kt1, p.K, kpp, kpn);
+    sa.template issue<1>(buf0 + 1 * P8_PIECE, c.kt0, c.kt1, p.K, kpp, kpn);
+    sb.template issue<0>(buf1 + 2 * P8_PIECE, c.kt0 + 1, c.kt1, p.K, kpp, kpn);
+    sa.template issue<0>(buf1 + 0 * P8_PIECE, c.kt0 + 1, c.kt1, p.K, kpp, kpn);
+    sb.template issue<1>(buf1 + 3 * P8_PIECE, c.kt0 + 1, c.kt1, p.K, kpp, kpn);
+    sa.template issue<1>(buf1 + 1 * P8_PIECE, c.kt0 + 1, c.kt1, p.K, kpp, kpn);
   };
   // vector-memory instructions the LDS-free epilogue issues per wave (stores only; vmcnt counts them like the DMA)
   const int epi_vm = (p.split_k > 1 || p.out_f32 || ((p.epilogue == SSAK_EPI_GELU || p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) && p.aux_out)) ? 8 * MH : 4 * MH;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 0 * P8_PIECE, i, kk);
       P8_FENCE();
-      if (!first) sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K);  // AB(t+1)
+      if (!first) sa.template issue<1>(nxt + 1 * P8_PIECE, kt + 1, kt1, p.K, kpp, kpn);  // AB(t+1)
       if (!settled) wait_vmcnt<8>();                                           // AB(t)
       __builtin_amdgcn_s_waitcnt(0xc07f);                                      // this wave's fragment reads are done
       P8_BARRIER();
@@ -400,9 +406,9 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(cur + 1 * P8_PIECE, i, kk);
       P8_FENCE();
-      sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K);  // AT(t+2)
-      sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K);  // BL(t+2)
-      sb.template issue<1>(cur + 3 * P8_PIECE, kt + 2, kt1, p.K);  // BR(t+2)
+      sa.template issue<0>(cur + 0 * P8_PIECE, kt + 2, kt1, p.K, kpp, kpn);  // AT(t+2)
+      sb.template issue<0>(cur + 2 * P8_PIECE, kt + 2, kt1, p.K, kpp, kpn);  // BL(t+2)
+      sb.template issue<1>(cur + 3 * P8_PIECE, kt + 2, kt1, p.K, kpp, kpn);  // BR(t+2)
       if (!(was_primed && first)) wait_vmcnt<8>();                 // AT(t+1), BL(t+1), BR(t+1)
       __builtin_amdgcn_s_waitcnt(0xc07f);
       P8_BARRIER();

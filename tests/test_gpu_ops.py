@@ -239,6 +239,28 @@ def test_gemm_toeplitz_conv(hip):
     assert torch.equal(y.cpu(), ref)
 
 
+@pytest.mark.parametrize("Tin,Cc,Co,k,s,km", [(4001, 512, 512, 3, 2, False), (2047, 512, 512, 3, 2, True), (3000, 256, 256, 3, 2, False),
+                                               (2001, 512, 512, 2, 2, False)])
+def test_gemm_toeplitz_conv_k_tile_order(hip, Tin, Cc, Co, k, s, km):
+    """The conv stack's shapes on the persistent kernel: with overlapping A rows (lda = s*C < K = k*C) the K tiles are visited
+    in (c, c + lda/64) pairs so that the second read of the same bytes follows the first (gemm_common.h: kperm_*); only the
+    summation order changes.  Small-integer operands: every partial sum is exact in fp32, so the result must EQUAL the fp32
+    convolution whatever the order (a wrong tile pairing or a weight tile out of step with its activation tile cannot)."""
+    g = torch.Generator().manual_seed(Tin + Cc)
+    Bn = 2
+    Tout = (Tin - k) // s + 1
+    x = torch.randint(-2, 3, (Bn, Tin, Cc), generator=g).to(torch.bfloat16)
+    w = torch.randint(-1, 2, (Co, Cc, k), generator=g).to(torch.bfloat16)
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), stride=s).transpose(1, 2)
+    wk = w.permute(0, 2, 1).contiguous().view(Co, k * Cc)  # [Co, k, Cin]: K index = tap*Cin + c
+    if km:
+        wk = wk.t().contiguous()  # [K, Co]
+    y = torch.empty(Bn, Tout, Co, dtype=torch.float32).cuda()
+    hip.gemm(x.cuda(), wk.cuda(), y, Tout, Co, k * Cc, lda=s * Cc, ldb=Co if km else k * Cc, ldc=Co, nb1=Bn, b_kmajor=km,
+             sa=(Tin * Cc, 0), sc=(Tout * Co, 0))
+    assert torch.equal(y.cpu(), ref)
+
+
 def test_gemm_rejects_bad_args(hip):
     A = torch.zeros(8, 8, dtype=torch.bfloat16).cuda()
     Cc = torch.zeros(8, 8, dtype=torch.float32).cuda()
