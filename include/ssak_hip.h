@@ -203,6 +203,15 @@ typedef struct {
 int ssak_prof_enable(int on);
 int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 128; returns the number of entries */
 
+/* ---- a3 (part): first layer of the feature encoder -------------------------------------------
+ * Conv1d(1, C, k=10, s=5, no bias) -> GroupNorm(C groups: per channel over time) -> GELU of Wav2Vec2GroupNormConvLayer
+ * (transformers modeling_wav2vec2.py:302-323), waveform x [B, T] fp32 -> out [B, T0, C] bf16 channels-last, T0 = (T-10)/5+1.
+ * w [C, 10], gamma / beta [C] fp32.  Statistics in fp64 from 65 input moments per utterance; for C = 512 the taps run on the
+ * matrix cores with a three-term bf16 split (fp32-grade).  Exported for per-op parity tests; the engine calls the same code. */
+size_t ssak_conv0_workspace_bytes(int B, int T, int C);
+int ssak_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, void* out_bf16, void* workspace,
+                       size_t workspace_bytes, int B, int T, int C, void* stream);
+
 /* ---- a7 (part): fused self-attention, head_dim 64 --------------------------------------------
  * Replaces Wav2Vec2Attention's softmax(QK^T d^-0.5 + key mask) -> dropout -> .V and its autograd
  * (transformers modeling_wav2vec2.py:438-463,500-548) for one layer.  qkv [B*F, 3H] bf16 (q | k | v, heads

@@ -146,6 +146,146 @@ __global__ __launch_bounds__(256) void conv0_bias_kernel(const float* __restrict
   }
 }
 
+// conv0 apply pass on the matrix cores (bf16 output, C = 512).  The VALU form above spends ~25 instructions per output
+// element -- ten fmas for the taps, the affine, the GELU -- and with 524 M elements per step of 32 utterances that is what
+// bounds it (tools/probes/valu_rate.hip: an fma is 4 cycles per wave; 344 us measured, 1.07 GB of stores would take ~200 us):
+// it is arithmetic-bound, not store-bound.  Here the ten-tap dot product is ONE pair of 16x16x32 MFMAs per 16 channels x 16
+// frames with fp32-grade accuracy from a three-term bf16 split, x = xh + xl, w = wh + wl (hi / lo bf16 parts):
+//   MFMA 1: K = [wh (10, padded to 16) | wh (16)] x [xh (16) | xl (16)]  = wh xh + wh xl
+//   MFMA 2: K = [wl (16) | 0]                     x [xh (16) | 0]        = wl xh          (wl xl ~ 2^-18 relative: dropped)
+// so the VALU only runs y = v a_c + b_c (the GroupNorm folded into one fma) and the GELU, in packed fp32.
+//   workgroup = 128 frames of one utterance, 4 waves x 128 channels; the frames' [xh | xl] rows are built once per workgroup
+//   in LDS (64 B per frame), the weight fragments once per wave in registers.  Orientation out^T[channel][frame] = W X^T: a
+//   lane then holds four consecutive channels of one frame, which go through a wave-private, XOR-swizzled LDS tile
+//   ([16 frames][128 channels], 8-byte writes) and leave as 16-byte stores of whole 256-byte row segments.
+constexpr int C0M_FR = 128;
+constexpr int C0M_NS = (C0M_FR - 1) * ST0 + KS0;  // 645 input samples
+typedef __attribute__((ext_vector_type(2))) float c0_f32x2;
+
+__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16* __restrict__ out, const double* __restrict__ sums, int T, int T0) {
+  constexpr int C = 512;
+  __shared__ float xs[C0M_NS + 3];
+  __shared__ __attribute__((aligned(16))) float ab[2][C];                 // y = v * ab[0][c] + ab[1][c]
+  __shared__ __attribute__((aligned(16))) char ximg[C0M_FR * 64];        // per frame: xh[0..9], 0 x 6 | xl[0..9], 0 x 6 (bf16)
+  __shared__ __attribute__((aligned(16))) char ostage[4][16 * 256];      // per wave: [16 frames][128 channels] bf16, 16-byte chunk ch of row r at ch ^ r
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lc = lane & 15;
+  const int b = blockIdx.y, f0 = blockIdx.x * C0M_FR;
+  const float* xb = x + (size_t)b * T;
+  for (int i = threadIdx.x; i < C0M_NS; i += 256) {
+    const int sidx = f0 * ST0 + i;
+    xs[i] = (sidx < T) ? xb[sidx] : 0.f;
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double s1 = sums[((size_t)b * C + c) * 2], s2 = sums[((size_t)b * C + c) * 2 + 1];
+    const double m = s1 / T0;
+    const double var = fmax(s2 / T0 - m * m, 0.0);
+    const float mu = (float)m, rs = (float)(1.0 / sqrt(var + 1e-5));
+    const float a = rs * gamma[c];
+    ab[0][c] = a;
+    ab[1][c] = beta[c] - mu * a;
+  }
+  // weight fragments (A operands: row = channel 128 wave + 16 ct + lc, k = 8 g + j):
+  //   A1 = [wh | wh]: g even -> taps 0..7, g odd -> taps 8, 9, then zeros;   A2 = [wl | 0]: the same for g < 2, zeros above
+  bf16x8 wa1[8], wa2[8];
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct) {
+    const float* wc = w + (size_t)(128 * wave + 16 * ct + lc) * KS0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = (g & 1) * 8 + j;
+      const float v = k < KS0 ? wc[k] : 0.f;
+      const bf16 hi = (bf16)v;
+      const bf16 lo = (bf16)(v - (float)hi);
+      wa1[ct][j] = hi;
+      wa2[ct][j] = g < 2 ? lo : (bf16)0.f;
+    }
+  }
+  __syncthreads();
+  {  // [xh | xl] rows: thread = (frame, half)
+    const int f = threadIdx.x >> 1, half = threadIdx.x & 1;
+    bf16x8 r0, r1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float v = k < KS0 ? xs[f * ST0 + k] : 0.f;
+      const bf16 hi = (bf16)v;
+      const bf16 e = half ? (bf16)(v - (float)hi) : hi;
+      if (k < 8)
+        r0[k] = e;
+      else
+        r1[k - 8] = e;
+    }
+    *reinterpret_cast<bf16x8*>(ximg + f * 64 + half * 32) = r0;
+    *reinterpret_cast<bf16x8*>(ximg + f * 64 + half * 32 + 16) = r1;
+  }
+  __syncthreads();
+  char* const ost = ostage[wave];
+  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  for (int ft = 0; ft < C0M_FR / 16; ++ft) {
+    if (f0 + 16 * ft >= T0) break;  // uniform
+    // B operands: column = frame 16 ft + lc, k = 8 g + j of the frame's 64-byte row
+    const bf16x8 xb1 = *reinterpret_cast<const bf16x8*>(ximg + (16 * ft + lc) * 64 + g * 16);
+    const bf16x8 xb2 = g < 2 ? xb1 : zero8;
+    // Stage-major over the eight channel tiles: as one chain per tile (affine -> polynomial -> exp -> rcp -> store) the
+    // compiler emitted the eight GELU chains one after the other, each waiting on its own transcendental latencies.
+    c0_f32x2 y[16];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1[ct], xb1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa2[ct], xb2, acc, 0, 0, 0);
+      // acc[r] = conv(channel 128 wave + 16 ct + 4 g + r, frame 16 ft + lc)
+      const int c0 = 128 * wave + 16 * ct + 4 * g;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ab[0][c0]);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&ab[1][c0]);
+      y[2 * ct] = (c0_f32x2){acc[0], acc[1]} * (c0_f32x2){a4[0], a4[1]} + (c0_f32x2){b4[0], b4[1]};
+      y[2 * ct + 1] = (c0_f32x2){acc[2], acc[3]} * (c0_f32x2){a4[2], a4[3]} + (c0_f32x2){b4[2], b4[3]};
+    }
+    {  // GELU = y * Phi(y), Phi = 1 / (1 + exp2(q(y))) (common.h: phi2), every stage over all sixteen pairs
+      c0_f32x2 xc[16], q[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xc[i] = (c0_f32x2){__builtin_amdgcn_fmed3f(y[i][0], -6.f, 6.f), __builtin_amdgcn_fmed3f(y[i][1], -6.f, 6.f)};
+      c0_f32x2 sq[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sq[i] = xc[i] * xc[i];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) q[i] = __builtin_elementwise_fma(sq[i], (c0_f32x2){SSAK_PHI_C3, SSAK_PHI_C3}, (c0_f32x2){SSAK_PHI_C2, SSAK_PHI_C2});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) q[i] = __builtin_elementwise_fma(q[i], sq[i], (c0_f32x2){SSAK_PHI_C1, SSAK_PHI_C1});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) q[i] = __builtin_elementwise_fma(q[i], sq[i], (c0_f32x2){SSAK_PHI_C0, SSAK_PHI_C0});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) q[i] = q[i] * xc[i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) q[i] = (c0_f32x2){__builtin_amdgcn_exp2f(q[i][0]), __builtin_amdgcn_exp2f(q[i][1])} + (c0_f32x2){1.f, 1.f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) q[i] = (c0_f32x2){__builtin_amdgcn_rcpf(q[i][0]), __builtin_amdgcn_rcpf(q[i][1])};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const c0_f32x2 o0 = y[2 * ct] * q[2 * ct], o1 = y[2 * ct + 1] * q[2 * ct + 1];
+        const bf16x4 o = {(bf16)o0[0], (bf16)o0[1], (bf16)o1[0], (bf16)o1[1]};
+        // row lc of the wave's tile, channels 16 ct + 4 g .. + 3: 16-byte chunk 2 ct + (g >> 1), half (g & 1)
+        *reinterpret_cast<bf16x4*>(ost + lc * 256 + (((2 * ct + (g >> 1)) ^ lc) << 4) + (g & 1) * 8) = o;
+      }
+    }
+    // the tile leaves as whole 256-byte row segments: lane = (row 4 pass + g, chunk lc)
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = 4 * pass + g;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ost + r * 256 + ((lc ^ r) << 4));
+      const int frame = f0 + 16 * ft + r;
+      if (frame < T0) *reinterpret_cast<f32x4*>(out + ((size_t)b * T0 + frame) * C + 128 * wave + 8 * lc) = v;
+    }
+  }
+}
+
 // GroupNorm statistics of the conv0 output WITHOUT evaluating the convolution: y[c,t] = sum_k w[c,k] x[5t+k], hence
 //   sum_t y[c,t]   = sum_k w[c,k] S[k],              S[k]    = sum_t x[5t+k]
 //   sum_t y[c,t]^2 = sum_{k,k'} w[c,k] w[c,k'] R[k,k'],  R[k,k'] = sum_t x[5t+k] x[5t+k']
@@ -619,6 +759,14 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
     conv0_channel_stats_kernel<<<dim3(ssak_cdiv(C, 256), B), 256, 0, st>>>(partial, nblk, w, C, sums);
     SSAK_LAUNCH_CHECK();
   }
+  static const bool no_mfma = getenv("SSAK_CONV0_VALU") != nullptr;  // development: the VALU apply pass
+  if constexpr (sizeof(OT) == 2) {
+    if (C == 512 && !no_mfma) {
+      conv0_mfma_kernel<<<dim3(ssak_cdiv(T0, C0M_FR), B), 256, 0, st>>>(x, w, gamma, beta, (bf16*)out, sums, T, T0);
+      SSAK_LAUNCH_CHECK();
+      return SSAK_OK;
+    }
+  }
   conv0_kernel<OT, true, FR_APPLY><<<dim3(ssak_cdiv(T0, FR_APPLY), B), 256, 0, st>>>(x, w, gamma, beta, out, nullptr, sums, T, T0, C);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
@@ -744,3 +892,17 @@ int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, cons
   template int k_posconv_pack_t<T>(const T*, T*, int, int, int, int, int, hipStream_t);
 SSAK_INSTANTIATE_CONV_KERNELS(bf16)
 SSAK_INSTANTIATE_CONV_KERNELS(float)
+
+// exported for per-op parity tests (a3: first layer of the feature encoder)
+extern "C" int ssak_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, void* out_bf16, void* workspace,
+                                  size_t workspace_bytes, int B, int T, int C, void* stream) {
+  SSAK_REQUIRE(x && w && gamma && beta && out_bf16 && workspace, "conv0_gn_gelu: null pointer");
+  SSAK_REQUIRE(T >= KS0, "conv0_gn_gelu: T=%d shorter than the kernel", T);
+  const int T0 = (T - KS0) / ST0 + 1;
+  SSAK_REQUIRE(workspace_bytes >= k_conv0_stats_doubles(B, T0, C) * sizeof(double), "conv0_gn_gelu: workspace too small");
+  return k_conv0_gn_gelu_t<bf16>(x, w, gamma, beta, (bf16*)out_bf16, (double*)workspace, B, T, T0, C, KS0, ST0, (hipStream_t)stream);
+}
+extern "C" size_t ssak_conv0_workspace_bytes(int B, int T, int C) {
+  if (T < KS0) return 0;
+  return k_conv0_stats_doubles(B, (T - KS0) / ST0 + 1, C) * sizeof(double);
+}

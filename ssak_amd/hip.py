@@ -74,6 +74,8 @@ def _load():
         "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "ssak_gemm_tile_order": (i32, [i32]),
         "ssak_attention_bwd_mode": (i32, [i32]),
+        "ssak_conv0_workspace_bytes": (sz, [i32, i32, i32]),
+        "ssak_conv0_gn_gelu": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
         "ssak_prof_enable": (i32, [i32]),
         "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
@@ -302,6 +304,18 @@ def prof_collect():
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops, BOUNDS[arr[i].bound]) for i in range(n)]
+
+
+def conv0_gn_gelu(x: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """x [B, T] fp32, w [C, 10], gamma / beta [C] -> [B, T0, C] bf16 (conv k=10 s=5 -> GroupNorm per channel -> GELU)."""
+    B, T = x.shape
+    C = w.shape[0]
+    T0 = (T - 10) // 5 + 1
+    out = torch.full((B, T0, C), float("nan"), dtype=torch.bfloat16, device=x.device)
+    nb = lib.ssak_conv0_workspace_bytes(B, T, C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(lib.ssak_conv0_gn_gelu(ptr(x), ptr(w.contiguous()), ptr(gamma), ptr(beta), ptr(out), ptr(ws), nb, B, T, C, stream()))
+    return out
 
 
 def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0):

@@ -308,6 +308,31 @@ def test_logmel_batch_ragged_and_properties(hip):
     assert (c[:, 0, :] == 9.0).all() and (c[:, 3001:, :] == 9.0).all()       # pad rows untouched
 
 
+# ------------------------------------------------------------------ conv0 + GroupNorm + GELU (a3)
+@pytest.mark.parametrize("B,T,C", [(2, 16000, 512), (3, 4007, 512), (1, 645, 512), (2, 3200, 64)])
+def test_conv0_groupnorm_gelu_vs_fp64(hip, B, T, C):
+    """First feature-encoder layer against an fp64 evaluation of Conv1d(k=10, s=5) -> GroupNorm(C, C) -> exact GELU
+    (transformers modeling_wav2vec2.py:302-323).  C = 512 takes the matrix-core form (taps as a three-term bf16 split: the
+    pre-normalisation values are fp32-grade, so the bf16 output may differ from the rounded reference by one bf16 ulp);
+    C = 64 the VALU form.  Tail frames of the last 128-frame block and every element of the output are covered (the buffer is
+    poisoned with NaN)."""
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(B, T, generator=g)
+    x = (x - x.mean(1, keepdim=True)) / x.std(1, keepdim=True)
+    w = torch.randn(C, 10, generator=g) * 0.3
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    out = hip.conv0_gn_gelu(x.cuda(), w.cuda(), gamma.cuda(), beta.cuda()).float().cpu()
+    y = torch.nn.functional.conv1d(x.double()[:, None, :], w.double()[:, None, :], stride=5)  # [B, C, T0]
+    y = (y - y.mean(2, keepdim=True)) / torch.sqrt(y.var(2, unbiased=False, keepdim=True) + 1e-5)
+    y = y * gamma.double()[None, :, None] + beta.double()[None, :, None]
+    ref = (0.5 * y * (1.0 + torch.erf(y / 2 ** 0.5))).transpose(1, 2)  # [B, T0, C]
+    assert torch.isfinite(out).all()
+    err = (out.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-4  # one bf16 ulp (2^-8 relative) + the GELU fit's 1.6e-5 * |y| near zero
+    assert (err <= tol).all(), float((err - tol).max())
+
+
 # ------------------------------------------------------------------ fused attention (head_dim 64)
 def _attn_ref(qkv, B, F, nh, klens=None):
     H = qkv.shape[1] // 3
