@@ -7,11 +7,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 d, out_path = sys.argv[1], sys.argv[2]
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-f = sorted(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True))[-1]
+f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)  # the newest pass (the directory keeps older ones)
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):

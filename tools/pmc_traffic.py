@@ -9,11 +9,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 
 def agg(d, cname):
-    f = sorted(glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"))[-1]
+    f = max(glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"), key=os.path.getmtime)  # the newest pass (the directory keeps older ones)
     a = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != cname:
