@@ -222,11 +222,13 @@ int ssak_attention_fwd(const void* qkv, void* ctx, float* lse, const int32_t* kl
                        uint64_t seed, uint32_t stream_id, void* stream);
 int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx, float* delta,
                        void* dqkv, int B, int F, int nh, int H, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
-/* Backward form: 1 (default) = two kernels (dQ; dK + dV), each recomputing P; 0 = ONE fused pass for dQ, dK and dV (a
- * workgroup per head walks the keys in blocks of 128 and adds each block's dQ tiles onto what it stored for the previous
- * blocks: fixed order, no atomics, bit-reproducible).  The fused form does 40 % fewer VALU instructions but is slower at the
- * train-step shape today; it is kept parity-tested.  Environment SSAK_ATTN_BWD=fused selects 0 at start-up. */
-int ssak_attention_bwd_mode(int split);
+/* Backward form: 1 (default) = two kernels (dQ; dK + dV), each recomputing P; 0 = one fused pass with producer / consumer
+ * wave specialisation; 2 = one fused pass with every wave in every role.  The fused forms evaluate P, the dropout words and dS
+ * once (40 % fewer VALU instructions, five matrix products instead of seven); a workgroup per head walks the keys in blocks and
+ * adds each block's dQ tiles onto what it stored for the previous blocks (fixed order, no atomics, bit-reproducible).  Both
+ * are parity-tested against the two-kernel form and both are slower at the train-step shape today.
+ * Environment SSAK_ATTN_BWD=ws / fused selects 0 / 2 at start-up. */
+int ssak_attention_bwd_mode(int mode);
 
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer

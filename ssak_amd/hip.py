@@ -329,9 +329,10 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
     return ctx, lse
 
 
-def attention_bwd_mode(split: bool):
-    """True (the default): two-kernel backward (dQ; dK + dV); False: the fused single-pass kernel."""
-    check(lib.ssak_attention_bwd_mode(1 if split else 0))
+def attention_bwd_mode(mode):
+    """1 / True (the default): two-kernel backward (dQ; dK + dV); 0 / False: the wave-specialised single-pass kernel;
+    2: the single-pass kernel with every wave in every role."""
+    check(lib.ssak_attention_bwd_mode(int(mode)))
 
 
 def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0):

@@ -405,9 +405,11 @@ def test_fused_attention_dropout_consistency(hip):
 @pytest.mark.parametrize("B,F,nh,ragged,p", [(2, 499, 12, False, 0.1), (3, 200, 4, True, 0.0), (3, 500, 2, True, 0.25),
                                               (1, 64, 2, False, 0.3), (2, 512, 3, False, 0.1), (1, 257, 1, False, 0.0),
                                               (2, 33, 8, True, 0.1), (2, 1500, 2, False, 0.1), (3, 749, 16, True, 0.05)])
-def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, p):
-    """The single-pass backward (dQ, dK, dV from one evaluation of P / the dropout words / dS; a workgroup per head walks the
-    keys in blocks of 256 and adds each block's dQ tiles onto what it stored for the previous blocks) against the two-kernel
+@pytest.mark.parametrize("mode", [0, 2])
+def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, p, mode):
+    """The single-pass backward forms (mode 0: producer / consumer wave specialisation; mode 2: every wave in every role) --
+    dQ, dK, dV from one evaluation of P / the dropout words / dS; a workgroup per head walks the keys in blocks and adds each
+    block's dQ tiles onto what it stored for the previous blocks -- against the two-kernel
     form on the same inputs and the same dropout stream: same mask, so the results differ by bf16 rounding only (<= 1e-2
     relative L2 per block of columns, the distance either sits from the fp32 reference).  The output buffer is poisoned
     (NaN): every element of dqkv must be written and the first key block must not read it.  Two fused runs are bit-identical."""
@@ -419,13 +421,13 @@ def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, 
     kw = dict(drop_p=p, seed=99, stream_id=5) if p else {}
     ctx, lse = hip.attention_fwd(qkv, B, F, nh, klens, **kw)
     try:
-        hip.attention_bwd_mode(True)
+        hip.attention_bwd_mode(1)
         ref = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
-        hip.attention_bwd_mode(False)
+        hip.attention_bwd_mode(mode)
         got = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
         again = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
     finally:
-        hip.attention_bwd_mode(True)  # the default form
+        hip.attention_bwd_mode(1)  # the default form
     assert torch.isfinite(got.float()).all() and torch.isfinite(ref.float()).all()
     assert torch.equal(got, again)
     rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))

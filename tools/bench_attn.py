@@ -38,9 +38,9 @@ for p in (0.0, 0.1):
     bwd = lambda: h.check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), None, ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H, p, 1, 3, st()))
     tf = timeit(fwd)
     out = [f"p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s)"]
-    for split in (False, True):
-        h.attention_bwd_mode(split)
+    for mode, name in ((0, "wave-spec."), (2, "fused"), (1, "two-kernel")):
+        h.attention_bwd_mode(mode)
         tb = timeit(bwd)
-        out.append(f"bwd {'two-kernel' if split else 'fused':10s} {tb:7.1f} us ({2 * fl / tb / 1e6:6.1f} TF/s algorithmic)")
-    h.attention_bwd_mode(True)
+        out.append(f"bwd {name:10s} {tb:7.1f} us ({2 * fl / tb / 1e6:6.1f} TF/s)")
+    h.attention_bwd_mode(1)
     print("   ".join(out))
