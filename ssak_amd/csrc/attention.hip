@@ -29,7 +29,6 @@ int attn_bwd_mode();
 int attn_tile(int which);  // 16-row sub-tiles per wave: 0 forward (queries), 1 dQ kernel (queries), 2 dK/dV kernel (keys)
 
 constexpr int HD = 64;    // head dim
-constexpr int QB = 128;   // queries per workgroup of the unfused paths that still use the constant
 constexpr int KT = 64;    // keys (or queries in dkv) per streamed tile
 constexpr int TILE_BYTES = KT * HD * 2;  // 8 KiB
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -87,13 +86,22 @@ __device__ __forceinline__ bool drop_keep_odd(uint32_t w, uint32_t thi) { return
 // LDS tile images (64 rows x 128 B each):
 //   row-read image  : chunk c of row r at c ^ ((r >> 1) & 7)      -> ds_read_b128 fragments (row on the lane)
 //   transpose image : chunk c of row r at c ^ (r & 6)             -> ds_read_b64_tr_b16 fragments (column on the lane)
+//   dual image      : chunk c of row r at c ^ rotl3((r >> 1) & 7) -> BOTH kinds of fragment without bank conflicts: the eight
+//                     row pairs still land on eight different chunk slots (row reads), and the rotation puts the bit that
+//                     separates rows 4 g + {0, 1} from 4 g + {2, 3} above the chunk's low bit, which a transposing read's lane
+//                     pair owns.  One image per tensor instead of two: a wave issues an LDS-DMA instruction only every ~110
+//                     cycles, and the backward kernels staged 6 (dQ) and 8 (dK / dV) per wave and tile.
+__device__ __forceinline__ int dual_swz(int r) {
+  const int x = (r >> 1) & 7;
+  return ((x << 1) & 7) | (x >> 2);
+}
 __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, uint32_t col_byte, long ld_bytes,
-                                         int row0, int nrows_total, bool transpose_image, int wave, int lane) {
+                                         int row0, int nrows_total, int image /* 0 row-read, 1 transpose, 2 dual */, int wave, int lane) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int S = (wave * 2 + j) * 64 + lane;
     const int r = S >> 3, pc = S & 7;
-    const int c = transpose_image ? (pc ^ (r & 6)) : (pc ^ ((r >> 1) & 7));
+    const int c = image == 2 ? (pc ^ dual_swz(r)) : image == 1 ? (pc ^ (r & 6)) : (pc ^ ((r >> 1) & 7));
     const int gr = row0 + r;
     const uint32_t off = gr < nrows_total ? (uint32_t)((long)gr * ld_bytes + col_byte + c * 16) : 0x80000000u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
@@ -114,6 +122,23 @@ __device__ __forceinline__ bf16x8 frag_cols_perm(const char* tile, int ci, int r
   const int r = rbase + 4 * g + q4;
   const int ch = 2 * ci + (p4 >> 1);
   const char* a = tile + r * 128 + ((ch ^ (r & 6)) << 4) + (p4 & 1) * 8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a + 16 * 128));
+  s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// the same two fragments from a dual image
+__device__ __forceinline__ bf16x8 frag_rows_d(const char* tile, int sub, int kk, int lane) {
+  const int r = 16 * sub + (lane & 15);
+  const int c = kk * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ dual_swz(r)) << 4));
+}
+__device__ __forceinline__ bf16x8 frag_cols_perm_d(const char* tile, int ci, int rbase, int lane) {
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int r = rbase + 4 * g + q4;
+  const int ch = 2 * ci + (p4 >> 1);
+  const char* a = tile + r * 128 + ((ch ^ dual_swz(r)) << 4) + (p4 & 1) * 8;  // row + 16: the same swizzle
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a + 16 * 128));
   s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -212,8 +237,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int i = 0; i < 4; ++i) oacc[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (nkt > 0) {
-    dma_tile(rsrc, smem, kcol, ld * 2, 0, F, false, wave, lane);
-    dma_tile(rsrc, smem + TILE_BYTES, vcol, ld * 2, 0, F, true, wave, lane);
+    dma_tile(rsrc, smem, kcol, ld * 2, 0, F, 0, wave, lane);
+    dma_tile(rsrc, smem + TILE_BYTES, vcol, ld * 2, 0, F, 1, wave, lane);
   }
   const int g = lane >> 4;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -221,8 +246,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
     if (kt + 1 < nkt) {
-      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES, kcol, ld * 2, (kt + 1) * KT, F, false, wave, lane);
-      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, vcol, ld * 2, (kt + 1) * KT, F, true, wave, lane);
+      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES, kcol, ld * 2, (kt + 1) * KT, F, 0, wave, lane);
+      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, vcol, ld * 2, (kt + 1) * KT, F, 1, wave, lane);
     }
     const char* kt_lds = smem + cur * 2 * TILE_BYTES;
     const char* vt_lds = kt_lds + TILE_BYTES;
@@ -350,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 //   S^T[key][q], dP^T[key][q] = V dO^T, dS^T = P^T * (dP^T * mask/(1-p) - delta[q]); dQ^T[d][q] += K^T[d][key] dS^T[key][q].
 template <bool DROP, int NQS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K rows | K transpose | V rows)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K dual image | V rows)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const AttnBlock ab = attn_block();
   const int b = ab.b, h = ab.h, q0 = ab.blk * (64 * NQS);
@@ -399,10 +424,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto issue = [&](int kt, int stage) {
-    char* s0 = smem + stage * 3 * TILE_BYTES;
-    dma_tile(rsrc, s0, kcol, ld * 2, kt * KT, F, false, wave, lane);
-    dma_tile(rsrc, s0 + TILE_BYTES, kcol, ld * 2, kt * KT, F, true, wave, lane);
-    dma_tile(rsrc, s0 + 2 * TILE_BYTES, vcol, ld * 2, kt * KT, F, false, wave, lane);
+    char* s0 = smem + stage * 2 * TILE_BYTES;
+    dma_tile(rsrc, s0, kcol, ld * 2, kt * KT, F, 2, wave, lane);
+    dma_tile(rsrc, s0 + TILE_BYTES, vcol, ld * 2, kt * KT, F, 2, wave, lane);
   };
   if (nkt > 0) issue(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -410,9 +434,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     if (kt + 1 < nkt) issue(kt + 1, cur ^ 1);
-    const char* k_rows = smem + cur * 3 * TILE_BYTES;
-    const char* k_tr = k_rows + TILE_BYTES;
-    const char* v_rows = k_rows + 2 * TILE_BYTES;
+    const char* k_rows = smem + cur * 2 * TILE_BYTES;  // one dual image of K serves the row and the transposing reads
+    const char* k_tr = k_rows;
+    const char* v_rows = k_rows + TILE_BYTES;
     const int k0 = kt * KT;
     const bool edge = k0 + KT > kl;  // uniform: only this tile needs the key-length mask
 #pragma unroll
@@ -423,8 +447,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
           const int ks = 2 * t2 + kh;
-          const bf16x8 ka = frag_rows(k_rows, ks, 0, lane), kb = frag_rows(k_rows, ks, 1, lane);
-          const bf16x8 va = frag_rows(v_rows, ks, 0, lane), vb = frag_rows(v_rows, ks, 1, lane);
+          const bf16x8 ka = frag_rows_d(k_rows, ks, 0, lane), kb = frag_rows_d(k_rows, ks, 1, lane);
+          const bf16x8 va = frag_rows_d(v_rows, ks, 0, lane), vb = frag_rows_d(v_rows, ks, 1, lane);
 #pragma unroll
           for (int qs = 0; qs < NQS; ++qs) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
@@ -473,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bf16x8 ka = frag_cols_perm(k_tr, i, 32 * t2, lane);
+        const bf16x8 ka = frag_cols_perm_d(k_tr, i, 32 * t2, lane);
 #pragma unroll
         for (int qs = 0; qs < NQS; ++qs) dq[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb[qs], dq[qs][i], 0, 0, 0);
       }
@@ -498,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 //   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key].
 template <bool DROP, int NKS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q rows|Q tr|dO rows|dO tr), then lse|delta per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q dual image | dO dual image), then lse|delta|seed per stage
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const AttnBlock ab = attn_block();
   const int b = ab.b, h = ab.h, key0 = ab.blk * (64 * NKS);
@@ -511,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
   __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dctx + (long)b * F * H), 0, (int)((long)F * H * 2), 0x00020000);
   const uint32_t qcol = (uint32_t)(h * HD * 2);
   const int g = lane >> 4;
-  float* stat = reinterpret_cast<float*>(smem + 2 * 4 * TILE_BYTES);  // [stage][lse * log2 e KT | delta KT | dropout row seed KT]
+  float* stat = reinterpret_cast<float*>(smem + 2 * 2 * TILE_BYTES);  // [stage][lse * log2 e KT | delta KT | dropout row seed KT]
   int krow[NKS];
   bf16x8 kf[NKS][2], vf[NKS][2];
 #pragma unroll
@@ -545,11 +569,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       dv[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   auto issue = [&](int qt, int stage) {
-    char* s0 = smem + stage * 4 * TILE_BYTES;
-    dma_tile(rs_qkv, s0, qcol, ld * 2, qt * KT, F, false, wave, lane);
-    dma_tile(rs_qkv, s0 + TILE_BYTES, qcol, ld * 2, qt * KT, F, true, wave, lane);
-    dma_tile(rs_do, s0 + 2 * TILE_BYTES, qcol, (long)H * 2, qt * KT, F, false, wave, lane);
-    dma_tile(rs_do, s0 + 3 * TILE_BYTES, qcol, (long)H * 2, qt * KT, F, true, wave, lane);
+    char* s0 = smem + stage * 2 * TILE_BYTES;
+    dma_tile(rs_qkv, s0, qcol, ld * 2, qt * KT, F, 2, wave, lane);
+    dma_tile(rs_do, s0 + TILE_BYTES, qcol, (long)H * 2, qt * KT, F, 2, wave, lane);
     if (threadIdx.x < KT) {
       const int q = qt * KT + threadIdx.x;
       const long o = ((long)b * p.nh + h) * F + min(q, F - 1);
@@ -567,10 +589,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     if (qt + 1 < nqt) issue(qt + 1, cur ^ 1);
-    const char* q_rows = smem + cur * 4 * TILE_BYTES;
-    const char* q_tr = q_rows + TILE_BYTES;
-    const char* do_rows = q_rows + 2 * TILE_BYTES;
-    const char* do_tr = q_rows + 3 * TILE_BYTES;
+    const char* q_rows = smem + cur * 2 * TILE_BYTES;  // dual images: row reads and transposing reads from the same tile
+    const char* q_tr = q_rows;
+    const char* do_rows = q_rows + TILE_BYTES;
+    const char* do_tr = do_rows;
     const float* lse_s = stat + cur * 3 * KT;
     const float* dl_s = lse_s + KT;
     const uint32_t* seed_s = reinterpret_cast<const uint32_t*>(lse_s + 2 * KT);
@@ -582,8 +604,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
           const int qsb = 2 * t2 + qh;
-          const bf16x8 qa = frag_rows(q_rows, qsb, 0, lane), qb = frag_rows(q_rows, qsb, 1, lane);
-          const bf16x8 da = frag_rows(do_rows, qsb, 0, lane), db = frag_rows(do_rows, qsb, 1, lane);
+          const bf16x8 qa = frag_rows_d(q_rows, qsb, 0, lane), qb = frag_rows_d(q_rows, qsb, 1, lane);
+          const bf16x8 da = frag_rows_d(do_rows, qsb, 0, lane), db = frag_rows_d(do_rows, qsb, 1, lane);
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks) {
             // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
@@ -651,8 +673,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bf16x8 doa = frag_cols_perm(do_tr, i, 32 * t2, lane);
-        const bf16x8 qa = frag_cols_perm(q_tr, i, 32 * t2, lane);
+        const bf16x8 doa = frag_cols_perm_d(do_tr, i, 32 * t2, lane);
+        const bf16x8 qa = frag_cols_perm_d(q_tr, i, 32 * t2, lane);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           dv[ks][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa, pdb[ks], dv[ks][i], 0, 0, 0);
@@ -1632,7 +1654,7 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
     return SSAK_OK;
   }
   const int nqs = attn_tile(1), nks = attn_tile(2);
-#define ATT_LAUNCH_DQ(D, N) attn_bwd_dq_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 3 * TILE_BYTES, st>>>(p)
+#define ATT_LAUNCH_DQ(D, N) attn_bwd_dq_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p)
   if (p.thresh16) {
     if (nqs == 1) ATT_LAUNCH_DQ(true, 1); else ATT_LAUNCH_DQ(true, 2);
   } else {
@@ -1640,7 +1662,7 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
   }
 #undef ATT_LAUNCH_DQ
   SSAK_LAUNCH_CHECK();
-  constexpr int dkv_lds = 2 * 4 * TILE_BYTES + 2 * 3 * KT * 4;
+  constexpr int dkv_lds = 2 * 2 * TILE_BYTES + 2 * 3 * KT * 4;
   static bool attr_done = false;
   if (!attr_done) {
     SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
