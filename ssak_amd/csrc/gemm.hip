@@ -931,7 +931,6 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
   int Ms[8], Ns[8];
   long lda[8], ldb[8], ldc[8];
   uint32_t ea[8], eb[8];
-  double flops = 0.0;
   for (int i = 0; i < n; ++i) {
     const ssak_gemm_desc& d = descs[i];
     SSAK_REQUIRE(A[i] && B[i] && C[i], "gemm_grouped: null operand");
@@ -957,7 +956,6 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
     lda[i] = d.lda;
     ldb[i] = d.ldb;
     ldc[i] = d.ldc;
-    flops += 2.0 * d.M * d.N * (double)d.K;
   }
   GemmParams p{};
   p.K = d0.K;
