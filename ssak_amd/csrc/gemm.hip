@@ -344,11 +344,15 @@ struct DmaFrag {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int BKT>
+// NJ (0 = all): column sub-tiles of a wave that are actually multiplied.  The grouped positional convolution has N = 48 per
+// group: with 128 x 64 tiles as 2 x 2 waves a quarter of the MFMAs multiplied padding; as 4 x 1 waves with NJ = 3 every wave
+// skips the fourth (all-padding) sub-tile -- its accumulators stay zero and the bounds-checked epilogue never stores them.
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int BKT, int NJ = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int NJU = NJ ? NJ : NI;
   constexpr int ABYTES = BM * BKT * 2, BBYTES = BN * BKT * 2, STAGE = ABYTES + BBYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -402,15 +406,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const GemmParams p) 
     const char* lb = la + ABYTES;
 #pragma unroll
     for (int kk = 0; kk < BKT / 32; ++kk) {
-      bf16x8 fa[MI], fb[NI];
+      bf16x8 fa[MI], fb[NJU];
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = fra.read(la, i, kk);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[j] = frb.read(lb, j, kk);
+      for (int j = 0; j < NJU; ++j) fb[j] = frb.read(lb, j, kk);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NJU; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   }
@@ -627,10 +631,10 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
 }
 
 bool g_no_big_tile = false;  // development switch (SSAK_GEMM_NO_BIG=1): keep the 128x128 kernels
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NJ = 0>
 int launch(const GemmParams& p, bool dma, hipStream_t st) {
   const size_t lds = dma ? 2 * (size_t)(BM + BN) * 128 : 2 * (size_t)(Tile<BM, A_KM>::BYTES + Tile<BN, B_KM>::BYTES);
-  auto kern = dma ? gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM, 64> : gemm_kernel<BM, BN, WM, WN, A_KM, B_KM>;
+  auto kern = dma ? gemm_dma_kernel<BM, BN, WM, WN, A_KM, B_KM, 64, NJ> : gemm_kernel<BM, BN, WM, WN, A_KM, B_KM>;
   if (lds > 64 * 1024) {
     static bool attr_done[2] = {false, false};  // per instantiation and kernel flavour
     if (!attr_done[dma]) {
@@ -642,8 +646,8 @@ int launch(const GemmParams& p, bool dma, hipStream_t st) {
   static int slots[2] = {-1, -1};
   if (slots[dma] < 0) {
     char nm[112];
-    snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d, %s, %s%s>", dma ? "gemm_dma_kernel" : "gemm_kernel", BM, BN, WM, WN, A_KM ? "true" : "false",
-             B_KM ? "true" : "false", dma ? ", 64" : "");
+    snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d, %s, %s%s%s>", dma ? "gemm_dma_kernel" : "gemm_kernel", BM, BN, WM, WN, A_KM ? "true" : "false",
+             B_KM ? "true" : "false", dma ? ", 64" : "", dma && NJ ? ", 3" : "");
     slots[dma] = ssak_prof_register(nm, SSAK_BOUND_MFMA);
   }
   ProfScope prof_scope(slots[dma], 2.0 * p.M * p.N * (double)p.K * p.nz, st);
@@ -681,12 +685,12 @@ int dispatch_big(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
   return launch_big<true, false>(p, st);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NJ = 0>
 int dispatch_layout(const GemmParams& p, int a_km, int b_km, bool dma, hipStream_t st) {
-  if (!a_km && !b_km) return launch<BM, BN, WM, WN, false, false>(p, dma, st);
-  if (!a_km && b_km) return launch<BM, BN, WM, WN, false, true>(p, dma, st);
-  if (a_km && b_km) return launch<BM, BN, WM, WN, true, true>(p, dma, st);
-  return launch<BM, BN, WM, WN, true, false>(p, dma, st);
+  if (!a_km && !b_km) return launch<BM, BN, WM, WN, false, false, NJ>(p, dma, st);
+  if (!a_km && b_km) return launch<BM, BN, WM, WN, false, true, NJ>(p, dma, st);
+  if (a_km && b_km) return launch<BM, BN, WM, WN, true, true, NJ>(p, dma, st);
+  return launch<BM, BN, WM, WN, true, false, NJ>(p, dma, st);
 }
 
 
@@ -895,7 +899,11 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   } else {
     p.tiles_m = ssak_cdiv(d->M, 128);
     p.tiles_n = ssak_cdiv(d->N, 64);
-    rc = dispatch_layout<128, 64, 2, 2>(p, d->a_kmajor, d->b_kmajor, dma, st);
+    static const bool env_no_n48 = getenv("SSAK_GEMM_NO_N48") != nullptr;  // development switch
+    if (dma && d->N > 32 && d->N <= 48 && !env_no_n48)
+      rc = dispatch_layout<128, 64, 4, 1, 3>(p, d->a_kmajor, d->b_kmajor, dma, st);  // N = 48 (grouped positional conv): no padding MFMAs
+    else
+      rc = dispatch_layout<128, 64, 2, 2>(p, d->a_kmajor, d->b_kmajor, dma, st);
   }
   if (rc != SSAK_OK) return rc;
   if (split > 1) {
