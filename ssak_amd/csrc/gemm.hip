@@ -905,6 +905,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
       // K-contiguous operands: 256-row tiles -- twice the MFMA work per K step behind the same LDS-DMA round trip (this two-stage
       // kernel is latency-bound): 437 -> 378 us per step for the three forward / dX launches.  (K-major operands, the weight
       // gradient: 250 -> 325 us, so they stay on 128 rows.)
+      // (512-row tiles, one workgroup per CU: 576 us)
       p.tiles_m = ssak_cdiv(d->M, 256);
       rc = launch<256, 64, 4, 1, false, false, 3>(p, dma, st);
     } else if (dma && d->N > 32 && d->N <= 48 && !env_no_n48)
