@@ -169,10 +169,11 @@ int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const voi
 int ssak_gemm_f32(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                   const void* aux_in, void* aux_out, void* stream);
 
-/* Grouped form: n <= 8 plain products (no bias / activation / dropout / batches / split-K) that share K, the operand layouts,
- * alpha and the output type run as ONE launch whose tiles are dealt over the whole chip -- the weight gradients
- * dW = dY^T X of one or two encoder layers (loss.backward() of wav2vec_train.py:415), which one at a time are too few tiles
- * to fill the GPU without split-K slabs.  descs / A / B / C are host arrays of length n. */
+/* Grouped form: n <= 48 plain products (no bias / activation / dropout / batches / split-K) that share K, the operand layouts,
+ * alpha and the output type run as ONE persistent launch whose tiles are dealt over the whole chip -- the weight gradients
+ * dW = dY^T X of the encoder layers (loss.backward() of wav2vec_train.py:415), which one at a time are too few tiles to fill
+ * the GPU without split-K slabs: the engine launches two layers at a time (216 tiles, one round; under data parallelism their
+ * gradient ranges become ready early for the all-reduce).  descs / A / B / C are host arrays of length n. */
 int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs /*host*/, int n, const void* const* A, const void* const* B, void* const* C,
                            void* stream);
 

@@ -942,11 +942,11 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
 // together are 216 tiles -- one round of workgroups, every accumulator written once, straight into the gradient buffer.
 extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const void* const* A, const void* const* B, void* const* C,
                                       void* stream) {
-  SSAK_REQUIRE(descs && A && B && C && n >= 1 && n <= 8, "gemm_grouped: need 1..8 problems");
+  SSAK_REQUIRE(descs && A && B && C && n >= 1 && n <= 48, "gemm_grouped: need 1..48 problems");
   const ssak_gemm_desc& d0 = descs[0];
-  int Ms[8], Ns[8];
-  long lda[8], ldb[8], ldc[8];
-  uint32_t ea[8], eb[8];
+  int Ms[48], Ns[48];
+  long lda[48], ldb[48], ldc[48];
+  uint32_t ea[48], eb[48];
   for (int i = 0; i < n; ++i) {
     const ssak_gemm_desc& d = descs[i];
     SSAK_REQUIRE(A[i] && B[i] && C[i], "gemm_grouped: null operand");

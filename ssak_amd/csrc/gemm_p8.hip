@@ -215,15 +215,22 @@ struct P8Problem {
   uint32_t ext_a, ext_b;
   int tile0, tiles_n;  // first tile id of this problem, its tile columns
 };
-struct P8Group {
+// CAP = 48 for the grouped instantiations (twelve encoder layers x 4 weight gradients: on one GPU the whole backward's weight
+// gradients run as ONE multi-round launch, which fills the chip where a pair of layers -- 216 tiles -- leaves 40 CUs idle), 1 for
+// the others (the table travels by value in the kernel arguments).
+constexpr int P8_GROUP_CAP = 48;
+template <int CAP>
+struct P8GroupT {
   int n, total_tiles;
-  P8Problem pr[8];
+  P8Problem pr[CAP];
 };
+typedef P8GroupT<P8_GROUP_CAP> P8Group;
+static_assert(sizeof(GemmParams) + sizeof(P8Group) <= 4096, "kernel arguments are limited to 4 KiB");
 
 // EPI: -1 = every epilogue mode of the general-purpose form; SSAK_EPI_GELU_SAVE_GRAD / SSAK_EPI_MUL_AUX = the feed-forward pair
 // (gemm_common.h: gemm_epilogue_direct), instantiated for the layouts the encoder uses them with.
 template <int MH, bool A_KM, bool B_KM, bool GROUPED = false, int EPI = -1>
-__global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p, const P8Group grp) {
+__global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p, const P8GroupT<GROUPED ? P8_GROUP_CAP : 1> grp) {
   constexpr int BM = 64 * MH, SEGA = 16 * MH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P8_STAMPS
@@ -554,7 +561,7 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
   const long ntiles = (long)p.tiles_m * p.tiles_n * p.nz * p.split_k;
   int n_cu = 0;
   if (int rc = p8_num_cu(&n_cu)) return rc;
-  P8Group none;
+  P8GroupT<1> none;
   none.n = 0;
   none.total_tiles = 0;
   GemmParams q = p;
@@ -642,7 +649,7 @@ int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStrea
   return dispatch_p8<2>(p, a_km, b_km, st);
 }
 
-// Grouped launch of n <= 8 problems sharing K, layouts, alpha and output type (256-row tiles).  `params` carries the shared
+// Grouped launch of n <= 48 problems sharing K, layouts, alpha and output type (256-row tiles).  `params` carries the shared
 // fields (K, alpha, out_f32, accumulate, ...); A/B/C, M/N, leading dimensions and extents come per problem.
 int ssak_gemm_p8_launch_grouped(const void* params, int n, const void* const* A, const void* const* B, void* const* C, const int* M,
                                 const int* N, const long* lda, const long* ldb, const long* ldc, const uint32_t* ext_a,
@@ -667,7 +674,7 @@ int ssak_gemm_p8_launch_grouped(const void* params, int n, const void* const* A,
     q.tiles_n = ssak_cdiv(N[i], 256);
     t0 += ssak_cdiv(M[i], 256) * q.tiles_n;
   }
-  for (int i = n; i < 8; ++i) grp.pr[i] = grp.pr[0];
+  for (int i = n; i < P8_GROUP_CAP; ++i) grp.pr[i] = grp.pr[0];
   grp.total_tiles = t0;
   if (!a_km && !b_km) return launch_p8_grouped<false, false>(p, grp, st);
   if (!a_km && b_km) return launch_p8_grouped<false, true>(p, grp, st);

@@ -24,6 +24,13 @@
 
 namespace {
 
+constexpr int WGRAD_SETS = 12;  // most buffer sets of the queued weight-gradient operands = layers per grouped launch (4 products each: ssak_gemm_bf16_grouped takes 48)
+bool wgrad_all() {
+  static const bool v = getenv("SSAK_WGRAD_ALL") != nullptr;  // development switch: see the workspace plan
+  return v;
+}
+
+
 struct PInfo {
   std::string name;
   std::vector<long> shape;
@@ -60,9 +67,11 @@ struct Plan {
   std::vector<LayerBuf> lb;
   // backward temporaries
   size_t dlog, dA, dB, dY, dC, dI, dqkv, dSb, pgdy, dwf, slab, dln0, scratchH, lnpart, redring, redring_floats;
-  // second set of the buffers the weight-gradient products read (dy of both LayerNorms, dI, dqkv): those products are
-  // queued and launched two layers at a time, so a layer's set must survive the next layer's backward
-  size_t dY1 = 0, dYb[2] = {0, 0}, dIb[2] = {0, 0}, dqkvb[2] = {0, 0}, dY1b[2] = {0, 0};
+  // sets of the buffers the weight-gradient products read (dy of both LayerNorms, dI, dqkv): those products are queued and
+  // launched several layers at a time (two under data parallelism, up to WGRAD_SETS on a single GPU), so a layer's set
+  // must survive the backward of the layers queued after it
+  size_t dY1 = 0, dYb[WGRAD_SETS] = {0}, dIb[WGRAD_SETS] = {0}, dqkvb[WGRAD_SETS] = {0}, dY1b[WGRAD_SETS] = {0};
+  int wgrad_sets = 2;
   // Whisper front end: RS2 rows per utterance after conv2, RS1 = 2*RS2 before it
   int Tin = 0, RS1 = 0, RS2 = 0;
   bool fused_attn = false;
@@ -396,10 +405,16 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.dY1b[0] = p.dY1;
     p.dIb[0] = p.dI;
     p.dqkvb[0] = p.dqkv;
-    p.dYb[1] = cv.take((size_t)M * H * b2);
-    p.dY1b[1] = cv.take((size_t)M * H * b2);
-    p.dIb[1] = cv.take((size_t)M * I * b2);
-    p.dqkvb[1] = cv.take((size_t)M * 3 * H * b2);
+    // two sets (layer pairs) by default; SSAK_WGRAD_ALL=1: up to WGRAD_SETS layers per grouped launch on a single GPU -- measured
+    // SLOWER (eleven layers as one 1 188-tile launch: 2 064 us per step against 2 014 us in pairs, the same 0.46 of the roof per
+    // tile: the better fill of the rounds is lost again to the operand panels of many layers competing for the L2)
+    p.wgrad_sets = wgrad_all() ? std::max(2, std::min(WGRAD_SETS, c.num_layers)) : 2;
+    for (int s2 = 1; s2 < p.wgrad_sets; ++s2) {
+      p.dYb[s2] = cv.take((size_t)M * H * b2);
+      p.dY1b[s2] = cv.take((size_t)M * H * b2);
+      p.dIb[s2] = cv.take((size_t)M * I * b2);
+      p.dqkvb[s2] = cv.take((size_t)M * 3 * H * b2);
+    }
     p.dSb = cv.take(p.fused_attn ? 256 : (size_t)B * nh * p.F * p.Fp * b2);
     p.delta = cv.take((size_t)B * nh * p.F * sizeof(float));
     p.pgdy = cv.take((size_t)G * p.pg_rows * (H / G) * b2);
@@ -510,14 +525,17 @@ struct GemmX : Gemm {
   GemmX(int M, int N, int K) : Gemm(M, N, K, EXACT) {}
 };
 
-// Weight-gradient products are not on the critical path of the backward: they are queued and launched together (one or
-// two layers = up to 8 products) as ONE grouped GEMM that fills a round of workgroups with 256x256 tiles, instead of
-// four launches per layer that each need split-K slabs and a reduction pass (ssak_gemm_bf16_grouped).
+// Weight-gradient products are not on the critical path of the backward: they are queued and launched together as ONE grouped
+// GEMM (ssak_gemm_bf16_grouped) instead of four launches per layer that each need split-K slabs and a reduction pass: two
+// layers at a time (216 tiles of 256 x 256: one round of workgroups; under data parallelism their gradient ranges are announced
+// early for the bucketed all-reduce).  All kept layers in one multi-round launch (SSAK_WGRAD_ALL=1; 1 188 tiles for eleven
+// layers = 4.6 rounds, 93 % of the CU-rounds busy where a pair fills 84 %) was measured slower on one GPU: see the plan.
 struct WgradQueue {
-  ssak_gemm_desc d[8];
-  const void* A[8];
-  const void* B[8];
-  void* C[8];
+  static constexpr int CAP = 4 * WGRAD_SETS;  // four products per encoder layer
+  ssak_gemm_desc d[CAP];
+  const void* A[CAP];
+  const void* B[CAP];
+  void* C[CAP];
   int n = 0, layers = 0, tiles = 0;
   bool f32 = false;
   // gradient ranges to announce once the queued products have been launched, in LAYER ORDER: a data-parallel caller
@@ -1126,9 +1144,13 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   int kept = 0;  // layers that ran so far: selects the buffer set their weight-gradient operands live in
   const int layer_tiles = ssak_cdiv(3 * H, 256) * ssak_cdiv(H, 256) + ssak_cdiv(H, 256) * ssak_cdiv(H, 256) +
                           2 * ssak_cdiv(I, 256) * ssak_cdiv(H, 256);
-  auto flush_wgrads = [&]() -> int {
+  auto flush_reductions = [&]() -> int {
     TRY(k_reduce_flush(sink, st));
     red_used = 0;
+    return SSAK_OK;
+  };
+  auto flush_wgrads = [&]() -> int {
+    TRY(flush_reductions());
     TRY(wq.flush(st, slab, p.slab_bytes));
     for (int i = 0; i < wq.n_ann; ++i) announce(wq.ann_off[i], layer_span);
     wq.n_ann = 0;
@@ -1166,7 +1188,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     TRY(red_get(ffn_part_floats, &ffn_part));
     TRY(red_get((size_t)64 * 3 * H, &qkv_part));
     AT* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
-    const int set = kept & 1;
+    const int set = kept % p.wgrad_sets;
     ++kept;
     AT* dY = BF(p.dYb[set]);     // dy of the feed-forward branch (dropout mask applied): dX and dW operand
     AT* dY1 = BF(p.dY1b[set]);   // dy of the attention branch
@@ -1230,8 +1252,12 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
     wq.ann_off[wq.n_ann++] = L.wqkv;
     ++wq.layers;
-    // launch when a second layer is queued, or when another layer would spill into a second round of workgroups
-    if (wq.layers == 2 || wq.tiles + layer_tiles > 256) TRY(flush_wgrads());
+    // data parallelism (a gradient-ready callback is installed): launch when a second layer is queued, or when another layer
+    // would spill into a second round of workgroups; single GPU: when every buffer set is in use (then at the end of the loop)
+    if ((e->on_ready || p.wgrad_sets == 2) ? (wq.layers == 2 || wq.tiles + layer_tiles > 256) : (wq.layers == p.wgrad_sets))
+      TRY(flush_wgrads());
+    else if (wq.layers > 0 && (wq.layers & 1) == 0)
+      TRY(flush_reductions());  // the deferred second stages of the column reductions still go out every two layers
     if (!stable) {
       // gradient w.r.t. this layer's input = dR1 (residual of r1) + dX
       gA = dR1;
