@@ -482,6 +482,8 @@ def test_gemm_grouped_exact(hip, a_km, b_km):
     g = torch.Generator().manual_seed(11)
     K = 1000
     shapes = [(768, 768), (2304, 768), (300, 520), (256, 256), (768, 3072), (264, 40)]
+    if a_km and b_km:  # the weight-gradient layout also with more than eight products (the table holds 48) and several rounds of tiles
+        shapes = shapes + [(512, 768), (768, 520), (40, 264), (1024, 256), (256, 1024), (776, 8), (3072, 768), (768, 768), (2304, 768)]
     probs, refs = [], []
     for M, N in shapes:
         Mp, Np, Kp = (M + 7) // 8 * 8, (N + 7) // 8 * 8, (K + 7) // 8 * 8
