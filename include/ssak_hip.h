@@ -388,6 +388,17 @@ int ssak_cast_bf16_f32(const void* src_bf16, float* dst, long n, void* stream);
 size_t ssak_colsum_workspace_bytes(int N);
 int ssak_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- debug: dropout bits of one site --------------------------------------------------------------------------------
+ * The engine stores no dropout mask: each site recomputes keep(seed, site, element) in its forward and backward kernels
+ * (transformers draws torch's global generator at modeling_wav2vec2.py:433,458,568,571,596,692,1698; the reference passes the
+ * probabilities at ssak/train/transformers/wav2vec_train.py:313-318).  These two entries write the bits out so that the CPU
+ * restatement oracle/dropout_hash.py -- which feeds the SAME masks to transformers.Wav2Vec2ForCTC for the regularisers-on
+ * goldens -- is pinned bit for bit against the device functions.  keep [n] uint8 over flat element offsets (row-major
+ * [rows, channels] sites); attention: keep [B, nh, F, F] (query-major).  site = the engine's stream id of the dropout site;
+ * *scale_out (host, may be NULL) = the factor kept elements are multiplied by.  Never called on the hot path. */
+int ssak_debug_dropout_mask(uint64_t seed, uint32_t site, float p, long n, uint8_t* keep, float* scale_out /*host*/, void* stream);
+int ssak_debug_attention_dropout_mask(uint64_t seed, uint32_t site, float p, int B, int nh, int F, uint8_t* keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,11 +245,40 @@ def pos_conv_embed(p, cfg: W2V2Config, h: torch.Tensor) -> torch.Tensor:
     return F.gelu(y).transpose(1, 2)
 
 
+class HashDropout:
+    """The engine's counter-hash dropout masks (oracle/dropout_hash.py) for one forward: ``drop(x, p, site)`` replaces
+    ``F.dropout(x, p, training=True)`` with mask(seed, site) * 1 / (1 - p) -- torch's own scale, so that a site whose kernel used
+    another factor shows up.  ``attention=True``: x is [B, nh, F, F] attention probabilities (the per-row hash of attention.hip)."""
+
+    def __init__(self, seed: int):
+        self.seed = int(seed)
+        self.log = []  # (site, shape, p) in call order
+
+    def __call__(self, x: torch.Tensor, p: float, site: int, attention: bool = False) -> torch.Tensor:
+        from . import dropout_hash as DH
+        self.log.append((site, tuple(x.shape), p))
+        if p <= 0:
+            return x
+        if attention:
+            B, nh, Fq, Fk = x.shape
+            keep = DH.attention_keep_mask(self.seed, site, B, nh, Fq, p, Fk)
+        else:
+            keep = DH.keep_mask(self.seed, site, tuple(x.shape), p)
+        return x * (torch.from_numpy(keep).to(x.dtype) / (1.0 - p))
+
+
+def _drop(x, p, train, drop, site, attention=False):
+    """F.dropout with torch's generator (drop is None) or with the engine's hash masks (drop = HashDropout)."""
+    if drop is None or not train:
+        return F.dropout(x, p=p, training=train)
+    return drop(x, p, site, attention)
+
+
 def _ln(p, prefix, x, eps):
     return F.layer_norm(x, (x.shape[-1],), p[prefix + ".weight"], p[prefix + ".bias"], eps=eps)
 
 
-def attention(p, cfg: W2V2Config, prefix: str, h: torch.Tensor, key_mask, train: bool) -> torch.Tensor:
+def attention(p, cfg: W2V2Config, prefix: str, h: torch.Tensor, key_mask, train: bool, drop=None, l: int = 0) -> torch.Tensor:
     """``Wav2Vec2Attention.forward`` + ``eager_attention_forward`` (:438-463,:500-548)."""
     B, T, H = h.shape
     nh = cfg.num_attention_heads
@@ -261,45 +290,46 @@ def attention(p, cfg: W2V2Config, prefix: str, h: torch.Tensor, key_mask, train:
     if key_mask is not None:  # padded KEYS get -inf; padded query rows are left alone (create_bidirectional_mask)
         s = s.masked_fill(~key_mask[:, None, None, :], float("-inf"))
     a = F.softmax(s, dim=-1)
-    a = F.dropout(a, p=cfg.attention_dropout, training=train)
+    a = _drop(a, cfg.attention_dropout, train, drop, 16 + 4 * l, attention=True)
     o = torch.matmul(a, v).transpose(1, 2).reshape(B, T, H)
     return F.linear(o, p[prefix + "out_proj.weight"], p[prefix + "out_proj.bias"])
 
 
-def feed_forward(p, cfg: W2V2Config, prefix: str, h: torch.Tensor, train: bool) -> torch.Tensor:
+def feed_forward(p, cfg: W2V2Config, prefix: str, h: torch.Tensor, train: bool, drop=None, l: int = 0) -> torch.Tensor:
     """``Wav2Vec2FeedForward.forward`` (:565-572)."""
     x = F.gelu(F.linear(h, p[prefix + "intermediate_dense.weight"], p[prefix + "intermediate_dense.bias"]))
-    x = F.dropout(x, p=cfg.activation_dropout, training=train)
+    x = _drop(x, cfg.activation_dropout, train, drop, 16 + 4 * l + 2)
     x = F.linear(x, p[prefix + "output_dense.weight"], p[prefix + "output_dense.bias"])
-    return F.dropout(x, p=cfg.hidden_dropout, training=train)
+    return _drop(x, cfg.hidden_dropout, train, drop, 16 + 4 * l + 3)
 
 
-def encoder_layer(p, cfg: W2V2Config, l: int, h: torch.Tensor, key_mask, train: bool) -> torch.Tensor:
+def encoder_layer(p, cfg: W2V2Config, l: int, h: torch.Tensor, key_mask, train: bool, drop=None) -> torch.Tensor:
     """post-LN ``Wav2Vec2EncoderLayer`` (:591-608) / pre-LN ``...StableLayerNorm`` (:631-654)."""
     pre = f"wav2vec2.encoder.layers.{l}."
     eps = cfg.layer_norm_eps
     if not cfg.do_stable_layer_norm:
-        a = attention(p, cfg, pre + "attention.", h, key_mask, train)
-        h = h + F.dropout(a, p=cfg.hidden_dropout, training=train)
+        a = attention(p, cfg, pre + "attention.", h, key_mask, train, drop, l)
+        h = h + _drop(a, cfg.hidden_dropout, train, drop, 16 + 4 * l + 1)
         h = _ln(p, pre + "layer_norm", h, eps)
-        h = h + feed_forward(p, cfg, pre + "feed_forward.", h, train)
+        h = h + feed_forward(p, cfg, pre + "feed_forward.", h, train, drop, l)
         return _ln(p, pre + "final_layer_norm", h, eps)
-    a = attention(p, cfg, pre + "attention.", _ln(p, pre + "layer_norm", h, eps), key_mask, train)
-    h = h + F.dropout(a, p=cfg.hidden_dropout, training=train)
-    return h + feed_forward(p, cfg, pre + "feed_forward.", _ln(p, pre + "final_layer_norm", h, eps), train)
+    a = attention(p, cfg, pre + "attention.", _ln(p, pre + "layer_norm", h, eps), key_mask, train, drop, l)
+    h = h + _drop(a, cfg.hidden_dropout, train, drop, 16 + 4 * l + 1)
+    return h + feed_forward(p, cfg, pre + "feed_forward.", _ln(p, pre + "final_layer_norm", h, eps), train, drop, l)
 
 
 def forward(p: Dict[str, torch.Tensor], cfg: W2V2Config, input_values: torch.Tensor,
             lengths=None, labels: Optional[torch.Tensor] = None, train: bool = False,
             mask_time_indices: Optional[torch.Tensor] = None, layer_keep=None, stages: Optional[dict] = None,
-            gradient_checkpointing: bool = False):
+            gradient_checkpointing: bool = False, drop: Optional[HashDropout] = None):
     """``Wav2Vec2ForCTC.forward`` (:1667-1742) through ``Wav2Vec2Model.forward`` (:1319-1380) and
     ``Wav2Vec2Encoder.forward`` (:667-726).
 
     ``lengths`` (samples per utterance) stands for ``attention_mask`` (None = no mask, the
     group-norm/base convention).  ``mask_time_indices`` [B,F] bool is the
     SpecAugment mask (``_mask_hidden_states`` :1272-1316) supplied by the caller; ``layer_keep``
-    is the per-layer LayerDrop decision (:701-712).  Returns (loss | None, logits[B,F,V])."""
+    is the per-layer LayerDrop decision (:701-712); ``drop`` (with ``train=True``) replaces torch's dropout generator
+    by the engine's counter-hash masks (site ids of w2v2_engine.hip:127-131).  Returns (loss | None, logits[B,F,V])."""
     B, T = input_values.shape
     eps = cfg.layer_norm_eps
     feats = feature_encoder(p, cfg, input_values, stages).transpose(1, 2)  # [B,F,C]
@@ -311,7 +341,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: W2V2Config, input_values: torch.Ten
     nf = _ln(p, "wav2vec2.feature_projection.layer_norm", feats, eps)  # :429-434
     h = F.linear(nf, p["wav2vec2.feature_projection.projection.weight"],
                  p["wav2vec2.feature_projection.projection.bias"])
-    h = F.dropout(h, p=cfg.feat_proj_dropout, training=train)
+    h = _drop(h, cfg.feat_proj_dropout, train, drop, 1)
     if stages is not None:
         stages["feat_proj"] = h
     if mask_time_indices is not None:
@@ -323,7 +353,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: W2V2Config, input_values: torch.Ten
         stages["pos_conv_added"] = h
     if not cfg.do_stable_layer_norm:
         h = _ln(p, "wav2vec2.encoder.layer_norm", h, eps)
-    h = F.dropout(h, p=cfg.hidden_dropout, training=train)
+    h = _drop(h, cfg.hidden_dropout, train, drop, 2)
     if stages is not None:
         stages["encoder_in"] = h
     for l in range(cfg.num_hidden_layers):
@@ -333,17 +363,17 @@ def forward(p: Dict[str, torch.Tensor], cfg: W2V2Config, input_values: torch.Ten
             # model.gradient_checkpointing_enable() of the train script (wav2vec_train.py:329): each encoder layer's
             # activations are recomputed in the backward (modeling_wav2vec2.py: GradientCheckpointingLayer)
             from torch.utils.checkpoint import checkpoint
-            h = checkpoint(lambda t, l=l: encoder_layer(p, cfg, l, t, key_mask, train), h, use_reentrant=False,
+            h = checkpoint(lambda t, l=l: encoder_layer(p, cfg, l, t, key_mask, train, drop), h, use_reentrant=False,
                            preserve_rng_state=train)
         else:
-            h = encoder_layer(p, cfg, l, h, key_mask, train)
+            h = encoder_layer(p, cfg, l, h, key_mask, train, drop)
         if stages is not None:
             stages[f"layer{l}"] = h
     if cfg.do_stable_layer_norm:
         h = _ln(p, "wav2vec2.encoder.layer_norm", h, eps)
     if stages is not None:
         stages["last_hidden"] = h  # Wav2Vec2Model(...)[0]: what the SpeechBrain recipe's wav2vec2 module returns
-    h = F.dropout(h, p=cfg.final_dropout, training=train)
+    h = _drop(h, cfg.final_dropout, train, drop, 3)
     logits = F.linear(h, p["lm_head.weight"], p["lm_head.bias"])
     loss = None
     if labels is not None:

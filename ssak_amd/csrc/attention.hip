@@ -69,15 +69,8 @@ __device__ __forceinline__ int opaque_s(int v) {
 // kernel; the 32-bit word of key pair kp of that row is one multiply-xorshift round of (row seed + kp * golden ratio):
 // low 16 bits -> even key, high 16 bits -> odd key, keep iff the field >= thresh16.  8 VALU slots per word instead of the
 // 14 of a full hash per pair; neighbouring keys / rows / pairs measured uncorrelated (|rho| < 2e-3 on 2M samples).
-constexpr uint32_t DROP_PHI = 0x9E3779B9u;
 __device__ __forceinline__ uint32_t drop_rowseed(const AttnParams& p, int b, int h, int q) {
-  return hash_u32(p.seed, p.stream, (uint64_t)((uint32_t)(b * p.nh + h) * (uint32_t)p.F + (uint32_t)min(q, p.F - 1)));
-}
-__device__ __forceinline__ uint32_t drop_word(uint32_t x /* row seed + kp * DROP_PHI */) {
-  x ^= x >> 15;
-  x *= 0x2C1B3C6Du;
-  x ^= x >> 12;
-  return x;
+  return attn_drop_rowseed(p.seed, p.stream, (uint32_t)(b * p.nh + h) * (uint32_t)p.F + (uint32_t)min(q, p.F - 1));
 }
 // keep tests against thi = thresh16 << 16 (no field extraction: the odd key's field is the word's top half)
 __device__ __forceinline__ bool drop_keep_even(uint32_t w, uint32_t thi) { return (w << 16) >= thi; }

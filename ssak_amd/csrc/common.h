@@ -271,4 +271,21 @@ __device__ __forceinline__ bool keep_bit(uint64_t seed, uint32_t stream, uint64_
 __device__ __forceinline__ uint32_t hash_pair16(uint64_t seed, uint32_t stream, uint64_t idx_even) {
   return hash_u32(seed, stream, idx_even >> 1);
 }
+// Attention-probability dropout (fused kernels in attention.hip AND the unfused softmax kernels in norm_act.hip draw the same
+// bits): every (utterance, head, query) row has a seed = hash(seed, stream, row index); the 32-bit word of key pair kp of that
+// row is one multiply-xorshift round of (row seed + kp * golden ratio): low 16 bits -> even key, high 16 bits -> odd key.
+constexpr uint32_t DROP_PHI = 0x9E3779B9u;
+__device__ __forceinline__ uint32_t attn_drop_rowseed(uint64_t seed, uint32_t stream, uint32_t row /* (b * nh + h) * F + q */) {
+  return hash_u32(seed, stream, (uint64_t)row);
+}
+__device__ __forceinline__ uint32_t drop_word(uint32_t x /* row seed + kp * DROP_PHI */) {
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  return x;
+}
+__device__ __forceinline__ bool attn_keep_bit(uint32_t rowseed, uint32_t key, uint32_t thresh16) {
+  const uint32_t w = drop_word(rowseed + (key >> 1) * DROP_PHI);
+  return ((key & 1) ? (w >> 16) : (w & 0xffffu)) >= thresh16;
+}
 #endif

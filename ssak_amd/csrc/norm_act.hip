@@ -418,8 +418,10 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxP
       for (int k = 0; k < 8; ++k) pr[k] = v[i][k] * inv;
       st8<T>(p.P + o, f_to_chunk8<T>(pr));
       if (p.Pd) {
+        // the fused attention kernels' bits (common.h attn_keep_bit): row = (b * nh + h) * F + q, key = column
+        const uint32_t rs = attn_drop_rowseed(p.seed, p.stream, (uint32_t)row);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pr[k] = (!p.thresh || keep_bit(p.seed, p.stream, o + k, p.thresh)) ? pr[k] * p.scale : 0.f;
+        for (int k = 0; k < 8; ++k) pr[k] = (!p.thresh || attn_keep_bit(rs, (uint32_t)(ch * 8 + k), p.thresh)) ? pr[k] * p.scale : 0.f;
         st8<T>(p.Pd + o, f_to_chunk8<T>(pr));
       }
     }
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
   const int nch = p.ld >> 3;
   float pr[NCH][8], dp[NCH][8];
   float dot = 0.f;
+  const uint32_t rs = attn_drop_rowseed(p.seed, p.stream, (uint32_t)row);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
       for (int k = 0; k < 8; ++k) {
         const bool in = ch * 8 + k < p.cols;
         pr[i][k] = in ? pr[i][k] : 0.f;
-        dp[i][k] = (in && (!p.thresh || keep_bit(p.seed, p.stream, o + k, p.thresh))) ? g[k] * p.scale : 0.f;
+        dp[i][k] = (in && (!p.thresh || attn_keep_bit(rs, (uint32_t)(ch * 8 + k), p.thresh))) ? g[k] * p.scale : 0.f;
         dot += pr[i][k] * dp[i][k];
       }
     }
@@ -599,6 +602,12 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
 // 16-bit dropout threshold and the scale of the probability it realises
 uint32_t thresh_of(float p) { return p <= 0.f ? 0u : (uint32_t)fminf(65535.f, roundf(p * 65536.f)); }
 float scale_of(float p) { return p <= 0.f ? 1.f : 1.f / (1.f - (float)thresh_of(p) / 65536.f); }
+// the sites of one launch share the step's seed; take it from whichever site is active (round 3: it used to be read from the
+// pre-dropout site alone, so a launch with only a post- or sum-dropout -- the encoder-input site -- ran on seed 0: the same
+// mask every step.  Found by the regularisers-on goldens, tests/test_gpu_dropout.py)
+uint64_t seed_of(const DropSpec& pre, const DropSpec& post, const DropSpec& mid) {
+  return pre.p > 0.f ? pre.seed : post.p > 0.f ? post.seed : mid.seed;
+}
 
 }  // namespace
 
@@ -609,7 +618,7 @@ int k_layernorm_fwd_t(const T* y, const T* res, const float* gamma, const float*
                       float* mean, float* rstd, int M, int C, float eps, const DropSpec& pre, const DropSpec& post,
                       hipStream_t st, const DropSpec& mid, bool post_gelu) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
-  LnFwdParams<T> p{y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, pre.seed,
+  LnFwdParams<T> p{y, res, gamma, beta, r_out, out, mean, rstd, M, C, eps, seed_of(pre, post, mid),
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
                 scale_of(pre.p), scale_of(post.p),
                 mid.stream, thresh_of(mid.p), scale_of(mid.p), post_gelu ? 1 : 0};
@@ -633,7 +642,7 @@ int k_layernorm_bwd_t(const T* g1, const T* g2, const T* r, const float* mean, c
                       const DropSpec& mid, float* dy_colsum, const float* post_gelu_beta) {
   SSAK_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= 1536, "layernorm_bwd: C=%d must be a multiple of 8 and <= 1536", C);
   SSAK_REQUIRE(!dy_colsum || dy, "layernorm_bwd: the dy column sum needs the dy output");
-  LnBwdParams<T> p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, post_gelu_beta, M, C, pre.seed,
+  LnBwdParams<T> p{g1, g2, r, mean, rstd, gamma, g_res, dr, dy, dgamma, dbeta, partial, dy_colsum, post_gelu_beta, M, C, seed_of(pre, post, mid),
                 pre.stream, thresh_of(pre.p), post.stream, thresh_of(post.p),
                 scale_of(pre.p), scale_of(post.p), 1,
                 mid.stream, thresh_of(mid.p), scale_of(mid.p)};
@@ -827,4 +836,33 @@ int k_layernorm_bwd(const bf16* g1, const bf16* g2, const bf16* r, const float* 
 int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, float* scratch, size_t scratch_floats,
              const uint8_t* rowmask, const int32_t* flens, int F) {
   return k_colsum_t<bf16>(X, ld, M, N, out, st, scratch, scratch_floats, rowmask, flens, F);
+}
+
+// ---- debug: the dropout bits of one site, written out (tests/test_gpu_dropout.py pins oracle/dropout_hash.py against them).
+// The product kernels inline the same device functions (common.h keep_bit / attn_keep_bit); nothing on the hot path calls these.
+__global__ void debug_dropout_mask_kernel(uint64_t seed, uint32_t stream, uint32_t thresh, long n, uint8_t* keep) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keep[i] = (!thresh || keep_bit(seed, stream, (uint64_t)i, thresh)) ? 1 : 0;
+}
+__global__ void debug_attention_dropout_mask_kernel(uint64_t seed, uint32_t stream, uint32_t thresh, long rows, int Fk, uint8_t* keep) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Fk) return;
+  const uint32_t row = (uint32_t)(i / Fk), key = (uint32_t)(i % Fk);
+  keep[i] = (!thresh || attn_keep_bit(attn_drop_rowseed(seed, stream, row), key, thresh)) ? 1 : 0;
+}
+extern "C" int ssak_debug_dropout_mask(uint64_t seed, uint32_t site, float p, long n, uint8_t* keep, float* scale_out /*host*/,
+                                       void* stream) {
+  SSAK_REQUIRE(keep && n > 0, "debug_dropout_mask: bad arguments");
+  debug_dropout_mask_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(seed, site, thresh_of(p), n, keep);
+  SSAK_LAUNCH_CHECK();
+  if (scale_out) *scale_out = scale_of(p);
+  return SSAK_OK;
+}
+extern "C" int ssak_debug_attention_dropout_mask(uint64_t seed, uint32_t site, float p, int B, int nh, int F, uint8_t* keep,
+                                                 void* stream) {
+  SSAK_REQUIRE(keep && B > 0 && nh > 0 && F > 0, "debug_attention_dropout_mask: bad arguments");
+  const long rows = (long)B * nh * F, n = rows * F;
+  debug_attention_dropout_mask_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(seed, site, thresh_of(p), rows, F, keep);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
 }

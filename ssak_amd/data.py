@@ -42,15 +42,19 @@ def _wavscp_audio_path(entry: str) -> str:
 
 
 def parse_kaldi_wavscp(path: str) -> Dict[str, str]:
-    """wav.scp -> {recording id: audio path}, environment variables expanded (semantics of ssak/utils/kaldi.py:8-37; pinned by
-    the reference's own test folders, tests/golden/host_strings.json)."""
+    """wav.scp -> {recording id: audio path}, environment variables expanded (semantics of ssak/utils/kaldi.py:8-37: fields
+    are separated by ANY whitespace, tabs included; a line with a quote takes what stands between its first two quotes;
+    pinned by the reference's own test folders, tests/golden/host_strings.json)."""
     table: Dict[str, str] = {}
     with open(path) as f:
         for raw in f:
-            rec_id, _, entry = raw.strip().partition(" ")
-            if not rec_id:
+            parts = raw.split(None, 1)
+            if not parts:
                 continue
-            audio = _wavscp_audio_path(entry.strip()) if "'" not in raw else _QUOTED.search(raw).group(1)
+            rec_id, entry = parts[0], (parts[1].strip() if len(parts) > 1 else "")
+            if not entry:
+                raise RuntimeError(f"wav.scp line without an audio entry: {raw.strip()!r} in {path}")
+            audio = _wavscp_audio_path(entry)
             table[rec_id] = os.path.expandvars(audio) if "$" in audio else audio
     return table
 

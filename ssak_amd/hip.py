@@ -115,6 +115,8 @@ def _load():
         "ssak_cast_bf16_f32": (i32, [vp, vp, C.c_long, vp]),
         "ssak_colsum_workspace_bytes": (sz, [i32]),
         "ssak_colsum_bf16": (i32, [vp, C.c_long, i32, i32, vp, vp, sz, vp]),
+        "ssak_debug_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, C.c_long, vp, C.POINTER(f32), vp]),
+        "ssak_debug_attention_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, i32, i32, i32, vp, vp]),
     }
     ab_override = bool(os.environ.get("SSAK_HIP_LIB"))  # an older build named explicitly for a same-box A/B (tools/ab.sh)
     for name, (res, args) in sig.items():

@@ -235,10 +235,10 @@ class Wav2Vec2ForCTC:
         return self._ws
 
     def __call__(self, input_values, attention_mask=None, labels=None, mask_time_indices=None, layer_keep=None,
-                 lengths=None):
-        return self.forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths)
+                 lengths=None, dropout_seed=None):
+        return self.forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths, dropout_seed)
 
-    def _prelude(self, input_values, attention_mask, mask_time_indices, layer_keep, lengths, training):
+    def _prelude(self, input_values, attention_mask, mask_time_indices, layer_keep, lengths, training, dropout_seed=None):
         """Everything before the engine call: device copies, workspace, the host-drawn SpecAugment spans / LayerDrop
         decisions and the step's dropout seed."""
         cfg = self.config
@@ -284,11 +284,15 @@ class Wav2Vec2ForCTC:
             self.train_forwards += 1
             self.kept_layers += cfg.num_hidden_layers if layer_keep is None else int(sum(bool(k) for k in layer_keep))
         self._step_seed = (int(self._step_seed) * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        # like the SpecAugment mask and the LayerDrop decisions, the step's dropout seed can be supplied by the caller
+        # (regularisers-on parity runs: oracle/dropout_hash.py turns it into the masks transformers is fed)
+        self._used_seed = int(self._step_seed) if dropout_seed is None else int(dropout_seed) % (1 << 64)
         flens = torch.empty(B, dtype=torch.int32, device=self.device) if lens_dev is not None else None
         return x, B, T, F, lens_dev, ws, mask_dev, keep_arr, flens
 
     def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                labels: Optional[torch.Tensor] = None, mask_time_indices=None, layer_keep=None, lengths=None):
+                labels: Optional[torch.Tensor] = None, mask_time_indices=None, layer_keep=None, lengths=None,
+                dropout_seed: Optional[int] = None):
         cfg = self.config
         training = self.training
         if labels is not None:
@@ -299,12 +303,12 @@ class Wav2Vec2ForCTC:
             if not labels.is_cuda and labels.numel() and int(labels.max()) >= cfg.vocab_size:
                 raise ValueError(f"Label values must be <= vocab_size: {cfg.vocab_size}")
         x, B, T, F, lens_dev, ws, mask_dev, keep_arr, flens = self._prelude(input_values, attention_mask, mask_time_indices,
-                                                                            layer_keep, lengths, training)
+                                                                            layer_keep, lengths, training, dropout_seed)
         Vp = self._c.vocab_size
         logits = torch.empty((B, F, Vp), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             hip.check(hip.lib.ssak_w2v2_forward(self._h, hip.ptr(x), hip.ptr(lens_dev), B, T, hip.ptr(mask_dev), keep_arr,
-                                                C.c_uint64(int(self._step_seed)), int(training), hip.ptr(logits),
+                                                C.c_uint64(self._used_seed), int(training), hip.ptr(logits),
                                                 hip.ptr(flens), hip.ptr(ws), ws.numel(), hip.stream()))
             loss = nll = dlogits = None
             if labels is not None:
@@ -326,7 +330,7 @@ class Wav2Vec2ForCTC:
         hidden = torch.empty((B, F, self.config.hidden_size), dtype=torch.bfloat16, device=self.device)
         with torch.cuda.device(self.device):
             hip.check(hip.lib.ssak_w2v2_forward_hidden(self._h, hip.ptr(x), hip.ptr(lens_dev), B, T, hip.ptr(mask_dev), keep_arr,
-                                                       C.c_uint64(int(self._step_seed)), int(training), hip.ptr(hidden),
+                                                       C.c_uint64(self._used_seed), int(training), hip.ptr(hidden),
                                                        hip.ptr(flens), hip.ptr(ws), ws.numel(), hip.stream()))
         self._last = ("hidden", mask_dev, lens_dev, x) if training else None
         return hidden, flens

@@ -44,6 +44,12 @@ def test_wavscp_forms(kaldi):
         D.parse_kaldi_wavscp(str(kaldi / "bad.scp"))
     (kaldi / "flac.scp").write_text("x flac -c -d -s -f /tmp/foo.flac |\n")
     assert D.parse_kaldi_wavscp(str(kaldi / "flac.scp"))["x"] == "/tmp/foo.flac"
+    # any whitespace separates the fields, as line.split() does in ssak/utils/kaldi.py:13 (tab-separated wav.scp files exist)
+    (kaldi / "tabs.scp").write_text("utt1\t/data/a.wav\nutt2\tsox /d/a.wav -t wav - |\nutt3   /data/c.wav  \n\nutt4 \t sox\t'/d/x y.wav' -t wav - |\n")
+    assert D.parse_kaldi_wavscp(str(kaldi / "tabs.scp")) == {"utt1": "/data/a.wav", "utt2": "/d/a.wav", "utt3": "/data/c.wav", "utt4": "/d/x y.wav"}
+    (kaldi / "empty.scp").write_text("utt1\n")
+    with pytest.raises(RuntimeError):
+        D.parse_kaldi_wavscp(str(kaldi / "empty.scp"))
 
 
 def test_kaldi_folder_semantics(kaldi):
