@@ -50,8 +50,8 @@ class _EngineStep(torch.autograd.Function):
     of the flat parameter (autograd then owns ``params.grad``: accumulation over several backward calls adds up as usual)."""
 
     @staticmethod
-    def forward(ctx, params, model, input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths):
-        out = Wav2Vec2ForCTC.forward(model, input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths)
+    def forward(ctx, params, model, input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths, dropout_seed=None):
+        out = Wav2Vec2ForCTC.forward(model, input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths, dropout_seed)
         ctx.model = model
         ctx.mark_non_differentiable(out.logits)
         model._torch_out = out
@@ -62,7 +62,7 @@ class _EngineStep(torch.autograd.Function):
         m = ctx.model
         m.backward(grad_scale=1.0)
         g = m.grads * g_loss  # a fresh tensor: the engine's buffer is overwritten by the next backward
-        return g, None, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None, None
 
 
 class TorchWav2Vec2ForCTC(Wav2Vec2ForCTC):
@@ -88,15 +88,16 @@ class TorchWav2Vec2ForCTC(Wav2Vec2ForCTC):
         self._synced_version = self.params._version
         return r
 
-    def forward(self, input_values, attention_mask=None, labels=None, mask_time_indices=None, layer_keep=None, lengths=None):
+    def forward(self, input_values, attention_mask=None, labels=None, mask_time_indices=None, layer_keep=None, lengths=None,
+                dropout_seed=None):
         if self.params._version != self._synced_version:  # an optimizer (or the caller) wrote the master weights
             self.sync_weights(full=True)
             self._synced_version = self.params._version
         if labels is None or not (self.training and torch.is_grad_enabled()):
             with torch.no_grad():
-                return super().forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths)
+                return super().forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths, dropout_seed)
         loss, logits = _EngineStep.apply(self.params, self, input_values, attention_mask, labels, mask_time_indices, layer_keep,
-                                         lengths)
+                                         lengths, dropout_seed)
         out = self._torch_out
         self._torch_out = None
         return CTCOutput(loss, out.logits, out.nll, out.frame_lens)

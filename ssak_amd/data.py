@@ -306,9 +306,14 @@ def length_grouped_batches(lengths: Sequence[float], batch_size: int, rng: np.ra
 
 def shard_batch(indices: Sequence[int], rank: int, world: int) -> List[int]:
     """Contiguous shard of a (length-sorted) global batch for one data-parallel rank
-    (``per_device_train_batch_size = batch_size // num_devices``, wav2vec_train.py:349,356)."""
-    per = len(indices) // world
-    return list(indices[rank * per:(rank + 1) * per])
+    (``per_device_train_batch_size = batch_size // num_devices``, wav2vec_train.py:349,356).  Nothing is dropped: HF's default
+    ``dataloader_drop_last=False`` (docker/transformers_modified/trainer.py:834) trains on the short last batch of an epoch,
+    so when the batch does not divide by the world size the first ``len % world`` ranks take one utterance more and the
+    trainer weights each rank's gradient by its utterance count; a rank may get an empty shard."""
+    n = len(indices)
+    base, extra = divmod(n, world)
+    start = rank * base + min(rank, extra)
+    return list(indices[start:start + base + (1 if rank < extra else 0)])
 
 
 def to_audio_batches(inputs, batch_size: int = 1, sort_by_len: bool = False, output_ids: bool = False,

@@ -117,6 +117,14 @@ class Wav2Vec2ForCTC:
             hip.check(n)
         return [(off[i], cnt[i]) for i in range(n)]
 
+    def announced_grad_ranges(self):
+        """The (offset, count) sequence this model's backward announces (its own engine configuration, Whisper included)."""
+        off, cnt = (C.c_long * 128)(), (C.c_long * 128)()
+        n = hip.lib.ssak_w2v2_grad_ranges(C.byref(self._c), off, cnt, 128)
+        if n < 0:
+            hip.check(n)
+        return [(off[i], cnt[i]) for i in range(n)]
+
     def _finish_init(self, c, seed):
         config = self.config
         self._seed = seed

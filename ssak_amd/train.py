@@ -3,6 +3,11 @@ HIP kernels.  Same positional arguments and flags (wav2vec_train.py:144-175); HF
 ``ssak_amd.trainer`` (one process per GPU; launch with ``python -m torch.distributed.run --nproc-per-node N
 -m ssak_amd.train ...`` for data parallelism over RCCL).  Output folder naming follows :210-243; evaluation
 computes eval_loss and WER with greedy decoding every ``--eval_steps`` and writes ``trainer_state.json``.
+
+What decides the output model, as in the reference (wav2vec_train.py:368-372,392,419-420): ``metric_for_best_model="wer"``
+(lower is better) is tracked across evaluations, ``EarlyStoppingCallback(early_stopping_patience=15)`` ends the run after 15
+evaluations without improvement, ``save_total_limit=2`` keeps the best and the newest checkpoint, and
+``load_best_model_at_end`` reloads the best checkpoint's weights before ``final/`` is written.
 """
 from __future__ import annotations
 
@@ -38,6 +43,48 @@ def word_error_rate(refs, hyps) -> float:
         errs += d[len(h)]
         tot += len(r)
     return errs / max(tot, 1)
+
+
+EARLY_STOPPING_PATIENCE = 15  # transformers.EarlyStoppingCallback(early_stopping_patience=15), wav2vec_train.py:392
+
+
+class BestModelTracker:
+    """``metric_for_best_model="wer"``, ``greater_is_better=False``, ``load_best_model_at_end=True`` plus
+    ``EarlyStoppingCallback(patience)`` as HF Trainer sequences them after every evaluation
+    (docker/transformers_modified/trainer.py:2224-2238 and transformers/trainer_callback.py ``check_metric_value``):
+    the callback compares the new WER with the best SO FAR (strictly lower resets its counter, anything else -- a tie
+    included -- counts as no improvement), THEN the checkpoint is saved and the best metric / checkpoint are updated
+    (strictly lower, or nothing recorded yet)."""
+
+    def __init__(self, state: dict, patience: int | None = None):
+        self.state, self.patience = state, (EARLY_STOPPING_PATIENCE if patience is None else patience)
+        state.setdefault("best_metric", None)
+        state.setdefault("best_model_checkpoint", None)
+        state.setdefault("early_stopping_patience_counter", 0)
+
+    def after_evaluation(self, wer: float, checkpoint_dir: str) -> bool:
+        """Record one evaluation whose checkpoint is ``checkpoint_dir``; True = stop training."""
+        st = self.state
+        best = st["best_metric"]
+        if best is None or wer < best:
+            st["early_stopping_patience_counter"] = 0
+        else:
+            st["early_stopping_patience_counter"] += 1
+        if best is None or st["best_model_checkpoint"] is None or wer < best:
+            st["best_metric"], st["best_model_checkpoint"] = wer, checkpoint_dir
+        return st["early_stopping_patience_counter"] >= self.patience
+
+
+def rotate_checkpoints(out_dir: str, best: str | None, limit: int = 2):
+    """``save_total_limit=2`` (wav2vec_train.py:370) with HF's ordering (trainer.py:2735-2754): oldest first, but the best
+    checkpoint is moved up to the second-newest place, so the best and the newest survive."""
+    cks = sorted_checkpoints(out_dir)
+    if best is not None and os.path.abspath(best) in [os.path.abspath(c) for c in cks]:
+        i = [os.path.abspath(c) for c in cks].index(os.path.abspath(best))
+        for j in range(i, len(cks) - 2):
+            cks[j], cks[j + 1] = cks[j + 1], cks[j]
+    for old in cks[:max(0, len(cks) - limit)]:
+        shutil.rmtree(old, ignore_errors=True)
 
 
 def build_parser():
@@ -109,11 +156,17 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(1, torch.cuda.device_count())  # (rehearsals put several ranks on one card)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        # RCCL over xGMI; SSAK_DIST_BACKEND=gloo lets a multi-rank run be rehearsed on a single card (tests)
+        backend = os.environ.get("SSAK_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     args.online = args.online or args.data_augment  # wav2vec_train.py:188
     train_u = load_kaldi(args.train, args.min_duration, args.max_duration)
     valid_u = load_kaldi(args.valid, args.min_duration, args.max_duration)
@@ -147,12 +200,13 @@ def main(argv=None):
         tw, tl = prepare(train_u, tok)
         train_len = [len(w) for w in tw]
     vw, vl = prepare(valid_u, tok)
-    steps_per_epoch = max(1, len(tl) // args.batch_size)
+    steps_per_epoch = max(1, -(-len(tl) // args.batch_size))  # dataloader_drop_last=False: the short last batch is a step
     total = round(args.num_epochs * len(tl) / args.batch_size)
     opt = AdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay, warmup_steps=500, total_steps=max(total, 1))
     trainer = Trainer(model, opt)
     trainer.broadcast_parameters()
     state = {"log_history": [], "global_step": 0, "max_steps": total}
+    tracker = BestModelTracker(state)
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, "README.txt"), "a") as readme:  # wav2vec_train.py:247-254
@@ -184,57 +238,99 @@ def main(argv=None):
         opt.load_state_dict(torch.load(os.path.join(last, "optimizer.pt")))
         with open(os.path.join(last, "trainer_state.json")) as f:
             state = json.load(f)
-        with open(os.path.join(last, "rng.json")) as f:  # plain JSON, no pickle
+        tracker = BestModelTracker(state)
+        # every rank restores ITS OWN regulariser streams (the trainer seeds ranks differently: seed + rank); a checkpoint of
+        # an older build or of a run with fewer ranks only has rank 0's file
+        rng_file = os.path.join(last, f"rng-rank{rank}.json")
+        if not os.path.exists(rng_file):
+            rng_file = os.path.join(last, "rng.json")
+        with open(rng_file) as f:  # plain JSON, no pickle
             extra = json.load(f)
         model._step_seed = int(extra["step_seed"])
         kind, keys, pos, has_gauss, cached = extra["host_rng"]
         model._host_rng.set_state((kind, np.asarray(keys, dtype=np.uint32), int(pos), int(has_gauss), float(cached)))
+        best = state.get("best_model_checkpoint")
+        if best is not None and not os.path.isdir(best):  # the output folder was moved: checkpoints are found by name
+            state["best_model_checkpoint"] = os.path.join(out_dir, os.path.basename(best))
         resume_step = int(state["global_step"])
         if rank == 0:
             print(f"resuming from {last} (step {resume_step} of {total})")
     while step < total:
-        plan = [shard_batch(idx, rank, world) if world > 1 else idx for idx in length_grouped_batches(train_len, args.batch_size, rng)]
-        plan = [m for m in plan if m][:total - step]
+        # (global batch, this rank's contiguous shard of it): shards may differ by one utterance on the short last batch and
+        # may be empty; the trainer weights by utterance count
+        plan = [(idx, shard_batch(idx, rank, world) if world > 1 else idx) for idx in length_grouped_batches(train_len, args.batch_size, rng)]
+        plan = [gm for gm in plan if gm[0]][:total - step]
         if not plan:
-            raise RuntimeError("empty batch plan: fewer training utterances than data-parallel ranks per batch")
+            raise RuntimeError("empty batch plan: no training utterances")
         if step < resume_step:  # batches the checkpointed run already consumed
             skip = min(len(plan), resume_step - step)
             plan, step = plan[skip:], step + skip
             if not plan:
                 continue
         if args.online:
-            feed = BatchPrefetcher(ingest, [[(train_u[i].path, train_u[i].start or None, train_u[i].end or None) for i in m] for m in plan])
+            feed = BatchPrefetcher(ingest, [[(train_u[i].path, train_u[i].start or None, train_u[i].end or None) for i in m] for _, m in plan if m])
+            feed = iter(feed)
         else:
-            feed = (pad_waves([tw[i] for i in m]) for m in plan)
-        for mine, (x, lens) in zip(plan, feed):
-            lab = pad_labels([tl[i] for i in mine])
-            if args.online:  # already on the device and normalised
-                loss = trainer.train_step(x, lens, torch.from_numpy(lab).to(dev), raw=False)
+            feed = (pad_waves([tw[i] for i in m]) for _, m in plan if m)
+        stop = False
+        for whole, mine in plan:
+            gc = len(whole) if world > 1 else None
+            if not mine:  # this rank's shard of a short last batch is empty: zeros into the same collectives
+                loss = trainer.train_step(None, None, None, global_count=gc)
             else:
-                loss = trainer.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(lens).to(dev),
-                                          torch.from_numpy(lab).to(dev))
+                x, lens = next(feed)
+                lab = pad_labels([tl[i] for i in mine])
+                if args.online:  # already on the device and normalised
+                    loss = trainer.train_step(x, lens, torch.from_numpy(lab).to(dev), raw=False, global_count=gc)
+                else:
+                    loss = trainer.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(lens).to(dev),
+                                              torch.from_numpy(lab).to(dev), global_count=gc)
             run_loss.append(loss)
             step += 1
             if step % args.eval_steps == 0 or step == total:
                 entry = {"epoch": step / steps_per_epoch, "step": step, "learning_rate": opt.current_lr(),
                          "loss": float(torch.stack(run_loss).mean().item())}
                 run_loss = []
+                ck = os.path.join(out_dir, f"checkpoint-{step}")
                 if rank == 0:
                     state["log_history"].append(entry)
-                    state["log_history"].append({"epoch": entry["epoch"], "step": step, **evaluate(model, tok, vw, vl, args.batch_size)})
+                    metrics = evaluate(model, tok, vw, vl, args.batch_size)
+                    state["log_history"].append({"epoch": entry["epoch"], "step": step, **metrics})
                     state["global_step"] = step
-                    ck = os.path.join(out_dir, f"checkpoint-{step}")
+                    # on_evaluate (early stopping) first, then save + best-metric bookkeeping, then rotation: HF's order
+                    stop = tracker.after_evaluation(metrics["eval_wer"], ck)
                     save_pretrained(model, tok, ck)
                     torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
-                    kind, keys, pos, has_gauss, cached = model._host_rng.get_state()
-                    with open(os.path.join(ck, "rng.json"), "w") as f:
-                        json.dump({"step_seed": int(model._step_seed),
-                                   "host_rng": [kind, [int(k) for k in keys], int(pos), int(has_gauss), float(cached)]}, f)
+                if world > 1:
+                    torch.distributed.barrier()  # the checkpoint folder exists
+                kind, keys, pos, has_gauss, cached = model._host_rng.get_state()
+                with open(os.path.join(ck, f"rng-rank{rank}.json"), "w") as f:  # each rank's own regulariser streams
+                    json.dump({"step_seed": int(model._step_seed),
+                               "host_rng": [kind, [int(k) for k in keys], int(pos), int(has_gauss), float(cached)]}, f)
+                if world > 1:
+                    torch.distributed.barrier()  # ... and holds every rank's file before it counts as a checkpoint
+                if rank == 0:
                     with open(os.path.join(ck, "trainer_state.json"), "w") as f:
                         json.dump(state, f, indent=1)
-                    for old in sorted_checkpoints(out_dir)[:-2]:  # save_total_limit=2 (wav2vec_train.py:370)
-                        shutil.rmtree(old, ignore_errors=True)
+                    rotate_checkpoints(out_dir, state["best_model_checkpoint"])
+                if world > 1:  # every rank leaves the loop together
+                    flag = torch.tensor([int(stop)], device=dev)
+                    torch.distributed.broadcast(flag, src=0)
+                    stop = bool(flag.item())
+                if stop:
+                    break
+        if stop:
+            if rank == 0:
+                print(f"early stopping at step {step}: {EARLY_STOPPING_PATIENCE} evaluations without a better WER "
+                      f"(best {state['best_metric']:.4f} at {state['best_model_checkpoint']})")
+            break
     if rank == 0:
+        # load_best_model_at_end (wav2vec_train.py:369; trainer.py:1893-1896): final/ holds the best-WER checkpoint's weights
+        best = state.get("best_model_checkpoint")
+        if best is not None and os.path.isdir(best):
+            from .checkpoint import load_state_dict_file
+            model.load_state_dict(load_state_dict_file(best))
+            print(f"loading best model from {best} (wer {state['best_metric']:.4f})")
         save_pretrained(model, tok, os.path.join(out_dir, "final"))
         print(f"trained {step} steps in {time.time() - t0:.1f} s -> {out_dir}")
     if world > 1:

@@ -224,19 +224,45 @@ class Trainer:
             torch.cuda.current_stream().wait_stream(compute_stream)
         self.opt.step(grad_scale=1.0 / self.world, norm_done=have_norm)
 
-    def train_step(self, waves: torch.Tensor, lengths, labels: torch.Tensor, raw: bool = True):
+    def train_step(self, waves: torch.Tensor, lengths, labels: torch.Tensor, raw: bool = True, global_count: int | None = None):
         """waves [B,T] fp32 on the device (raw samples when ``raw``: normalised here, a1), lengths [B] or None,
-        labels [B,L] (-100 padding).  Returns the (local) loss tensor; no host synchronisation."""
+        labels [B,L] (-100 padding).  Returns the (local) loss tensor; no host synchronisation.
+
+        ``global_count`` (data parallel): utterances of the GLOBAL batch when the ranks' shards differ in size (the short last
+        batch of an epoch, data.shard_batch).  The CTC loss is a mean over utterances, so rank r's gradient enters the sum
+        all-reduce weighted by n_r * world / global_count (the optimizer divides the sum by world): the update equals the
+        single-process update on the whole batch.  A rank whose shard is empty (``waves`` None or
+        zero rows) contributes zeros to the same sequence of collectives."""
         m = self.model
-        x = hip.wave_normalize(waves, lengths) if raw else waves
-        out = m(x, lengths=lengths if self.use_mask else None, labels=labels)
-        m.backward()  # with a process group: announces finished gradient ranges -> bucketed all-reduces overlap it
+        n_local = 0 if waves is None else int(waves.shape[0])
+        scale = 1.0
+        if global_count is not None and self.world > 1:
+            scale = n_local * self.world / float(global_count)
+        if n_local == 0:
+            if not (self.dist and self.world > 1):
+                raise ValueError("train_step: empty batch")
+            loss = self._empty_step()
+        else:
+            x = hip.wave_normalize(waves, lengths) if raw else waves
+            out = m(x, lengths=lengths if self.use_mask else None, labels=labels)
+            m.backward(grad_scale=scale)  # with a process group: announces finished gradient ranges -> bucketed all-reduces overlap it
+            loss = out.loss
         if self.opt_stream is None:
             self._tail(norm_from_buckets=False)
-            return out.loss
+            return loss
         with torch.cuda.device(m.device):
             cur = torch.cuda.current_stream()
             with torch.cuda.stream(self.opt_stream):
                 self._tail(norm_from_buckets=True, compute_stream=cur)
                 self._ready.record(self.opt_stream)
-        return out.loss
+        return loss
+
+    def _empty_step(self):
+        """This rank has no utterance of the global batch: zero gradients through the same bucket sequence the engine's
+        backward announces (ssak_w2v2_grad_ranges lists it from the configuration alone), so every rank still pairs the k-th
+        collective with the same range."""
+        m = self.model
+        m.grads[:m.num_trainable].zero_()
+        for off, cnt in m.announced_grad_ranges():
+            self._on_grads_ready(off, cnt)
+        return torch.zeros((), dtype=torch.float32, device=m.device)

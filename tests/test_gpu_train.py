@@ -283,6 +283,194 @@ def test_dp2_trainer_equals_single_process(tmp_path, exchange):
     assert du_ref.abs().max() > 1e-3 and rel < 0.1, rel
 
 
+def _dp_uneven_problem():
+    from oracle import w2v2_ref as R
+    oc = R.W2V2Config.tiny().deterministic()
+    rng = np.random.default_rng(13)
+    x = R.zero_mean_unit_var_norm([rng.standard_normal(9000).astype(np.float32) for _ in range(7)])
+    labels = R.pad_labels([list(rng.integers(1, 32, n)) for n in (5, 3, 8, 4, 6, 2, 7)])  # unequal target lengths on purpose
+    # 7 utterances in batches of 4: a full batch, the short last batch of the epoch (3 -> shards of 2 and 1), a batch of ONE
+    # (rank 1's shard is empty) and a batch of 5 (3 + 2)
+    batches = [[0, 1, 2, 3], [4, 5, 6], [0], [1, 2, 3, 4, 5]]
+    return oc, R.init_params(oc, 22), x, labels, batches
+
+
+def _dp_uneven_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.data import shard_batch
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    oc, p0, x, labels, batches = _dp_uneven_problem()
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
+    model.load_state_dict(p0)
+    tr = Trainer(model, AdamW(model, lr=1e-3, warmup_steps=2, total_steps=100, max_grad_norm=1.0))
+    tr.broadcast_parameters()
+    sizes = []
+    for whole in batches:
+        mine = shard_batch(whole, rank, world)
+        sizes.append(len(mine))
+        if mine:
+            tr.train_step(torch.tensor(x[mine]).cuda(), None, torch.tensor(labels[mine]).cuda(), raw=False, global_count=len(whole))
+        else:
+            tr.train_step(None, None, None, global_count=len(whole))
+    torch.save({"params": model.params[:model.num_trainable].cpu(), "sizes": sizes}, f"{out}.{rank}")
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp2_uneven_shards_weighted_by_utterance_count(tmp_path):
+    """SURVEY.md section 8e "with unequal shard sizes weight by utterance count": HF trains on the short last batch of an epoch
+    (dataloader_drop_last=False, docker/transformers_modified/trainer.py:834).  Two ranks over 7 utterances in batches of 4
+    -- shards of 2+2, 2+1, 1+0 (an EMPTY shard: zeros through the same collectives) and 3+2, unequal target lengths -- end
+    where the single-process run on the whole batches ends, and both ranks hold the same parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp_uneven.pt")
+    mp.spawn(_dp_uneven_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["sizes"] == [2, 2, 1, 3] and r1["sizes"] == [2, 1, 0, 2]
+    assert torch.equal(r0["params"], r1["params"])
+    oc, p0, x, labels, batches = _dp_uneven_problem()
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
+    model.load_state_dict(p0)
+    tr = Trainer(model, AdamW(model, lr=1e-3, warmup_steps=2, total_steps=100, max_grad_norm=1.0))
+    for whole in batches:
+        tr.train_step(torch.tensor(x[whole]).cuda(), None, torch.tensor(labels[whole]).cuda(), raw=False)
+    ref = model.params[:model.num_trainable].cpu()
+    start = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc))
+    start.load_state_dict(p0)
+    p_init = start.params[:start.num_trainable].cpu()
+    du_ref, du_dp = ref - p_init, r0["params"] - p_init
+    rel = float((du_dp - du_ref).norm() / du_ref.norm())
+    # an unweighted mean of the shard means (what equal-shard code would do) lands ~0.3 away on this problem
+    assert du_ref.abs().max() > 1e-3 and rel < 0.1, rel
+
+
+def test_train_cli_best_model_early_stopping_and_rotation(tmp_path, monkeypatch):
+    """What decides the reference's output model (wav2vec_train.py:368-372,392,419-420): metric_for_best_model="wer",
+    load_best_model_at_end, save_total_limit=2, EarlyStoppingCallback.  ssak_amd.train.main() runs in process with the
+    evaluation's WER scripted to 0.5, 0.4, 0.6, 0.7 (the last evaluations are WORSE) and the patience set to 2: training
+    stops after the 4th evaluation although steps remain, the 2nd checkpoint (best) and the 4th (newest) survive the
+    rotation, and final/ holds the best checkpoint's weights bit for bit -- not the last ones."""
+    from safetensors.numpy import load_file
+    from oracle import w2v2_ref as R
+    from ssak_amd import data as D
+    from ssak_amd import train as T
+    from ssak_amd.checkpoint import save_pretrained
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.synth import VOCAB, synth_text, synth_wave
+    rng = np.random.default_rng(0)
+    kd = tmp_path / "kaldi"
+    (kd / "audio").mkdir(parents=True)
+    with open(kd / "wav.scp", "w") as fw, open(kd / "text", "w") as ft, open(kd / "utt2dur", "w") as fd:
+        for i in range(7):  # 7 utterances, batches of 4: every epoch ends in a short batch of 3 (trained, not dropped)
+            n = int(rng.integers(16000, 24000))
+            D.write_wav(str(kd / "audio" / f"u{i}.wav"), synth_wave(rng, n))
+            fw.write(f"utt{i} {kd}/audio/u{i}.wav\n")
+            ft.write(f"utt{i} {synth_text(rng, 3, 6)}\n")
+            fd.write(f"utt{i} {n / 16000:.3f}\n")
+    oc = dataclasses.replace(R.W2V2Config.tiny(), layerdrop=0.0)
+    base = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc))
+    base.load_state_dict(R.init_params(oc, 1))
+    save_pretrained(base, D.CharTokenizer(VOCAB), str(tmp_path / "base"))
+    del base
+    script = iter([0.5, 0.4, 0.6, 0.7, 0.1, 0.1, 0.1, 0.1])
+    real_eval = T.evaluate
+
+    def scripted(model, tok, waves, labels, batch_size):
+        m = real_eval(model, tok, waves, labels, batch_size)
+        m["eval_wer"] = next(script)
+        return m
+
+    monkeypatch.setattr(T, "evaluate", scripted)
+    monkeypatch.setattr(T, "EARLY_STOPPING_PATIENCE", 2)
+    T.main([str(kd), str(kd), "--base_model", str(tmp_path / "base"), "--batch_size", "4", "--num_epochs", "20", "--eval_steps", "5",
+            "--learning_rate", "3e-3", "--min_duration", "0", "--disable_first_eval", "--output_dir", str(tmp_path / "out")])
+    run = tmp_path / "out" / [d for d in os.listdir(tmp_path / "out") if "_adamwt" in d][0]
+    cks = sorted(d for d in os.listdir(run) if d.startswith("checkpoint-"))
+    assert cks == ["checkpoint-10", "checkpoint-20"], cks  # best (2nd evaluation) + newest (4th); 35 steps were planned
+    st = json.load(open(run / "checkpoint-20" / "trainer_state.json"))
+    assert st["global_step"] == 20 and st["max_steps"] == 35 and st["best_metric"] == 0.4
+    assert st["best_model_checkpoint"].endswith("checkpoint-10") and st["early_stopping_patience_counter"] == 2
+    # epochs count the short batch as a step: 2 steps per epoch
+    assert [e["epoch"] for e in st["log_history"] if "loss" in e] == [2.5, 5.0, 7.5, 10.0]
+    final, best, last = (load_file(str(run / d / "model.safetensors")) for d in ("final", "checkpoint-10", "checkpoint-20"))
+    assert all(np.array_equal(final[k], best[k]) for k in best)
+    assert any(not np.array_equal(final[k], last[k]) for k in last)
+    assert os.path.exists(run / "checkpoint-20" / "rng-rank0.json")
+
+
+@pytest.mark.timeout(900)
+def test_train_cli_two_rank_resume_restores_each_ranks_regulariser_streams(tmp_path):
+    """A resumed data-parallel run continues the uninterrupted one: the trainer seeds rank r's dropout / SpecAugment / LayerDrop
+    streams with seed + r, every rank writes its own rng-rank{r}.json into a checkpoint, and on resume every rank reads ITS
+    file (round-2 advice: rank 0's state used to be loaded everywhere, after which all ranks drew identical masks).  Two ranks
+    over gloo on the one card: the streams at step 10 of a run resumed from checkpoint-5 equal those of the uninterrupted run,
+    rank by rank, and differ between the ranks."""
+    import shutil
+    import socket
+    from oracle import w2v2_ref as R
+    from ssak_amd import data as D
+    from ssak_amd.checkpoint import save_pretrained
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.synth import VOCAB, synth_text, synth_wave
+    rng = np.random.default_rng(2)
+    kd = tmp_path / "kaldi"
+    (kd / "audio").mkdir(parents=True)
+    with open(kd / "wav.scp", "w") as fw, open(kd / "text", "w") as ft, open(kd / "utt2dur", "w") as fd:
+        for i in range(9):  # 9 utterances in batches of 4 over 2 ranks: 2+2, 2+2, 1+0
+            n = int(rng.integers(16000, 24000))
+            D.write_wav(str(kd / "audio" / f"u{i}.wav"), synth_wave(rng, n))
+            fw.write(f"utt{i}\t{kd}/audio/u{i}.wav\n")
+            ft.write(f"utt{i} {synth_text(rng, 3, 6)}\n")
+            fd.write(f"utt{i} {n / 16000:.3f}\n")
+    oc = R.W2V2Config.tiny()  # dropouts, LayerDrop and SpecAugment at the script's defaults
+    base = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc))
+    base.load_state_dict(R.init_params(oc, 1))
+    save_pretrained(base, D.CharTokenizer(VOCAB), str(tmp_path / "base"))
+    del base
+    torch.cuda.synchronize()
+
+    def run(out):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, PYTHONPATH=ROOT, SSAK_DIST_BACKEND="gloo")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), "-m", "ssak_amd.train", str(kd), str(kd), "--base_model", str(tmp_path / "base"),
+                            "--batch_size", "4", "--num_epochs", "4", "--eval_steps", "5", "--learning_rate", "1e-3", "--min_duration", "0",
+                            "--disable_first_eval", "--output_dir", str(out)], env=env, capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r.stdout
+
+    run(tmp_path / "out")
+    name = [d for d in os.listdir(tmp_path / "out") if "_adamwt" in d][0]
+    full = tmp_path / "out" / name
+    assert json.load(open(full / "checkpoint-9" / "trainer_state.json"))["global_step"] == 9  # round(4 * 9 / 4)
+    shutil.copytree(tmp_path / "out", tmp_path / "out_resume")
+    res = tmp_path / "out_resume" / name
+    shutil.rmtree(res / "checkpoint-9")
+    shutil.rmtree(res / "final")
+    assert "resuming from" in run(tmp_path / "out_resume")
+    states = {}
+    for tag, folder in (("full", full), ("resumed", res)):
+        for r in (0, 1):
+            states[tag, r] = json.load(open(folder / "checkpoint-9" / f"rng-rank{r}.json"))
+    assert states["full", 0] == states["resumed", 0] and states["full", 1] == states["resumed", 1]
+    assert states["full", 0]["step_seed"] != states["full", 1]["step_seed"]
+    assert states["full", 0]["host_rng"] != states["full", 1]["host_rng"]
+
+
 def test_train_step_is_bitwise_reproducible():
     """No float atomics on the path: two runs from the same seed (dropout, LayerDrop and SpecAugment ON) end in bit-identical
     parameters and losses -- bias gradients, the SpecAugment embedding gradient and the clip norm are all fixed-order sums."""

@@ -281,3 +281,40 @@ def test_speechbrain_cli_yaml_and_overrides(tmp_path):
     assert v.symbols == ["<blank>", " ", "a", "b", "c"] and v.encode("a cz") == [2, 1, 4]
     t, tl = pad_tokens([[2, 3, 4, 2], [3]])
     assert t.tolist() == [[2, 3, 4, 2], [3, 0, 0, 0]] and tl.tolist() == [1.0, 0.25]
+
+
+def test_shard_batch_keeps_every_utterance():
+    """Uneven contiguous shards (the short last batch of an epoch is trained, HF dataloader_drop_last=False): the first
+    len % world ranks take one more, nothing is dropped, a rank may be empty."""
+    for n in range(0, 12):
+        for world in (1, 2, 3, 8):
+            idx = list(range(100, 100 + n))
+            shards = [D.shard_batch(idx, r, world) for r in range(world)]
+            assert sum(shards, []) == idx
+            sizes = [len(s) for s in shards]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_best_model_tracker_and_checkpoint_rotation(tmp_path):
+    """metric_for_best_model="wer" (lower is better) + EarlyStoppingCallback + save_total_limit=2 as HF Trainer sequences them
+    (wav2vec_train.py:368-372,392; docker/transformers_modified/trainer.py:2224-2238,2735-2783): a tie is no improvement for
+    the patience counter and does not move the best checkpoint; the best and the newest checkpoint survive the rotation."""
+    import json
+    from ssak_amd import train as T
+    state = {}
+    tr = T.BestModelTracker(state, patience=3)
+    out = tmp_path / "run"
+    wers = [0.9, 0.5, 0.5, 0.7, 0.4, 0.6, 0.6, 0.6]
+    stops, kept = [], []
+    for i, w in enumerate(wers, 1):
+        ck = out / f"checkpoint-{10 * i}"
+        ck.mkdir(parents=True)
+        stops.append(tr.after_evaluation(w, str(ck)))
+        (ck / "trainer_state.json").write_text(json.dumps(state))
+        T.rotate_checkpoints(str(out), state["best_model_checkpoint"])
+        kept.append(sorted(int(d.split("-")[1]) for d in os.listdir(out)))
+    assert stops == [False] * 7 + [True]
+    assert kept == [[10], [10, 20], [20, 30], [20, 40], [40, 50], [50, 60], [50, 70], [50, 80]]
+    assert state["best_metric"] == 0.4 and state["best_model_checkpoint"].endswith("checkpoint-50")
+    assert state["early_stopping_patience_counter"] == 3
+    assert T.EARLY_STOPPING_PATIENCE == 15  # the reference's patience
