@@ -159,6 +159,11 @@ typedef struct {
   int colsum; /* != 0: `aux_out` is a float [N] vector that receives += the column sums of the stored C (after the epilogue:
                  the bias gradient of the Linear that produced the GEMM's A operand side), summed in a fixed order;
                  needs workspace >= ceil(M / 64) * N * 4 bytes; not with SSAK_EPI_GELU, split_k or batches */
+  int dynamic_tiles; /* tile order of the persistent kernels for THIS product.  0 (default): static stride over the workgroups;
+                 1: every tile is drawn from per-XCD ticket counters, so that workgroups whose CU is held by another stream's
+                 kernel for a while -- the RCCL all-reduce of a data-parallel step -- take fewer tiles instead of finishing
+                 last.  Alone on the chip the static order is a few percent faster (no ticket round trip at the start of a
+                 launch); results are bit-identical either way.  (A grouped launch reads it from descs[0].) */
 } ssak_gemm_desc;
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);
@@ -177,17 +182,13 @@ int ssak_gemm_f32(const ssak_gemm_desc* desc /*host*/, const void* A, const void
 int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs /*host*/, int n, const void* const* A, const void* const* B, void* const* C,
                            void* stream);
 
-/* Tile order of the persistent GEMM kernels, process-wide.  0 (default): static stride over the workgroups; 1: every tile is
- * drawn from per-XCD ticket counters, so that workgroups whose CU is held by another stream's kernel for a while -- the RCCL
- * all-reduce of a data-parallel step -- take fewer tiles instead of finishing last.  The data-parallel trainers switch it on;
- * alone on the chip the static order is a few percent faster (no ticket round trip at the start of a launch). */
-int ssak_gemm_tile_order(int dynamic);
-
 /* Per-launch timing for the roofline report (measurement aid, not on the reference's path): while enabled, launches are
  * bracketed by HIP events on their own stream; ssak_prof_collect waits for them and returns one entry per slot: the kernel
  * classes of the train step (attention, LayerNorm, conv0, AdamW, CTC, ...) and every GEMM instantiation launched so far
  * (named as rocprofv3 prints it), each with launches / summed ms / ALGORITHMIC work -- flops for SSAK_BOUND_MFMA slots,
- * bytes for SSAK_BOUND_HBM / SSAK_BOUND_LATENCY slots.  ssak_prof_enable(0) = off, (1) = every launch, (2 + i) = only slot i:
+ * bytes for SSAK_BOUND_HBM / SSAK_BOUND_LATENCY slots.  Timing is switched on PER STREAM (no process-wide state: launches on
+ * other streams -- another handle, another thread -- are not touched and not reported): ssak_prof_enable(stream, 0) = off,
+ * (stream, 1) = every launch on that stream, (stream, 2 + i) = only slot i:
  * an event pair keeps consecutive kernels from overlapping head to tail, and bracketing all launches of a train step costs
  * a few per cent of it, so a benchmark surveys all slots in warm-up steps and times only the slot it reports on inside its
  * timed region. */
@@ -201,8 +202,8 @@ typedef struct {
   double total_flops; /* flops, or bytes for the HBM / latency-bound slots */
   int bound;
 } ssak_prof_entry;
-int ssak_prof_enable(int on);
-int ssak_prof_collect(ssak_prof_entry* out /*host*/, int cap); /* cap >= 128; returns the number of entries */
+int ssak_prof_enable(void* stream, int on);
+int ssak_prof_collect(void* stream, ssak_prof_entry* out /*host*/, int cap); /* cap >= 128; returns the number of entries */
 
 /* ---- a3 (part): first layer of the feature encoder -------------------------------------------
  * Conv1d(1, C, k=10, s=5, no bias) -> GroupNorm(C groups: per channel over time) -> GELU of Wav2Vec2GroupNormConvLayer
@@ -222,14 +223,17 @@ int ssak_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const
 int ssak_attention_fwd(const void* qkv, void* ctx, float* lse, const int32_t* klens, int B, int F, int nh, int H, float drop_p,
                        uint64_t seed, uint32_t stream_id, void* stream);
 int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx, float* delta,
-                       void* dqkv, int B, int F, int nh, int H, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
-/* Backward form: 1 (default) = two kernels (dQ; dK + dV), each recomputing P; 0 = one fused pass with producer / consumer
- * wave specialisation; 2 = one fused pass with every wave in every role.  The fused forms evaluate P, the dropout words and dS
- * once (40 % fewer VALU instructions, five matrix products instead of seven); a workgroup per head walks the keys in blocks and
- * adds each block's dQ tiles onto what it stored for the previous blocks (fixed order, no atomics, bit-reproducible).  Both
- * are parity-tested against the two-kernel form and both are slower at the train-step shape today.
- * Environment SSAK_ATTN_BWD=ws / fused selects 0 / 2 at start-up. */
-int ssak_attention_bwd_mode(int mode);
+                       void* dqkv, int B, int F, int nh, int H, float drop_p, uint64_t seed, uint32_t stream_id, int mode,
+                       void* stream);
+/* `mode` of the backward (per call; the engine takes it from its handle, ssak_w2v2_set_option): SSAK_ATTN_BWD_DEFAULT /
+ * SSAK_ATTN_BWD_TWO_KERNEL = two kernels (dQ; dK + dV), each recomputing P; SSAK_ATTN_BWD_FUSED = one fused pass that evaluates
+ * P, the dropout words and dS once (40 % fewer VALU instructions, five matrix products instead of seven): a workgroup per head
+ * walks the keys in blocks and adds each block's dQ tiles onto what it stored for the previous blocks (fixed order, no atomics,
+ * bit-reproducible).  Parity-tested against the two-kernel form; slower at the train-step shape B = 32 today, 9-11 % ahead at
+ * B = 64. */
+#define SSAK_ATTN_BWD_DEFAULT 0
+#define SSAK_ATTN_BWD_TWO_KERNEL 1
+#define SSAK_ATTN_BWD_FUSED 2
 
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer
@@ -316,6 +320,13 @@ int ssak_w2v2_set_grad_ready_callback(ssak_w2v2* h, ssak_grad_ready_fn fn, void*
  * the AdamW sweep of step n.  stall_begin / stall_end (hipEvent_t or NULL) are recorded around that wait: their distance is the
  * exposed part of the tail.  NULL params_ready removes the wait. */
 int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begin, void* stall_end);
+/* Per-handle execution options (nothing here changes results beyond rounding; no process-wide switches):
+ * SSAK_W2V2_OPT_DYNAMIC_TILES  0 / 1: ssak_gemm_desc.dynamic_tiles of every product the engine launches -- the data-parallel
+ *                              trainers set it, RCCL's kernels share the chip with the persistent GEMMs;
+ * SSAK_W2V2_OPT_ATTENTION_BWD  SSAK_ATTN_BWD_*: the form of the fused attention backward. */
+#define SSAK_W2V2_OPT_DYNAMIC_TILES 1
+#define SSAK_W2V2_OPT_ATTENTION_BWD 2
+int ssak_w2v2_set_option(ssak_w2v2* h, int option, int value);
 /* The gradient ranges ssak_w2v2_backward announces, in announcement order, from the configuration alone (host arithmetic, no
  * device): head matrix, one range per encoder layer from the last to the first (a layer's q|k|v|out|ffn matrices are
  * contiguous), the leading small matrices, then the vector region (biases, LayerNorm affines) [+ the feature encoder when it

@@ -18,24 +18,43 @@ void ssak_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int ssak_version(void) { return 100; }
+extern "C" int ssak_version(void) { return 300; }  // round 3: per-call / per-handle / per-stream switches (ABI change)
 extern "C" const char* ssak_last_error(void) { return g_err; }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around launches, on the launch's own stream ----
 // The first slots are the kernel classes of the train step (kernels.h: PROF_*); every GEMM instantiation registers a slot
 // under its own name (as rocprofv3 prints it) at its first launch.  An event pair keeps consecutive kernels from overlapping head to tail, so
 // bracketing everything costs a few per cent of a step: benchmarks survey all slots in warm-up steps and bracket one slot
-// inside their timed region (ssak_prof_enable(2 + slot)).
+// inside their timed region (ssak_prof_enable(stream, 2 + slot)).
+// State is PER STREAM (keyed by device + stream): enabling the timing for one caller's stream neither slows nor records the
+// launches of another handle / thread.  The fast path of an untimed process is one relaxed atomic load.
+#include <atomic>
+#include <map>
 namespace {
 struct ProfRec {
   hipEvent_t e0, e1;
   int slot;
   double work;
 };
-int g_prof_mode = 0;
-std::vector<ProfRec> g_prof;
+struct ProfStream {
+  int mode = 0;
+  std::vector<ProfRec> recs;
+};
+struct ProfKey {
+  int dev;
+  hipStream_t st;
+  bool operator<(const ProfKey& o) const { return dev != o.dev ? dev < o.dev : st < o.st; }
+};
+std::mutex g_prof_mu;
+std::map<ProfKey, ProfStream> g_prof_streams;
+std::atomic<int> g_prof_active{0};  // streams with mode != 0
 std::vector<hipEvent_t> g_event_pool;
-hipEvent_t prof_event() {
+ProfKey prof_key(hipStream_t st) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return ProfKey{dev, st};
+}
+hipEvent_t prof_event() {  // g_prof_mu held
   if (!g_event_pool.empty()) {
     hipEvent_t e = g_event_pool.back();
     g_event_pool.pop_back();
@@ -89,28 +108,41 @@ int ssak_prof_register(const char* name, int bound) {
   return register_locked(name, bound);
 }
 
-bool ssak_prof_wanted(int slot) { return g_prof_mode == 1 || g_prof_mode == slot + 2; }
+bool ssak_prof_wanted(int slot, hipStream_t st) {
+  if (g_prof_active.load(std::memory_order_relaxed) == 0) return false;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  auto it = g_prof_streams.find(prof_key(st));
+  return it != g_prof_streams.end() && (it->second.mode == 1 || it->second.mode == slot + 2);
+}
 
-ProfScope::ProfScope(int slot, double work, hipStream_t st) : st_(st), slot_(slot), work_(work), on_(ssak_prof_wanted(slot)) {
+ProfScope::ProfScope(int slot, double work, hipStream_t st) : st_(st), slot_(slot), work_(work), on_(ssak_prof_wanted(slot, st)) {
   if (on_) {
-    e0_ = prof_event();
+    {
+      std::lock_guard<std::mutex> lock(g_prof_mu);
+      e0_ = prof_event();
+    }
     (void)hipEventRecord(e0_, st_);
   }
 }
 ProfScope::~ProfScope() {
   if (on_) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     hipEvent_t e1 = prof_event();
     (void)hipEventRecord(e1, st_);
-    g_prof.push_back(ProfRec{e0_, e1, slot_, work_});
+    g_prof_streams[prof_key(st_)].recs.push_back(ProfRec{e0_, e1, slot_, work_});
   }
 }
 
-extern "C" int ssak_prof_enable(int on) {
-  g_prof_mode = on < 0 ? 0 : on;
+extern "C" int ssak_prof_enable(void* stream, int on) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  ProfStream& ps = g_prof_streams[prof_key((hipStream_t)stream)];
+  const int mode = on < 0 ? 0 : on;
+  if ((ps.mode != 0) != (mode != 0)) g_prof_active.fetch_add(mode != 0 ? 1 : -1, std::memory_order_relaxed);
+  ps.mode = mode;
   return SSAK_OK;
 }
 
-extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
+extern "C" int ssak_prof_collect(void* stream, ssak_prof_entry* out, int cap) {
   SSAK_REQUIRE(out && cap >= PROF_MAX_SLOTS, "prof_collect: need room for %d entries", PROF_MAX_SLOTS);
   int n;
   {
@@ -125,16 +157,23 @@ extern "C" int ssak_prof_collect(ssak_prof_entry* out, int cap) {
       out[i].total_flops = 0.0;
     }
   }
-  for (ProfRec& r : g_prof) {
+  std::vector<ProfRec> recs;
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    recs.swap(g_prof_streams[prof_key((hipStream_t)stream)].recs);
+  }
+  for (ProfRec& r : recs) {
     SSAK_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;
     SSAK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
     out[r.slot].launches += 1;
     out[r.slot].total_ms += ms;
     out[r.slot].total_flops += r.work;
+  }
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  for (ProfRec& r : recs) {
     g_event_pool.push_back(r.e0);
     g_event_pool.push_back(r.e1);
   }
-  g_prof.clear();
   return n;
 }

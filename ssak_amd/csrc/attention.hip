@@ -25,7 +25,6 @@
 
 namespace {
 
-int attn_bwd_mode();
 int attn_tile(int which);  // 16-row sub-tiles per wave: 0 forward (queries), 1 dQ kernel (queries), 2 dK/dV kernel (keys)
 
 constexpr int HD = 64;    // head dim
@@ -720,10 +719,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 //     element-wise math, no dQ phase) takes 125 us: two barriers per 1024 score elements per wave (the two-kernel form: one per
 //     2048) leave every wave in the same phase, so the LDS bursts, the MFMA blocks and the VALU work of a step queue up one
 //     behind the other.  At B = 64 (768 heads, whole rounds) the 8-wave form is 9-11 % ahead of the two-kernel form, at
-//     B = 32 behind.  NOT the default (ssak_attention_bwd_mode(0) / SSAK_ATTN_BWD=fused selects it; parity-tested against the
-//     two-kernel form for every shape class).  What it would take: producer / consumer wave specialisation (waves that only do
-//     S, dP and the element-wise math next to waves that only run the dK / dV / dQ products, handing P and dS over through
-//     double-buffered LDS tiles, one barrier per step), so that VALU and MFMA work of different waves overlap by construction.
+//     B = 32 behind.  NOT the default (mode SSAK_ATTN_BWD_FUSED of ssak_attention_bwd / the engine option selects it;
+//     parity-tested against the two-kernel form for every shape class).  A producer / consumer wave-specialised variant (waves
+//     that only do S, dP and the element-wise math next to waves that only run the dK / dV / dQ products, P and dS handed over
+//     through double-buffered LDS tiles) was built in round 2, measured at 195-205 us and removed in round 3.
 //   Pipeline: the query tiles (Q and dO as row and transpose images, O rows, lse) run through three LDS stages filled by LDS-DMA
 //   two steps ahead with counted vmcnt waits; raw s_barriers (__syncthreads() drains vmcnt(0)) and ds_read_b64_tr_b16 as inline
 //   asm (the builtin makes the compiler drain the DMA pipeline before every read).  The wait for tile t+1 sits in front of the
@@ -1113,433 +1112,6 @@ __global__ __launch_bounds__(64 * FNW, 2) void attn_bwd_fused_kernel(const AttnP
   }
 }
 
-// ================================================================================================ wave-specialised fused backward
-// The single-pass backward above loses to the two-kernel form because all its waves sit in the same phase: the VALU work of a
-// step (softmax / dropout / dS), its MFMA blocks and its LDS bursts run one after the other.  Here the two kinds of work live
-// on DIFFERENT waves of each SIMD (tools/probes/mfma_valu_overlap.hip: MFMA and VALU of different waves overlap):
-//   producers (waves 0-3): own 64 keys of the 256-key block each (K / V fragments in registers); per step of 32 queries they
-//     form S and dP (32 MFMAs), run the element-wise math (the VALU-heavy part) and hand P keep / (1-p) and dS over as bf16
-//     [key][query] tiles in LDS (double buffered);
-//   consumers (waves 4-7): one step behind; wave c owns the dK / dV accumulators of the SAME 64 keys (32 MFMAs per step with
-//     the handed-over tiles as B operands and the Q^T / dO^T transpose images as A operands), forms the dQ^T strip of d block c
-//     over all 256 keys (16 MFMAs, dS^T back through ds_read_b64_tr_b16, K^T strip in registers), reads-adds-stores it (same
-//     workgroup, fixed order over the key blocks: no atomics, bit-reproducible), and forms the row statistics (delta, lse') of
-//     the tile after next from LDS.
-// ONE barrier per step.  Query tiles run through LDS-DMA rings three steps ahead with counted vmcnt waits: row images + O + lse
-// four deep (read by the producers / the statistics), transpose images five deep (read by the consumers one step later).
-// Correct for every shape class (test_fused_attention_backward_equals_two_kernel_form, mode 0) and NOT faster: 195-205 us at
-// B = 32, F = 499, 12 heads against 153 us for the two-kernel form.  Phase stamps (-DATT_WS_STAMPS, tools/dbg/ws_stamps.py,
-// profiles/r02_attention_ws_phase_stamps.log; shader cycles per step of ~5 700): the consumer needs 1 500 cycles to get from the
-// barrier to its first LDS read -- the 32 LDS-DMA instructions a CU issues per step (24 of 16 bytes, 8 of 4 bytes incl. the
-// dummies that keep the counts uniform) queue behind its one address unit at ~100 cycles each --, then 600 cycles for every
-// LDS round trip a lone wave waits out (about ten per step: 2 200 cycles for the 32 dK / dV MFMAs, 1 300-1 500 for the 16 dQ
-// MFMAs), 400 for the statistics; the producer's 614-instruction stream takes 4 350 cycles by itself (7 cycles per
-// instruction: one wave issues every ~6 cycles, tools/probes/valu_rate.hip) and then waits 1 100-1 900 for the consumer.  With
-// 13 DMA instructions per step (no dummies, transposing reads from the row images), batched reads and the two roles balanced
-// the estimate is ~3 900 cycles per step = 147 us: no better than two kernels, whose 2-3 independent waves per SIMD hide
-// exactly these latencies from each other.  Kept opt-in (ssak_attention_bwd_mode(0) / SSAK_ATTN_BWD=ws).
-constexpr int WQ = 32;                       // queries per step
-constexpr int WK = 256;                      // keys per block
-constexpr int W_ROWS_NST = 4, W_TR_NST = 5;
-constexpr int W_ROWS_STAGE = 3 * FT + 1536;  // Q rows | dO rows | O rows | lse (256 B) | 4-byte dummies (256 B) | 16-byte dummies (1 KiB)
-constexpr int W_TR_STAGE = 2 * FT;           // Q transpose | dO transpose
-constexpr int W_HAND = WK * WQ * 2;          // 16 KiB: one [key][32 q] bf16 tile (rows of 64 B, chunk swizzle dst_swz)
-constexpr int W_OFF_TR = W_ROWS_NST * W_ROWS_STAGE;
-constexpr int W_OFF_STAT = W_OFF_TR + W_TR_NST * W_TR_STAGE;
-constexpr int W_OFF_HAND = W_OFF_STAT + 2 * F_STAT;  // [buffer][Pd | dS]
-constexpr int W_LDS = W_OFF_HAND + 2 * 2 * W_HAND;
-static_assert(W_LDS <= 160 * 1024, "one workgroup per CU");
-static_assert(W_OFF_TR >= WK * HD * 2, "the K transpose image of a block's prologue aliases the row ring");
-
-#ifdef ATT_WS_STAMPS
-#define WS_STAMP(role, i)                                                                                              \
-  do {                                                                                                                 \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wv == 0 && kb == 0 && qt < 24)                              \
-      reinterpret_cast<unsigned long long*>(p.delta)[((role) * 24 + qt) * 8 + (i)] = __builtin_readcyclecounter();   \
-  } while (0)
-#else
-#define WS_STAMP(role, i)
-#endif
-
-template <bool DROP>
-__global__ __launch_bounds__(512) void attn_bwd_ws_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool producer = wave < 4;
-  const int wv = wave & 3;  // producer / consumer index: keys 64 wv .. + 63 of the block; consumer: d block wv of dQ
-  const int h = blockIdx.x, b = blockIdx.y;
-  const int F = p.F, H = p.H;
-  const long ld = 3L * H;
-  const bf16* base = p.qkv + (long)b * F * ld;
-  const int kl = p.klens ? min(max(p.klens[b], 0), F) : F;
-  const int nqt = (F + WQ - 1) / WQ, nkb = (F + WK - 1) / WK;
-  __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_lse = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + ((long)b * p.nh + h) * F), 0, F * 4, 0x00020000);
-  const uint32_t qcol = (uint32_t)(h * HD * 2), kcol = (uint32_t)((H + h * HD) * 2);
-  const int g = lane >> 4, lc = lane & 15;
-  float* const stat0 = reinterpret_cast<float*>(smem + W_OFF_STAT);
-  const float c2 = p.scale * 1.4426950408889634f;
-  const float log2scale = __log2f(p.scale);
-  const uint32_t thi = p.thresh16 << 16;
-  const int par = lane & 1;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-
-  // LDS-DMA per wave and step: three 16-byte slots (slot s = 3 wave + j; s < 20: piece (s & 3) of image (s >> 2) in the order
-  // Q rows, Q transpose, dO rows, dO transpose, O rows; the rest dummies) + one 4-byte instruction (wave 0: lse), branch-free.
-  uint32_t dma_off[3], dma_step[3], dma_dst[3];
-  bool dma_tr[3];
-  __amdgpu_buffer_rsrc_t dma_rs[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int slot = wave * 3 + j;  // uniform
-    const int img = slot >> 2, piece = slot & 3;
-    const int S = piece * 64 + lane;
-    const int r = S >> 3, pc = S & 7;
-    const bool tr = img == 1 || img == 3;
-    const int c = tr ? (pc ^ (r & 6)) : (pc ^ ((r >> 1) & 7));
-    const long row_bytes = slot < 8 ? ld * 2 : (long)H * 2;
-    dma_off[j] = slot < 20 ? (uint32_t)(r * row_bytes + qcol + c * 16) : 0x80000000u;
-    dma_step[j] = slot < 20 ? (uint32_t)(WQ * row_bytes) : 0u;
-    dma_tr[j] = slot < 20 && tr;
-    // inside its ring stage: rows ring = Q rows (0) | dO rows (1) | O rows (2); transpose ring = Q tr (0) | dO tr (1)
-    const int inner = img == 0 ? 0 : img == 2 ? 1 : img == 4 ? 2 : img == 1 ? 0 : 1;
-    dma_dst[j] = slot < 20 ? (uint32_t)(inner * FT + piece * 1024) : (uint32_t)(3 * FT + 512);
-    const void* bp = slot < 8 ? (const void*)base : slot < 16 ? (const void*)(p.dctx + (long)b * F * H) : (const void*)(p.ctx + (long)b * F * H);
-    const long bytes = slot < 8 ? (long)F * ld * 2 : (long)F * H * 2;
-    dma_rs[j] = __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, (int)bytes, 0x00020000);
-  }
-  const uint32_t lse_off = (wave == 0 && lane < WQ) ? (uint32_t)(lane * 4) : 0x80000000u;
-  const uint32_t lse_dst = wave == 0 ? (uint32_t)(3 * FT) : (uint32_t)(3 * FT + 256);
-  auto issue = [&](int qt, int rows_idx, int tr_idx) {  // ring slots of tile qt (= qt mod the ring depths, kept as counters)
-    char* const rows0 = smem + rows_idx * W_ROWS_STAGE;
-    char* const tr0 = smem + W_OFF_TR + tr_idx * W_TR_STAGE;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rs[j], (lds_void_t*)((dma_tr[j] ? tr0 : rows0) + dma_dst[j]), 16,
-                                               dma_off[j] + (uint32_t)qt * dma_step[j], 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lse, (lds_void_t*)(rows0 + lse_dst), 4, lse_off + (uint32_t)qt * (uint32_t)(WQ * 4), 0, 0, 0);
-  };
-  // row statistics of tile qt (consumers: wave c owns rows 8 c + (lane >> 3)); dropout row seeds by consumer 3
-  auto rows_stat = [&](int qt, int rows_idx) {
-    const char* const s0 = smem + rows_idx * W_ROWS_STAGE;
-    const int r = 8 * wv + (lane >> 3), part = lane & 7;
-    const int o16 = r * 128 + ((part ^ ((r >> 1) & 7)) << 4);
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(s0 + 1 * FT + o16);
-    const bf16x8 o = *reinterpret_cast<const bf16x8*>(s0 + 2 * FT + o16);
-    float v = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) v = __builtin_amdgcn_fdot2_f32_bf16((bf16x2_t){a[e], a[e + 1]}, (bf16x2_t){o[e], o[e + 1]}, v, false);
-    v += dpp_f<0xB1, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E, 0xf>(0.f, v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141, 0xf>(0.f, v);  // row_half_mirror: every lane holds its 8-lane total
-    float* st = stat0 + (qt & 1) * 3 * 64;
-    if (part == 0) {
-      const float ls = reinterpret_cast<const float*>(s0 + 3 * FT)[r];  // (zero for rows beyond F)
-      st[r] = ls > -INFINITY ? fmaf(ls, 1.4426950408889634f, -log2scale) : INFINITY;
-      st[64 + r] = v;
-    }
-    if (DROP && wv == 3 && lane < WQ) reinterpret_cast<uint32_t*>(st)[128 + lane] = drop_rowseed(p, b, h, qt * WQ + lane);
-  };
-
-#pragma unroll 1
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int key0 = kb * WK;
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the previous block's pipeline and stores have drained
-    ATT_BARRIER();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dma_piece(rs_qkv, smem, kcol, ld * 2, key0, F, true, wave * 4 + j, lane);  // K transpose image (256 keys)
-    if (producer) {
-      // ================================================================================ producer
-      int krow[4];
-      bf16x8 kf[4][2], vf[4][2];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        krow[ks] = key0 + 64 * wv + 16 * ks + lc;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          kf[ks][kk] = load_row_frag(base + H + h * HD, ld, krow[ks], F, kk, lane);
-          vf[ks][kk] = load_row_frag(base + 2 * H + h * HD, ld, krow[ks], F, kk, lane);
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-      ATT_BARRIER();                       // K image landed (read by the consumers)
-      ATT_BARRIER();                       // ... and read out
-      const uint32_t kphi0 = (uint32_t)(krow[0] >> 1) * DROP_PHI;  // sub-tile ks: + 8 ks * DROP_PHI
-      float sbias[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) sbias[ks] = krow[ks] < kl ? 0.f : -3.0e38f;  // keys beyond the key length: exp2(-huge) = 0
-      issue(0, 0, 0);
-      issue(1, 1, 1);
-      issue(2, 2, 2);
-      __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4): tiles 0 and 1 have landed (this wave's share)
-      ATT_BARRIER();                       // (the consumers form the statistics of tile 0 behind this barrier)
-      int r_cur = 0, r_nx3 = 3, t_nx3 = 3;  // row-ring slot of tile qt; ring slots of tile qt + 3
-#pragma unroll 1
-      for (int qt = 0; qt <= nqt; ++qt) {
-        // this wave's vm operations: the four DMA of a step.  Tile qt+1 (statistics by the consumers during this step; S / dP
-        // in the next) must have landed: only tile qt+2's four may be in flight.  lgkmcnt(0): the handed-over tiles are written.
-        __builtin_amdgcn_s_waitcnt(0x0074);
-        ATT_BARRIER();
-        if (qt == nqt) break;  // the consumers' last step
-        WS_STAMP(0, 0);
-        issue(qt + 3, r_nx3, t_nx3);
-        const char* rows0 = smem + r_cur * W_ROWS_STAGE;
-        r_cur = r_cur == W_ROWS_NST - 1 ? 0 : r_cur + 1;
-        r_nx3 = r_nx3 == W_ROWS_NST - 1 ? 0 : r_nx3 + 1;
-        t_nx3 = t_nx3 == W_TR_NST - 1 ? 0 : t_nx3 + 1;
-        const char* q_rows = rows0;
-        const char* do_rows = rows0 + FT;
-        const float* lse_s = stat0 + (qt & 1) * 3 * 64;
-        const float* dl_s = lse_s + 64;
-        const uint32_t* seed_s = reinterpret_cast<const uint32_t*>(lse_s + 128);
-        char* const hand_pd = smem + W_OFF_HAND + (qt & 1) * 2 * W_HAND;
-        char* const hand_ds = hand_pd + W_HAND;
-        bf16x8 qfr[2][2], dfr[2][2];  // one batch of reads per step: both key pairs use them
-#pragma unroll
-        for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            qfr[qh][kk] = frag_rows(q_rows, qh, kk, lane);
-            dfr[qh][kk] = frag_rows(do_rows, qh, kk, lane);
-          }
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {  // two key sub-tile pairs, one after the other (32 accumulator registers live)
-          f32x4 s[2][2], dp[2][2];        // [sub-tile of the pair][query sub-tile]
-#pragma unroll
-          for (int qh = 0; qh < 2; ++qh) {
-            const bf16x8 qa = qfr[qh][0], qb = qfr[qh][1], da = dfr[qh][0], db = dfr[qh][1];
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-              const int ks = 2 * kp + k2;
-              float sb = sbias[ks];
-              asm volatile("" : "+v"(sb));
-              f32x4 a = {sb, sb, sb, sb}, c = {0.f, 0.f, 0.f, 0.f};
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf[ks][1], a, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks][0], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db, vf[ks][1], c, 0, 0, 0);
-              s[k2][qh] = a;
-              dp[k2][qh] = c;
-            }
-          }
-#pragma unroll
-          for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {  // row pairs r = 2 i, 2 i + 1
-              uint32_t W[2][2];
-              if (DROP) {
-                const uint32_t rs = seed_s[16 * qh + 4 * g + 2 * i + par];
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                  const uint32_t mine = drop_word(rs + kphi0 + (uint32_t)(8 * (2 * kp + k2)) * DROP_PHI);
-                  const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);
-                  W[k2][0] = par ? other : mine;
-                  W[k2][1] = par ? mine : other;
-                }
-              }
-              const int ql = 16 * qh + 4 * g + 2 * i;
-              const f32x2 c2v = {c2, c2}, lscv = {-lse_s[ql], -lse_s[ql + 1]}, dlv = {dl_s[ql], dl_s[ql + 1]};
-#pragma unroll
-              for (int k2 = 0; k2 < 2; ++k2) {
-                const f32x2 a = (f32x2){s[k2][qh][2 * i], s[k2][qh][2 * i + 1]} * c2v + lscv;
-                const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};  // P * scale
-                f32x2 dpv = {dp[k2][qh][2 * i], dp[k2][qh][2 * i + 1]}, pd = pr;
-                if (DROP) {
-                  f32x2 keep;
-#pragma unroll
-                  for (int e = 0; e < 2; ++e) {
-                    const uint32_t w = W[k2][e];
-                    const bool k = par ? drop_keep_odd(w, thi) : drop_keep_even(w, thi);
-                    keep[e] = k ? p.drop_scale : 0.f;
-                  }
-                  dpv *= keep;
-                  pd *= keep;
-                }
-                const f32x2 ds2 = pr * (dpv - dlv);
-                s[k2][qh][2 * i] = pd[0];
-                s[k2][qh][2 * i + 1] = pd[1];
-                dp[k2][qh][2 * i] = ds2[0];
-                dp[k2][qh][2 * i + 1] = ds2[1];
-              }
-            }
-          WS_STAMP(0, 1 + kp);
-          // hand over: key row 64 wv + 16 ks + lc, queries 16 qh + 4 g .. + 3 (8 bytes each)
-#pragma unroll
-          for (int k2 = 0; k2 < 2; ++k2) {
-            const int row = 64 * wv + 16 * (2 * kp + k2) + lc;
-            const int sw = dst_swz(row);
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh) {
-              const bf16x4 pd4 = {(bf16)s[k2][qh][0], (bf16)s[k2][qh][1], (bf16)s[k2][qh][2], (bf16)s[k2][qh][3]};
-              const bf16x4 ds4 = {(bf16)dp[k2][qh][0], (bf16)dp[k2][qh][1], (bf16)dp[k2][qh][2], (bf16)dp[k2][qh][3]};
-              const int o = row * 64 + (((4 * qh + g) ^ sw) << 3);
-              *reinterpret_cast<bf16x4*>(hand_pd + o) = pd4;
-              *reinterpret_cast<bf16x4*>(hand_ds + o) = ds4;
-            }
-          }
-        }
-        WS_STAMP(0, 3);
-      }
-    } else {
-      // ================================================================================ consumer
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-      ATT_BARRIER();                       // K image landed
-      bf16x8 ktf[8];                       // K^T[d = 16 wv + lc][keys of the block], 32 keys per fragment
-      {
-        s16x4 lo[8], hi[8];
-        tr_seq<0, 32 * 128, 16 * 128>(lds_addr(smem) + tr_img_off(wv, lane), lo, hi, std::make_integer_sequence<int, 8>());
-        ATT_WAIT_LDS();
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) ktf[s8] = join8(lo[s8], hi[s8]);
-      }
-      ATT_BARRIER();  // the image is read out before the rings are filled
-      f32x4 dk[4][4], dv[4][4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          dk[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          dv[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      int off_tr[4];
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci) off_tr[ci] = tr_img_off(ci, lane);
-      // B-operand reads of the handed-over tiles: key row 64 wv + 16 ks + lc (1 KiB per ks: an immediate offset; 16 ks leaves
-      // the swizzle's row bits alone), queries 4 g .. + 3 and 16 + 4 g .. + 3
-      const int hrow = 64 * wv + lc;
-      const int hand_rd0 = hrow * 64 + (((0 + g) ^ dst_swz(hrow)) << 3), hand_rd1 = hrow * 64 + (((4 + g) ^ dst_swz(hrow)) << 3);
-      const int dst_rd0 = tr_dst_off(0, lane), dst_rd1 = tr_dst_off(1, lane);
-      issue(0, 0, 0);
-      issue(1, 1, 1);
-      issue(2, 2, 2);
-      __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4): tiles 0 and 1 have landed (this wave's share)
-      ATT_BARRIER();
-      rows_stat(0, 0);
-      int r_nx1 = 1, r_nx3 = 3, t_nx3 = 3, t_ct = W_TR_NST - 1;  // ring slots of tiles qt + 1, qt + 3 and of the consumed tile qt - 1
-#pragma unroll 1
-      for (int qt = 0; qt <= nqt; ++qt) {
-        // vm operations per step: [2 dQ read-backs] [4 DMA] [2 dQ stores].  Tile qt+1 must have landed: everything older than the
-        // previous step's eight (vmcnt(8)); in the first two steps the read-backs / stores do not exist yet (vmcnt(4)).
-        if (qt < 2)
-          __builtin_amdgcn_s_waitcnt(0x0074);
-        else
-          __builtin_amdgcn_s_waitcnt(0x0078);
-        ATT_BARRIER();
-        WS_STAMP(1, 0);
-        const int ct = qt - 1;  // the tile consumed in this step
-        bf16* dq_ptr[2];
-        bf16x4 dq_prev[2];
-        if (qt >= 1) {
-#pragma unroll
-          for (int qh = 0; qh < 2; ++qh) {
-            const int q = ct * WQ + 16 * qh + lc;
-            dq_ptr[qh] = p.dqkv + ((long)b * F + min(q, F - 1)) * ld + h * HD + 16 * wv + 4 * g;
-            dq_prev[qh] = *reinterpret_cast<const bf16x4*>(dq_ptr[qh]);
-          }
-        }
-        if (qt < nqt) issue(qt + 3, r_nx3, t_nx3);
-        if (qt >= 1) {
-          const char* hand_pd = smem + W_OFF_HAND + (ct & 1) * 2 * W_HAND;
-          const char* hand_ds = hand_pd + W_HAND;
-          const uint32_t tr_base = lds_addr(smem + W_OFF_TR + t_ct * W_TR_STAGE);  // Q transpose; dO transpose is FT further
-          // ---- dV^T += dO^T Pd, dK^T += Q^T dS for this wave's 64 keys: two d-block pairs, the B fragments streamed per sub-tile
-          WS_STAMP(1, 4);
-#pragma unroll
-          for (int i2 = 0; i2 < 4; i2 += 2) {
-            s16x4 qlo[2], qhi[2], dlo[2], dhi[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const uint32_t a = tr_base + off_tr[i2 + i];
-              qlo[i] = tr_read<0>(a);
-              qhi[i] = tr_read<16 * 128>(a);
-              dlo[i] = tr_read<FT>(a);
-              dhi[i] = tr_read<FT + 16 * 128>(a);
-            }
-            ATT_WAIT_LDS();
-            if (i2 == 0) WS_STAMP(1, 5);
-            const bf16x8 doa0 = join8(dlo[0], dhi[0]), qa0 = join8(qlo[0], qhi[0]);
-            const bf16x8 doa1 = join8(dlo[1], dhi[1]), qa1 = join8(qlo[1], qhi[1]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              const s16x4 p0 = *reinterpret_cast<const s16x4*>(hand_pd + hand_rd0 + 1024 * ks), p1 = *reinterpret_cast<const s16x4*>(hand_pd + hand_rd1 + 1024 * ks);
-              const s16x4 d0 = *reinterpret_cast<const s16x4*>(hand_ds + hand_rd0 + 1024 * ks), d1 = *reinterpret_cast<const s16x4*>(hand_ds + hand_rd1 + 1024 * ks);
-              const bf16x8 pdb = join8(p0, p1), dsb = join8(d0, d1);
-              dv[ks][i2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa0, pdb, dv[ks][i2], 0, 0, 0);
-              dk[ks][i2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, dsb, dk[ks][i2], 0, 0, 0);
-              dv[ks][i2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa1, pdb, dv[ks][i2 + 1], 0, 0, 0);
-              dk[ks][i2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, dsb, dk[ks][i2 + 1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (i2 == 0) WS_STAMP(1, 6);
-          }
-          WS_STAMP(1, 1);
-          // ---- dQ^T[16 wv + 4 g + r][16 qh + lc] = sum over the 256 keys K^T dS^T, one query sub-tile at a time
-          f32x4 acc[2];
-          const uint32_t dsa = lds_addr(hand_ds);
-#pragma unroll
-          for (int qh = 0; qh < 2; ++qh) {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};  // two chains
-            const uint32_t ad = dsa + (qh ? dst_rd1 : dst_rd0);
-            {
-              s16x4 lo[4], hi[4];
-              tr_seq<0, 32 * 64, 16 * 64>(ad, lo, hi, std::make_integer_sequence<int, 4>());
-              ATT_WAIT_LDS();
-#pragma unroll
-              for (int s8 = 0; s8 < 4; s8 += 2) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[s8], join8(lo[s8], hi[s8]), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[s8 + 1], join8(lo[s8 + 1], hi[s8 + 1]), a1, 0, 0, 0);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            {
-              s16x4 lo[4], hi[4];
-              tr_seq<4 * 32 * 64, 32 * 64, 16 * 64>(ad, lo, hi, std::make_integer_sequence<int, 4>());
-              ATT_WAIT_LDS();
-#pragma unroll
-              for (int s8 = 0; s8 < 4; s8 += 2) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[4 + s8], join8(lo[s8], hi[s8]), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[5 + s8], join8(lo[s8 + 1], hi[s8 + 1]), a1, 0, 0, 0);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            acc[qh] = a0 + a1;
-          }
-          const bool first = kb == 0;
-#pragma unroll
-          for (int qh = 0; qh < 2; ++qh) {
-            const bf16x4 out = {(bf16)(acc[qh][0] + (first ? 0.f : (float)dq_prev[qh][0])), (bf16)(acc[qh][1] + (first ? 0.f : (float)dq_prev[qh][1])),
-                                (bf16)(acc[qh][2] + (first ? 0.f : (float)dq_prev[qh][2])), (bf16)(acc[qh][3] + (first ? 0.f : (float)dq_prev[qh][3]))};
-            if (ct * WQ + 16 * qh + lc < F) *reinterpret_cast<bf16x4*>(dq_ptr[qh]) = out;
-          }
-        }
-        WS_STAMP(1, 2);
-        if (qt < nqt) rows_stat(qt + 1, r_nx1);  // its row ring stage landed before this step's barrier; published by the next one
-        WS_STAMP(1, 3);
-        r_nx1 = r_nx1 == W_ROWS_NST - 1 ? 0 : r_nx1 + 1;
-        r_nx3 = r_nx3 == W_ROWS_NST - 1 ? 0 : r_nx3 + 1;
-        t_nx3 = t_nx3 == W_TR_NST - 1 ? 0 : t_nx3 + 1;
-        t_ct = t_ct == W_TR_NST - 1 ? 0 : t_ct + 1;
-      }
-      const float inv_scale = 1.f / p.scale;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int key = key0 + 64 * wv + 16 * ks + lc;
-        if (key >= F) continue;
-        bf16* dkd = p.dqkv + ((long)b * F + key) * ld + H + h * HD + 4 * g;
-        bf16* dvd = dkd + H;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf16x4 a = {(bf16)dk[ks][i][0], (bf16)dk[ks][i][1], (bf16)dk[ks][i][2], (bf16)dk[ks][i][3]};
-          const bf16x4 c = {(bf16)(dv[ks][i][0] * inv_scale), (bf16)(dv[ks][i][1] * inv_scale), (bf16)(dv[ks][i][2] * inv_scale),
-                            (bf16)(dv[ks][i][3] * inv_scale)};
-          *reinterpret_cast<bf16x4*>(dkd + 16 * i) = a;
-          *reinterpret_cast<bf16x4*>(dvd + 16 * i) = c;
-        }
-      }
-    }
-  }
-}
-
 AttnParams make_params(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens, const bf16* dctx, float* delta, bf16* dqkv,
                        int B, int F, int nh, int H, const DropSpec& drop) {
   AttnParams p;
@@ -1563,15 +1135,6 @@ AttnParams make_params(const bf16* qkv, bf16* ctx, float* lse, const int32_t* kl
   return p;
 }
 
-int g_attn_bwd_mode = -1;  // -1: environment SSAK_ATTN_BWD decides ("fused" = the single-pass kernel); 0 fused single pass; 1 two-kernel form (default)
-int attn_bwd_mode() {
-  if (g_attn_bwd_mode < 0) {
-    const char* e = getenv("SSAK_ATTN_BWD");
-    g_attn_bwd_mode = (e && e[0] == 'w') ? 0 : (e && e[0] == 'f') ? 2 : 1;  // "ws" | "fused" | default: two kernels
-  }
-  return g_attn_bwd_mode;
-}
-
 // Per-wave tile of the three kernels (SSAK_ATTN_TILE="f,q,k", each 1 or 2; development switch).  The kernels are bound by
 // how many waves per SIMD are in their VALU phase at once (tools/probes/valu_rate.hip: one wave issues a VALU instruction
 // every ~6 cycles, the SIMD takes one every 3-4), so the smaller per-wave state of a 16-row tile can pay for its extra LDS reads.
@@ -1579,19 +1142,13 @@ int attn_tile(int which) {
   static int t[3] = {-1, -1, -1};
   if (t[0] < 0) {
     int v[3] = {2, 2, 2};
-    if (const char* e = getenv("SSAK_ATTN_TILE")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+    if (const char* e = SSAK_DEV_ENV("SSAK_ATTN_TILE")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
     for (int i = 0; i < 3; ++i) t[i] = v[i] == 1 ? 1 : 2;
   }
   return t[which];
 }
 
 }  // namespace
-
-extern "C" int ssak_attention_bwd_mode(int mode) {
-  SSAK_REQUIRE(mode >= 0 && mode <= 2, "attention_bwd_mode: %d (0 wave-specialised single pass, 1 two kernels, 2 single pass)", mode);
-  g_attn_bwd_mode = mode;
-  return SSAK_OK;
-}
 
 bool k_attention_supported(int H, int nh) { return nh > 0 && H / nh == HD && H % nh == 0; }
 
@@ -1614,25 +1171,12 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens
 }
 
 int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const int32_t* klens, const bf16* dctx, float* delta,
-                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, hipStream_t st) {
+                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode, hipStream_t st) {
   SSAK_REQUIRE(k_attention_supported(H, nh), "attention: fused kernels are built for head_dim 64 (got %d)", nh ? H / nh : 0);
+  SSAK_REQUIRE(mode >= 0 && mode <= 2, "attention_bwd: mode %d (0 / 1 = two kernels, the default; 2 = fused single pass)", mode);
   const AttnParams p = make_params(qkv, const_cast<bf16*>(ctx), const_cast<float*>(lse), klens, dctx, delta, dqkv, B, F, nh, H, drop);
   ProfScope prof_scope(PROF_ATTN_BWD, 8.0 * B * nh * (double)F * F * HD, st);  // dV, dP, dQ, dK (the recomputed S is not algorithmic work)
-  if (attn_bwd_mode() == 0) {  // wave-specialised single pass
-    static bool ws_attr = false;
-    if (!ws_attr) {
-      SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
-      SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
-      ws_attr = true;
-    }
-    if (p.thresh16)
-      attn_bwd_ws_kernel<true><<<dim3(nh, B), 512, W_LDS, st>>>(p);
-    else
-      attn_bwd_ws_kernel<false><<<dim3(nh, B), 512, W_LDS, st>>>(p);
-    SSAK_LAUNCH_CHECK();
-    return SSAK_OK;
-  }
-  if (attn_bwd_mode() == 2) {  // single pass, every wave in every role (4-wave workgroups)
+  if (mode == SSAK_ATTN_BWD_FUSED) {  // single pass, every wave in every role (4-wave workgroups)
     static bool fused_attr = false;
     if (!fused_attr) {
       SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
@@ -1688,12 +1232,12 @@ extern "C" int ssak_attention_fwd(const void* qkv, void* ctx, float* lse, const 
 
 extern "C" int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx,
                                   float* delta, void* dqkv, int B, int F, int nh, int H, float drop_p, uint64_t seed,
-                                  uint32_t stream_id, void* stream) {
+                                  uint32_t stream_id, int mode, void* stream) {
   SSAK_REQUIRE(qkv && ctx && lse && dctx && delta && dqkv, "attention_bwd: null pointer");
   DropSpec d;
   d.p = drop_p;
   d.seed = seed;
   d.stream = stream_id;
-  return k_attention_bwd((const bf16*)qkv, (const bf16*)ctx, lse, klens, (const bf16*)dctx, delta, (bf16*)dqkv, B, F, nh, H, d,
+  return k_attention_bwd((const bf16*)qkv, (const bf16*)ctx, lse, klens, (const bf16*)dctx, delta, (bf16*)dqkv, B, F, nh, H, d, mode,
                          (hipStream_t)stream);
 }

@@ -243,6 +243,13 @@ __device__ __forceinline__ float gelu_grad_s(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
   else return gelu_grad_f(x);
 }
+// Development switches read from the environment exist only in builds made with -DSSAK_DEV (`make DEV=1`); in the release
+// library the expression is a null constant and the code behind it folds away.
+#ifdef SSAK_DEV
+#define SSAK_DEV_ENV(name) getenv(name)
+#else
+#define SSAK_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 // counter-based RNG for dropout masks: the forward and backward kernels recompute the same bits from
 // (seed, stream, element index); no mask tensor is stored.  "lowbias32" mixer: 2 integer multiplies (v_mul_lo_u32 is
 // a slow VALU op; the GEMM epilogues and the attention kernels were VALU-bound on a 3-multiply hash).

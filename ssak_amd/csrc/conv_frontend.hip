@@ -747,7 +747,7 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
   ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * sizeof(OT)), st);  // waveform in, channels-last out
   double* sums = stats;
   double* partial = stats + (size_t)B * 2 * C;
-  static const bool direct_stats = getenv("SSAK_CONV0_DIRECT_STATS") != nullptr;  // development: the convolution-pass statistics
+  static const bool direct_stats = SSAK_DEV_ENV("SSAK_CONV0_DIRECT_STATS") != nullptr;  // development: the convolution-pass statistics
   if (direct_stats) {
     conv0_kernel<OT, false, FR_STATS><<<dim3(nblk, B), 256, 0, st>>>(x, w, gamma, beta, out, partial, nullptr, T, T0, C);
     SSAK_LAUNCH_CHECK();
@@ -759,7 +759,7 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
     conv0_channel_stats_kernel<<<dim3(ssak_cdiv(C, 256), B), 256, 0, st>>>(partial, nblk, w, C, sums);
     SSAK_LAUNCH_CHECK();
   }
-  static const bool no_mfma = getenv("SSAK_CONV0_VALU") != nullptr;  // development: the VALU apply pass
+  static const bool no_mfma = SSAK_DEV_ENV("SSAK_CONV0_VALU") != nullptr;  // development: the VALU apply pass
   if constexpr (sizeof(OT) == 2) {
     if (C == 512 && !no_mfma) {
       conv0_mfma_kernel<<<dim3(ssak_cdiv(T0, C0M_FR), B), 256, 0, st>>>(x, w, gamma, beta, (bf16*)out, sums, T, T0);

@@ -528,7 +528,7 @@ extern "C" int ssak_ctc_loss_fwd_bwd(const float* logits, const int32_t* in_lens
   ProfScope prof_scope(PROF_CTC, (double)B * F * V * 4.0 * (dlogits ? 2 : 1), st);  // logits in, gradient out
   float* ws = (float*)workspace;
   const int Smax = 2 * Lmax + 1;
-  static const bool env_mono = getenv("SSAK_CTC_MONOLITHIC") != nullptr;  // development switch
+  static const bool env_mono = SSAK_DEV_ENV("SSAK_CTC_MONOLITHIC") != nullptr;  // development switch
   if (Smax <= 1024 && Lmax >= 1 && !env_mono) {
     // wave-resident lattice: lp [B,F,V] | lattices [B][2][F][Spad] | wnll [B] | info [B][4]
     const int Spad = (Smax + 3) & ~3;

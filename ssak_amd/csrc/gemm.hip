@@ -729,9 +729,9 @@ struct GemmPlan {
 int g_env_p8 = -2, g_env_p8_bm = 0;
 GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
   if (g_env_p8 == -2) {
-    const char* v = getenv("SSAK_GEMM_P8");  // development switches: 0 = never, 1 = whenever it applies
+    const char* v = SSAK_DEV_ENV("SSAK_GEMM_P8");  // development switches: 0 = never, 1 = whenever it applies
     g_env_p8 = v ? atoi(v) : -1;
-    v = getenv("SSAK_GEMM_P8_BM");
+    v = SSAK_DEV_ENV("SSAK_GEMM_P8_BM");
     g_env_p8_bm = v ? atoi(v) : 0;
   }
   const int nkt = ssak_cdiv(d->K, BK);
@@ -794,7 +794,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   const bool dma = d->pads_are_zero || !(partial_a || partial_b);
   const GemmPlan plan = plan_gemm(d, dma, workspace ? workspace_bytes : 0);
   const int split = plan.split;
-  static const bool env_trace = getenv("SSAK_GEMM_TRACE") != nullptr;  // development: one line per launch
+  static const bool env_trace = SSAK_DEV_ENV("SSAK_GEMM_TRACE") != nullptr;  // development: one line per launch
   if (env_trace)
     fprintf(stderr, "gemm M=%d N=%d K=%d akm=%d bkm=%d nb=%dx%d epi=%d f32=%d acc=%d drop=%g dma=%d -> %s bm=%d split=%d cost=%.1f\n", d->M,
             d->N, d->K, d->a_kmajor, d->b_kmajor, d->nb1, d->nb2, d->epilogue, d->out_f32, d->accumulate, d->drop_p, (int)dma,
@@ -836,6 +836,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   p.epilogue = d->epilogue;
   p.out_f32 = d->out_f32;
   p.accumulate = d->accumulate;
+  p.dynamic = d->dynamic_tiles;
   p.split_k = split;
   p.nz = d->nb1 * d->nb2;
   // 16-bit dropout uniforms in the epilogue: threshold = round(p * 65536), scale from the realised keep probability
@@ -864,7 +865,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   hipStream_t st = (hipStream_t)stream;
   int rc;
   static const bool env_no_big = [] {
-    const char* nb = getenv("SSAK_GEMM_NO_BIG");
+    const char* nb = SSAK_DEV_ENV("SSAK_GEMM_NO_BIG");
     return nb && nb[0] == '1';
   }();
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
@@ -877,7 +878,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     // Toeplitz A (conv as GEMM, rows overlap: lda < K): visit the K tiles so that the two reads of the same bytes -- tap t + s of
     // row i is tap t of row i + 1 -- are one K step apart instead of lda / BK steps (gemm_common.h: kperm_*)
     static const bool env_no_perm = [] {
-      const char* e = getenv("SSAK_GEMM_NO_KPERM");
+      const char* e = SSAK_DEV_ENV("SSAK_GEMM_NO_KPERM");
       return e && e[0] == '1';
     }();
     if (!d->a_kmajor && split == 1 && d->K % BK == 0 && d->lda % BK == 0 && d->lda < d->K && !env_no_perm) {
@@ -899,8 +900,8 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   } else {
     p.tiles_m = ssak_cdiv(d->M, 128);
     p.tiles_n = ssak_cdiv(d->N, 64);
-    static const bool env_no_n48 = getenv("SSAK_GEMM_NO_N48") != nullptr;  // development switches
-    static const bool env_n48_128 = getenv("SSAK_GEMM_N48_128") != nullptr;
+    static const bool env_no_n48 = SSAK_DEV_ENV("SSAK_GEMM_NO_N48") != nullptr;  // development switches
+    static const bool env_n48_128 = SSAK_DEV_ENV("SSAK_GEMM_N48_128") != nullptr;
     if (dma && d->N > 32 && d->N <= 48 && !env_no_n48 && !env_n48_128 && d->M >= 256 && !d->a_kmajor && !d->b_kmajor) {
       // K-contiguous operands: 256-row tiles -- twice the MFMA work per K step behind the same LDS-DMA round trip (this two-stage
       // kernel is latency-bound): 437 -> 378 us per step for the three forward / dX launches.  (K-major operands, the weight
@@ -983,6 +984,7 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
   p.epilogue = SSAK_EPI_NONE;
   p.out_f32 = d0.out_f32;
   p.accumulate = d0.accumulate;
+  p.dynamic = d0.dynamic_tiles;
   p.split_k = 1;
   p.drop_scale = 1.f;
   p.kt_per_split = ssak_cdiv(d0.K, BK);

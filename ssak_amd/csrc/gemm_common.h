@@ -29,6 +29,7 @@ struct GemmParams {
   long bias_s2;
   uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
   float* colsum;          // [wave-tile rows][N] column sums of the stored values (bias gradient of the producing Linear) or null
+  int dynamic;            // ssak_gemm_desc.dynamic_tiles: draw tiles from ticket counters (persistent kernels)
   int* tile_ctr;          // persistent kernels: [0] = tickets handed out past the first round, [1] = workgroups done (or null: static)
   // K-tile visiting order of the persistent kernel for a Toeplitz A (conv as GEMM: lda = stride * C < K = k * C, so K tile kt
   // of row i + 1 IS K tile kt + kperm_p of row i): the first 2 * kperm_n2 steps visit (c, c + kperm_p) pairs, so the second

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
   // same moment, the 32 MB burst of a round takes 2.7 us (bf16) to 8 us (GELU + saved pre-activation) to drain at HBM
   // speed, and the pipeline fill of a fresh workgroup costs another 2 us -- all of it used to be exposed.
   // Tile order.  Static (tile_ctr == null, the single-GPU default): workgroup b takes logical ids b, b + grid, ...
-  // Dynamic (data-parallel runs): a workgroup draws every tile from a ticket counter, so that one which starts late -- its
+  // Dynamic (ssak_gemm_desc.dynamic_tiles; data-parallel runs): a workgroup draws every tile from a ticket counter, so that one which starts late -- its
   // CU held by another stream's kernel, e.g. the RCCL all-reduce of the previous layer's gradients -- simply takes fewer
   // tiles.  With the static stride such a workgroup ran its whole share after everyone else had finished
   // (tools/probes/hog_probe.hip: 32 busy CUs made these GEMMs 1.8x slower, not 1.14x).  There is one counter per XCD
@@ -541,15 +541,6 @@ int p8_num_cu(int* out) {
   return SSAK_OK;
 }
 
-int g_p8_dynamic = -1;  // -1: not set (environment SSAK_GEMM_DYNAMIC_TILES decides, default static)
-bool p8_dynamic() {
-  if (g_p8_dynamic < 0) {
-    const char* e = getenv("SSAK_GEMM_DYNAMIC_TILES");
-    g_p8_dynamic = (e && e[0] == '1') ? 1 : 0;
-  }
-  return g_p8_dynamic == 1;
-}
-
 template <int MH, bool A_KM, bool B_KM, int EPI = -1>
 int launch_p8(const GemmParams& p, hipStream_t st) {
   auto kern = gemm_p8_kernel<MH, A_KM, B_KM, false, EPI>;
@@ -566,7 +557,7 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
   none.total_tiles = 0;
   GemmParams q = p;
   q.tile_ctr = nullptr;
-  if (ntiles > n_cu && n_cu % 8 == 0 && p8_dynamic())
+  if (ntiles > n_cu && n_cu % 8 == 0 && p.dynamic)
     if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
   static int slot = -1;
   if (slot < 0) {
@@ -619,7 +610,7 @@ int launch_p8_grouped(const GemmParams& p, const P8Group& grp, hipStream_t st) {
   if (int rc = p8_num_cu(&n_cu)) return rc;
   GemmParams q = p;
   q.tile_ctr = nullptr;
-  if (grp.total_tiles > n_cu && n_cu % 8 == 0 && p8_dynamic())
+  if (grp.total_tiles > n_cu && n_cu % 8 == 0 && p.dynamic)
     if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
   static int slot = -1;
   if (slot < 0) {
@@ -636,11 +627,6 @@ int launch_p8_grouped(const GemmParams& p, const P8Group& grp, hipStream_t st) {
 }
 
 }  // namespace
-
-extern "C" int ssak_gemm_tile_order(int dynamic) {
-  g_p8_dynamic = dynamic ? 1 : 0;
-  return SSAK_OK;
-}
 
 int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);

@@ -11,7 +11,7 @@ enum : int {
 };
 constexpr int PROF_MAX_SLOTS = 128;
 int ssak_prof_register(const char* name, int bound);  // -> slot id (idempotent per name); thread-safe
-bool ssak_prof_wanted(int slot);
+bool ssak_prof_wanted(int slot, hipStream_t st);
 // Brackets everything launched on `st` during its lifetime when the slot is being profiled; `work` = the ALGORITHMIC flops
 // (MFMA-bound slots) or bytes (HBM / latency-bound slots) of what it covers.
 class ProfScope {
@@ -140,7 +140,7 @@ bool k_attention_supported(int H, int nh);
 int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens, int B, int F, int nh, int H,
                     const DropSpec& drop, hipStream_t st);
 int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const int32_t* klens, const bf16* dctx, float* delta,
-                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, hipStream_t st);
+                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode /* SSAK_ATTN_BWD_* */, hipStream_t st);
 
 // whisper_frontend.hip
 int k_mel_to_cl(const float* mel, bf16* cl, int B, int C, int T, int RS, int lead, hipStream_t st);

@@ -26,7 +26,7 @@ namespace {
 
 constexpr int WGRAD_SETS = 12;  // most buffer sets of the queued weight-gradient operands = layers per grouped launch (4 products each: ssak_gemm_bf16_grouped takes 48)
 bool wgrad_all() {
-  static const bool v = getenv("SSAK_WGRAD_ALL") != nullptr;  // development switch: see the workspace plan
+  static const bool v = SSAK_DEV_ENV("SSAK_WGRAD_ALL") != nullptr;  // development switch: see the workspace plan
   return v;
 }
 
@@ -119,6 +119,9 @@ struct ssak_w2v2 {
   void* on_ready_user = nullptr;
   // optimizer on a side stream: the forward waits for this event before its first read of a trainable parameter
   hipEvent_t params_ready = nullptr, stall_begin = nullptr, stall_end = nullptr;
+  // per-handle execution options (ssak_w2v2_set_option)
+  int dynamic_tiles = 0;
+  int attn_bwd_mode = SSAK_ATTN_BWD_DEFAULT;
 };
 
 namespace {
@@ -434,6 +437,15 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
   return SSAK_OK;
 }
 
+// Options of the handle whose forward / backward is running on this thread: the product builder below reads them, so the
+// ~60 call sites do not each pass them.  Scoped to one entry-point call (EngineCall), never process-wide.
+thread_local int t_dynamic_tiles = 0;
+struct EngineCall {
+  int saved;
+  explicit EngineCall(const ssak_w2v2* e) : saved(t_dynamic_tiles) { t_dynamic_tiles = e->dynamic_tiles; }
+  ~EngineCall() { t_dynamic_tiles = saved; }
+};
+
 struct Gemm {
   ssak_gemm_desc d;
   const void* A = nullptr;
@@ -445,6 +457,7 @@ struct Gemm {
   bool f32 = false;  // fp32-exact mode: float operands through ssak_gemm_f32
   Gemm(int M, int N, int K, bool exact = false) : f32(exact) {
     memset(&d, 0, sizeof(d));
+    d.dynamic_tiles = t_dynamic_tiles;  // the calling handle's option (EngineCall)
     d.M = M;
     d.N = N;
     d.K = K;
@@ -662,6 +675,20 @@ extern "C" int ssak_w2v2_bind(ssak_w2v2* e, float* params, float* grads, void* s
   return SSAK_OK;
 }
 
+extern "C" int ssak_w2v2_set_option(ssak_w2v2* e, int option, int value) {
+  SSAK_REQUIRE(e, "w2v2_set_option: null handle");
+  if (option == SSAK_W2V2_OPT_DYNAMIC_TILES) {
+    e->dynamic_tiles = value ? 1 : 0;
+  } else if (option == SSAK_W2V2_OPT_ATTENTION_BWD) {
+    SSAK_REQUIRE(value >= SSAK_ATTN_BWD_DEFAULT && value <= SSAK_ATTN_BWD_FUSED, "w2v2_set_option: attention backward form %d", value);
+    e->attn_bwd_mode = value;
+  } else {
+    ssak_set_error("w2v2_set_option: unknown option %d", option);
+    return SSAK_ERR_INVALID;
+  }
+  return SSAK_OK;
+}
+
 extern "C" int ssak_w2v2_set_grad_ready_callback(ssak_w2v2* e, ssak_grad_ready_fn fn, void* user) {
   SSAK_REQUIRE(e, "w2v2_set_grad_ready_callback: null handle");
   e->on_ready = fn;
@@ -770,6 +797,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   SSAK_REQUIRE(B > 0 && T > 0, "w2v2_forward: bad shape B=%d T=%d", B, T);
   SSAK_REQUIRE(((uintptr_t)workspace & 255) == 0, "w2v2_forward: workspace must be 256-byte aligned");
   constexpr bool EXACT = sizeof(AT) == 4;  // fp32-exact verification mode (ssak_w2v2_config.exact)
+  EngineCall engine_call(e);
   Plan& p = e->plan;
   e->have_fwd = false;
   TRY(make_plan(e, B, T, training, p));
@@ -1028,6 +1056,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     return SSAK_ERR_STATE;
   }
   constexpr bool EXACT = sizeof(AT) == 4;
+  EngineCall engine_call(e);
   SSAK_REQUIRE(e->G, "w2v2_backward: no gradient buffer bound");
   Plan& p = e->plan;
   SSAK_REQUIRE(workspace_bytes >= p.total, "w2v2_backward: workspace too small");
@@ -1235,7 +1264,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     if (p.fused_attn) {
       if constexpr (!EXACT)
         TRY(k_attention_bwd(qkv, BF(lb.ctx), FP(lb.lse), flens, dctx, FP(p.delta), dqkv, B, F, nh, H,
-                            DS(c.attention_dropout, ds_attn(l)), st));
+                            DS(c.attention_dropout, ds_attn(l)), e->attn_bwd_mode, st));
     } else {
       TRY(GemmX<EXACT>(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
               .batch(B, nh, sp1, sp2, sh1, hd, sq1, hd).run(st));  // dV = Pd^T dctx

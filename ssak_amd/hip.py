@@ -11,7 +11,9 @@ import os
 
 import torch
 
-_LIB_PATH = os.environ.get("SSAK_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")  # (the override is for A/B runs of two builds)
+_DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")
+_LIB_PATH = os.environ.get("SSAK_HIP_LIB") or _DEFAULT_LIB  # (the override names another build OF THE SAME ABI: A/B runs, instrumented builds)
+ABI_VERSION = 300  # ssak_version() of the library this binding's struct layouts and signatures were written for
 
 
 class GemmDesc(C.Structure):
@@ -20,7 +22,8 @@ class GemmDesc(C.Structure):
                 ("sa1", C.c_long), ("sa2", C.c_long), ("sb1", C.c_long), ("sb2", C.c_long), ("sc1", C.c_long),
                 ("sc2", C.c_long), ("alpha", C.c_float), ("epilogue", C.c_int), ("out_f32", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
-                ("drop_seed", C.c_uint64), ("bias_s2", C.c_long), ("pads_are_zero", C.c_int), ("colsum", C.c_int)]
+                ("drop_seed", C.c_uint64), ("bias_s2", C.c_long), ("pads_are_zero", C.c_int), ("colsum", C.c_int),
+                ("dynamic_tiles", C.c_int)]
 
 
 class W2V2Config(C.Structure):
@@ -72,14 +75,12 @@ def _load():
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp]),
         "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
-        "ssak_gemm_tile_order": (i32, [i32]),
-        "ssak_attention_bwd_mode": (i32, [i32]),
         "ssak_conv0_workspace_bytes": (sz, [i32, i32, i32]),
         "ssak_conv0_gn_gelu": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
-        "ssak_prof_enable": (i32, [i32]),
-        "ssak_prof_collect": (i32, [C.POINTER(ProfEntry), i32]),
+        "ssak_prof_enable": (i32, [vp, i32]),
+        "ssak_prof_collect": (i32, [vp, C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
-        "ssak_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
+        "ssak_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, i32, vp]),
         "ssak_grad_sumsq": (i32, [vp, C.c_long, vp, vp, sz, vp]),
         "ssak_adamw_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
         "ssak_w2v2_create": (i32, [C.POINTER(W2V2Config), C.POINTER(vp)]),
@@ -97,6 +98,7 @@ def _load():
         "ssak_w2v2_backward": (i32, [vp, vp, vp, sz, vp]),
         "ssak_w2v2_set_grad_ready_callback": (i32, [vp, GRAD_READY_FN, vp]),
         "ssak_w2v2_set_param_event": (i32, [vp, vp, vp, vp]),
+        "ssak_w2v2_set_option": (i32, [vp, i32, i32]),
         "ssak_w2v2_grad_ranges": (i32, [C.POINTER(W2V2Config), C.POINTER(C.c_long), C.POINTER(C.c_long), i32]),
         "ssak_w2v2_forward_hidden": (i32, [vp, vp, vp, i32, i32, vp, vp, C.c_uint64, i32, vp, vp, vp, sz, vp]),
         "ssak_w2v2_backward_hidden": (i32, [vp, vp, vp, sz, vp]),
@@ -118,14 +120,15 @@ def _load():
         "ssak_debug_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, C.c_long, vp, C.POINTER(f32), vp]),
         "ssak_debug_attention_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, i32, i32, i32, vp, vp]),
     }
-    ab_override = bool(os.environ.get("SSAK_HIP_LIB"))  # an older build named explicitly for a same-box A/B (tools/ab.sh)
+    lib.ssak_version.restype = i32
+    got = lib.ssak_version()
+    if got != ABI_VERSION:
+        # struct layouts (GemmDesc, W2V2Config, ProfEntry) and signatures belong to ONE ABI: driving another build through
+        # this table would pass arguments at the wrong offsets, so refuse it instead of skipping what it lacks
+        raise ImportError(f"{_LIB_PATH} reports ABI {got}, this binding is written for {ABI_VERSION}: rebuild with `make`"
+                          + (" (SSAK_HIP_LIB must name a build of the same ABI)" if os.environ.get("SSAK_HIP_LIB") else ""))
     for name, (res, args) in sig.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError:
-            if ab_override:
-                continue  # entry points newer than the A/B baseline: calling one still raises
-            raise
+        fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     return lib
 
@@ -249,11 +252,12 @@ def ctc_wer(hyp_ids: torch.Tensor, hyp_lens: torch.Tensor, labels: torch.Tensor,
 
 def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
-         accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0, pads_are_zero=False, colsum_out=None):
+         accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0, pads_are_zero=False, colsum_out=None,
+         dynamic_tiles=False):
     """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h)."""
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
                  sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k, float(drop_p),
-                 drop_stream, drop_seed, 0, int(pads_are_zero), int(colsum_out is not None))
+                 drop_stream, drop_seed, 0, int(pads_are_zero), int(colsum_out is not None), int(dynamic_tiles))
     n_slabs = split_k if split_k > 0 else max(1, min(32, ((K + 63) // 64) // 4))  # 0 = library-sized split
     ws = _ws(n_slabs * nb1 * nb2 * M * N * 4, A.device) if n_slabs > 1 else None
     if colsum_out is not None:
@@ -270,14 +274,14 @@ def gemm_f32(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, 
     """The fp32 GEMM of the exact mode (``ssak_gemm_f32``): same descriptor as :func:`gemm`, float tensors."""
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
                  sc[1], float(alpha), epilogue, 1, int(accumulate), 1, float(drop_p), drop_stream, drop_seed, bias_s2, 0,
-                 int(colsum_out is not None))
+                 int(colsum_out is not None), 0)
     if colsum_out is not None:
         aux_out = colsum_out
     check(lib.ssak_gemm_f32(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), stream()))
     return C_out
 
 
-def gemm_grouped(problems, stream_=None):
+def gemm_grouped(problems, stream_=None, dynamic_tiles=False):
     """problems: list of (A, B, C_out, M, N, K, lda, ldb, ldc) sharing K / layouts (a_kmajor, b_kmajor passed per call via
     keyword in each tuple's dict is not needed: the weight-gradient form is k-major on both operands)."""
     n = len(problems)
@@ -285,14 +289,15 @@ def gemm_grouped(problems, stream_=None):
     pa, pb, pc = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
     for i, (A, B, Cout, M, N, K, lda, ldb, ldc, akm, bkm) in enumerate(problems):
         descs[i] = GemmDesc(M, N, K, int(akm), int(bkm), lda, ldb, ldc, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0,
-                            int(Cout.dtype == torch.float32), 0, 1, 0.0, 0, 0, 0, 1, 0)
+                            int(Cout.dtype == torch.float32), 0, 1, 0.0, 0, 0, 0, 1, 0, int(dynamic_tiles))
         pa[i], pb[i], pc[i] = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
     check(lib.ssak_gemm_bf16_grouped(descs, n, pa, pb, pc, stream()))
 
 
 def prof_enable(mode: int):
-    """0 = off, 1 = every launch, 2 + i = only the slot at index i of :func:`prof_collect`'s list."""
-    check(lib.ssak_prof_enable(int(mode)))
+    """Launch timing on the CURRENT stream: 0 = off, 1 = every launch, 2 + i = only the slot at index i of
+    :func:`prof_collect`'s list.  Per stream: other streams / handles are neither slowed nor recorded."""
+    check(lib.ssak_prof_enable(stream(), int(mode)))
 
 
 BOUNDS = {0: "mfma", 1: "hbm", 2: "latency"}
@@ -302,7 +307,7 @@ def prof_collect():
     """[(kernel name, launches, total ms, total algorithmic work, bound)] since the last collect; work = flops for "mfma"
     slots, bytes for "hbm" / "latency" slots."""
     arr = (ProfEntry * 128)()
-    n = lib.ssak_prof_collect(arr, 128)
+    n = lib.ssak_prof_collect(stream(), arr, 128)
     if n < 0:
         check(n)
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops, BOUNDS[arr[i].bound]) for i in range(n)]
@@ -331,18 +336,18 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
     return ctx, lse
 
 
-def attention_bwd_mode(mode):
-    """1 / True (the default): two-kernel backward (dQ; dK + dV); 0 / False: the wave-specialised single-pass kernel;
-    2: the single-pass kernel with every wave in every role."""
-    check(lib.ssak_attention_bwd_mode(int(mode)))
+ATTN_BWD_DEFAULT, ATTN_BWD_TWO_KERNEL, ATTN_BWD_FUSED = 0, 1, 2
+W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD = 1, 2
 
 
-def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0):
+def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0,
+                  mode=ATTN_BWD_DEFAULT):
+    """``mode``: ATTN_BWD_TWO_KERNEL (= default: dQ; dK + dV) or ATTN_BWD_FUSED (one pass), per call."""
     H = qkv.shape[1] // 3
     dqkv = torch.full_like(qkv, float("nan"))  # poisoned: the kernels write every element
     delta = torch.empty((B, nh, F), dtype=torch.float32, device=qkv.device)
     if klens is not None:
         klens = klens.to(device=qkv.device, dtype=torch.int32).contiguous()
     check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), ptr(klens), ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H,
-                                 float(drop_p), seed, stream_id, stream()))
+                                 float(drop_p), seed, stream_id, int(mode), stream()))
     return dqkv

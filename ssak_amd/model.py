@@ -389,6 +389,11 @@ class Wav2Vec2ForCTC:
         if exc is not None:
             raise exc
 
+    def set_option(self, option: int, value: int):
+        """Per-handle execution options (``ssak_w2v2_set_option``): hip.W2V2_OPT_DYNAMIC_TILES (ticket tile order of the
+        persistent GEMMs, for data-parallel runs), hip.W2V2_OPT_ATTENTION_BWD (hip.ATTN_BWD_*)."""
+        hip.check(hip.lib.ssak_w2v2_set_option(self._h, int(option), int(value)))
+
     def set_param_event(self, event: Optional[torch.cuda.Event], stall_begin=None, stall_end=None):
         """The optimizer runs on a side stream: ``event`` is recorded there after the update; every forward waits for it at
         its first read of a trainable parameter (``ssak_w2v2_set_param_event``).  The host-side accessors wait through

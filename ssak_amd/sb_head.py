@@ -96,6 +96,7 @@ class CTCHead:
         self.slope, self.bn_eps, self.bn_momentum = leaky_slope, bn_eps, bn_momentum
         self.training = True
         self.sync_bn = False  # set by Brain under data parallelism: BatchNorm statistics over the global batch
+        self.dynamic_tiles = False  # set by Brain under data parallelism: ticket tile order of the persistent GEMMs
         self.layout: Dict[str, tuple] = {}
         cur = 0
 
@@ -218,7 +219,7 @@ class CTCHead:
                 din = h.shape[1]
                 a = torch.empty((M, D), dtype=torch.bfloat16, device=self.device)
                 hip.gemm(h, self._shadow(f"0.linear{i + 1}.w.weight"), a, M, D, din, lda=din, ldb=din, ldc=D,
-                         bias=self.param(f"0.linear{i + 1}.w.bias"))
+                         bias=self.param(f"0.linear{i + 1}.w.bias"), dynamic_tiles=self.dynamic_tiles)
                 y = torch.empty_like(a)
                 mean = torch.empty(D, dtype=torch.float32, device=self.device)
                 rstd = torch.empty(D, dtype=torch.float32, device=self.device)
@@ -235,7 +236,7 @@ class CTCHead:
                 saved.append((h, a, mean, rstd))
                 h = y
             logits = torch.empty((B, F, self.Vp), dtype=torch.float32, device=self.device)
-            hip.gemm(h, self._shadow("1.w.weight"), logits, M, self.Vp, D, lda=D, ldb=D, ldc=self.Vp, bias=self.param("1.w.bias"))
+            hip.gemm(h, self._shadow("1.w.weight"), logits, M, self.Vp, D, lda=D, ldb=D, ldc=self.Vp, bias=self.param("1.w.bias"), dynamic_tiles=self.dynamic_tiles)
         if tr:
             self.num_batches_tracked += 1
         self._saved = (saved, h, self._seed, (B, F)) if tr else None
@@ -261,10 +262,10 @@ class CTCHead:
             d = torch.empty((M, Vp), dtype=torch.bfloat16, device=dev)
             hip.check(hip.lib.ssak_cast_f32_bf16(hip.ptr(dlogits), hip.ptr(d), M * Vp, st))
             # ctc_lin: dW = d^T h, db = column sums of d, dh = d W
-            hip.gemm(d, h_last, self.grad("1.w.weight"), Vp, D, M, a_kmajor=True, b_kmajor=True, lda=Vp, ldb=D, ldc=D, split_k=0)
+            hip.gemm(d, h_last, self.grad("1.w.weight"), Vp, D, M, a_kmajor=True, b_kmajor=True, lda=Vp, ldb=D, ldc=D, split_k=0, dynamic_tiles=self.dynamic_tiles)
             colsum(d, Vp, self.grad("1.w.bias"))
             dh = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
-            hip.gemm(d, self._shadow("1.w.weight"), dh, M, D, Vp, lda=Vp, b_kmajor=True, ldb=D, ldc=D)
+            hip.gemm(d, self._shadow("1.w.weight"), dh, M, D, Vp, lda=Vp, b_kmajor=True, ldb=D, ldc=D, dynamic_tiles=self.dynamic_tiles)
             for i in reversed(range(self.nblk)):
                 h_in, a, mean, rstd = saved[i]
                 din = h_in.shape[1]
@@ -283,11 +284,11 @@ class CTCHead:
                     hip.check(hip.lib.ssak_batchnorm_act_bwd(hip.ptr(dh), hip.ptr(a), hip.ptr(da), *bn_args, None, None,
                                                              hip.ptr(self._bn_ws), self._bn_ws.numel(), st))
                 hip.gemm(da, h_in, self.grad(f"0.linear{i + 1}.w.weight"), D, din, M, a_kmajor=True, b_kmajor=True, lda=D, ldb=din,
-                         ldc=din, split_k=0)
+                         ldc=din, split_k=0, dynamic_tiles=self.dynamic_tiles)
                 colsum(da, D, self.grad(f"0.linear{i + 1}.w.bias"))
                 if i > 0 or need_input_grad:
                     dh = torch.empty((M, din), dtype=torch.bfloat16, device=dev)
-                    hip.gemm(da, self._shadow(f"0.linear{i + 1}.w.weight"), dh, M, din, D, lda=D, b_kmajor=True, ldb=din, ldc=din)
+                    hip.gemm(da, self._shadow(f"0.linear{i + 1}.w.weight"), dh, M, din, D, lda=D, b_kmajor=True, ldb=din, ldc=din, dynamic_tiles=self.dynamic_tiles)
                 else:
                     dh = None
         self._saved = None
@@ -351,7 +352,9 @@ class Brain:
         self.world = torch.distributed.get_world_size() if self.dist else 1
         self._works = []
         if self.dist and self.world > 1:
-            hip.check(hip.lib.ssak_gemm_tile_order(1))  # collectives share the chip with the persistent GEMMs
+            # collectives share the chip with the persistent GEMMs: ticket tile order for the encoder's and the head's products
+            wav2vec2.set_option(hip.W2V2_OPT_DYNAMIC_TILES, 1)
+            head.dynamic_tiles = True
         # BatchNorm over the global batch under data parallelism; False = per-rank statistics, what the
         # reference's nn.DataParallel / DDP without SyncBatchNorm computes
         head.sync_bn = bool(self.dist and sync_batchnorm)

@@ -152,6 +152,7 @@ class Trainer:
             # come from seed + rank (identical seeds would apply one mask pattern to every shard of the global batch)
             model.reseed(model._seed + torch.distributed.get_rank())
         self._works = []  # (work, offset, count) of this step's bucket all-reduces, in announcement order
+        self._bucket_ev = []  # per bucket: events around its wait on the optimizer stream (measure_stall)
         self.bucket_log = []  # [(offset, count)] of the last step (bench: bucket sizes)
         if optimizer_stream is None:
             # default: on under data parallelism (it hides the exchange tail + the update under the next step's conv stack),
@@ -173,8 +174,9 @@ class Trainer:
                 self._ready.record(self.opt_stream)
             model.set_param_event(self._ready, *(self._stall or (None, None)))
         if self.dist and self.world > 1:
-            # RCCL's kernels take CUs away from the persistent GEMMs for a while: draw tiles from tickets (include/ssak_hip.h)
-            hip.check(hip.lib.ssak_gemm_tile_order(1))
+            # RCCL's kernels take CUs away from the persistent GEMMs for a while: this handle's products draw their tiles
+            # from tickets (include/ssak_hip.h: ssak_gemm_desc.dynamic_tiles)
+            model.set_option(hip.W2V2_OPT_DYNAMIC_TILES, 1)
         if self.dist:
             # bucketed exchange: one async sum all-reduce per announced gradient range (a layer's matrices = 28 MB
             # for base), issued while the rest of the backward is still running; RCCL runs them on its own stream
@@ -207,11 +209,28 @@ class Trainer:
         self._stall[1].synchronize()
         return self._stall[0].elapsed_time(self._stall[1])
 
+    def bucket_wait_us(self):
+        """Per gradient bucket of the LAST step, in announcement order: microseconds the optimizer stream spent waiting for the
+        bucket's all-reduce (needs ``measure_stall=True`` and the side stream; synchronises).  The first entries absorb the
+        backward still running, the last one is the exposed exchange tail.  None without a process group."""
+        n = len(self.bucket_log)
+        if self._stall is None or self.opt_stream is None or n == 0 or len(self._bucket_ev) < n:
+            return None
+        self._bucket_ev[n - 1][1].synchronize()
+        return [round(1e3 * self._bucket_ev[i][0].elapsed_time(self._bucket_ev[i][1]), 1) for i in range(n)]
+
     def _tail(self, norm_from_buckets: bool, compute_stream=None):
         """Norm partials per reduced bucket, clip + AdamW, positional-conv layouts: on the current stream."""
         m = self.model
+        timed = self._stall is not None and self.opt_stream is not None
         for i, (work, off, cnt) in enumerate(self._works):
+            if timed:  # how long the optimizer stream sits at this bucket's collective (bench.py: optimizer_tail.bucket_wait_us)
+                while len(self._bucket_ev) <= i:
+                    self._bucket_ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                self._bucket_ev[i][0].record()
             work.wait()  # the current stream waits for this bucket's collective; the mean over ranks is folded into the optimizer
+            if timed:
+                self._bucket_ev[i][1].record()
             if self.grad_exchange_dtype == "bf16":
                 hip.check(hip.lib.ssak_cast_bf16_f32(hip.ptr(self._g16[off:]), hip.ptr(m.grads[off:]), cnt, hip.stream()))
             if norm_from_buckets:
@@ -265,4 +284,4 @@ class Trainer:
         m.grads[:m.num_trainable].zero_()
         for off, cnt in m.announced_grad_ranges():
             self._on_grads_ready(off, cnt)
-        return torch.zeros((), dtype=torch.float32, device=m.device)
+        return torch.zeros(1, dtype=torch.float32, device=m.device)  # (the shape of CTCOutput.loss)

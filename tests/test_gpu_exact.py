@@ -242,3 +242,43 @@ def test_exact_matched_loss_tiny_30_steps():
     rel = max(abs(a - b) / abs(b) for a, b in zip(got, ref))
     print("exact matched loss: first", got[0], ref[0], "last", got[-1], ref[-1], "max rel", rel)
     assert ref[-1] < 0.9 * ref[0] and rel < 1e-4
+
+
+def test_exact_base_matched_loss_50_steps_vs_hf_curve(gold):
+    """SURVEY.md section 8d "Matched loss ... fp32 kernel path within 1e-4" on the HEADLINE config: wav2vec2-base, B=2 x 10 s,
+    50 optimizer steps of HF Trainer's inner loop (the train script's schedule: lr 1e-4, warm-up 500, clip 1.0), golden curve made
+    with transformers.Wav2Vec2ForCTC + torch.optim.AdamW + get_linear_schedule_with_warmup + clip_grad_norm_
+    (oracle/gen_golden_full.py, tests/golden/w2v2_base_curve.npz).  The fp32-exact mode must stay within 1e-4 relative AT EVERY
+    STEP (the bf16 engine's bar on the same curve is 2e-2, test_base_matched_loss_50_steps_vs_hf_curve), and the gradient norm
+    the clip sees within 1e-3."""
+    from oracle import w2v2_ref as R
+    from oracle.gen_golden_full import curve_inputs
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    z = gold("w2v2_base_curve.npz")
+    steps = int(z["steps"])
+    oc = R.W2V2Config.base().deterministic()
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc), exact=True).train()
+    model.load_state_dict(R.init_params(oc, 69))
+    opt = AdamW(model, lr=float(z["base_lr"]), warmup_steps=int(z["warmup"]), total_steps=int(z["total"]),
+                weight_decay=float(z["weight_decay"]), max_grad_norm=float(z["max_grad_norm"]))
+    tr = Trainer(model, opt)
+    batches = [(torch.tensor(x).cuda(), torch.tensor(l).cuda()) for x, l in curve_inputs()]
+    got, norms = [], []
+    for s in range(steps):
+        assert abs(opt.current_lr() - float(z["lr"][s])) < 1e-12
+        x, l = batches[s % len(batches)]
+        got.append(float(tr.train_step(x, None, l, raw=False).item()))
+        norms.append(opt.grad_norm())
+    got, ref = np.array(got), z["loss"]
+    rel = np.abs(got - ref) / np.abs(ref)
+    gn = np.abs(np.array(norms) - z["grad_norm"]) / z["grad_norm"]
+    print("exact base curve: first", got[0], ref[0], "last", got[-1], ref[-1], "max rel", rel.max(), "at step", int(rel.argmax()),
+          "grad-norm max rel", gn.max())
+    assert ref[-8:].mean() < 0.6 * ref[:8].mean()
+    assert rel.max() < 1e-4 and gn.max() < 1e-3
+    sd = model.state_dict()
+    for n, nr in zip(z["param_names"], z["param_norms"]):  # where the 50 updates went
+        t = sd[str(n)].double().reshape(-1)
+        assert abs(float(t.norm()) - nr) < 1e-5 * nr + 1e-7, (str(n), float(t.norm()), nr)

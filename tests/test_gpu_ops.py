@@ -405,7 +405,7 @@ def test_fused_attention_dropout_consistency(hip):
 @pytest.mark.parametrize("B,F,nh,ragged,p", [(2, 499, 12, False, 0.1), (3, 200, 4, True, 0.0), (3, 500, 2, True, 0.25),
                                               (1, 64, 2, False, 0.3), (2, 512, 3, False, 0.1), (1, 257, 1, False, 0.0),
                                               (2, 33, 8, True, 0.1), (2, 1500, 2, False, 0.1), (3, 749, 16, True, 0.05)])
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [2])  # hip.ATTN_BWD_FUSED (the wave-specialised variant of round 2 was removed)
 def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, p, mode):
     """The single-pass backward forms (mode 0: producer / consumer wave specialisation; mode 2: every wave in every role) --
     dQ, dK, dV from one evaluation of P / the dropout words / dS; a workgroup per head walks the keys in blocks and adds each
@@ -420,14 +420,9 @@ def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, 
     klens = torch.tensor([F, max(1, F // 3), F - 7][:B]) if ragged else None
     kw = dict(drop_p=p, seed=99, stream_id=5) if p else {}
     ctx, lse = hip.attention_fwd(qkv, B, F, nh, klens, **kw)
-    try:
-        hip.attention_bwd_mode(1)
-        ref = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
-        hip.attention_bwd_mode(mode)
-        got = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
-        again = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
-    finally:
-        hip.attention_bwd_mode(1)  # the default form
+    ref = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, mode=hip.ATTN_BWD_TWO_KERNEL, **kw)
+    got = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, mode=mode, **kw)
+    again = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, mode=mode, **kw)
     assert torch.isfinite(got.float()).all() and torch.isfinite(ref.float()).all()
     assert torch.equal(got, again)
     rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
@@ -546,43 +541,40 @@ def test_gemm_dynamic_tile_order(hip):
         B = torch.randint(-3, 4, (K, N) if b_km else (N, K), generator=g).to(torch.bfloat16).cuda()
         data.append((A, B, M, N, K, a_km, b_km))
 
-    def run(stream=None):
+    def run(stream=None, dynamic=False):
         outs = []
         with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
             for A, B, M, N, K, a_km, b_km in data:
                 Cc = torch.empty(M, N, dtype=torch.float32, device="cuda")
-                hip.gemm(A, B, Cc, M, N, K, a_kmajor=a_km, b_kmajor=b_km, lda=A.shape[1], ldb=B.shape[1], ldc=N)
+                hip.gemm(A, B, Cc, M, N, K, a_kmajor=a_km, b_kmajor=b_km, lda=A.shape[1], ldb=B.shape[1], ldc=N, dynamic_tiles=dynamic)
                 outs.append(Cc)
         return outs
 
     ref = run()
     torch.cuda.synchronize()
-    hip.check(hip.lib.ssak_gemm_tile_order(1))
-    try:
-        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-        for _ in range(3):
-            o0 = run()
-            o1, o2 = run(s1), run(s2)
-            torch.cuda.synchronize()
-            for o in (o0, o1, o2):
-                for got, want in zip(o, ref):
-                    assert torch.equal(got, want)
-        # grouped (weight-gradient form): 2 x (768 x 3072) + (2304 x 768) at 256 x 256 tiles = 99 tiles ... make it > 256
-        K = 512
-        probs, wants = [], []
-        for M, N in [(3072, 3072), (3072, 2304), (2304, 3072)]:
-            A = torch.randint(-3, 4, (K, M), generator=g).to(torch.bfloat16).cuda()
-            B = torch.randint(-3, 4, (K, N), generator=g).to(torch.bfloat16).cuda()
-            Cc = torch.empty(M, N, dtype=torch.float32, device="cuda")
-            probs.append((A, B, Cc, M, N, K, M, N, N, True, True))
-            wants.append(A.float().T @ B.float())
-        for _ in range(2):
-            hip.gemm_grouped(probs)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        o0 = run(dynamic=True)
+        o1, o2 = run(s1, True), run(s2, True)
+        o3 = run(dynamic=False)  # the option is per product: a static launch between dynamic ones
         torch.cuda.synchronize()
-        for (A, B, Cc, *_), w in zip(probs, wants):
-            assert torch.equal(Cc, w)
-    finally:
-        hip.check(hip.lib.ssak_gemm_tile_order(0))
+        for o in (o0, o1, o2, o3):
+            for got, want in zip(o, ref):
+                assert torch.equal(got, want)
+    # grouped (weight-gradient form): 2 x (768 x 3072) + (2304 x 768) at 256 x 256 tiles = 99 tiles ... make it > 256
+    K = 512
+    probs, wants = [], []
+    for M, N in [(3072, 3072), (3072, 2304), (2304, 3072)]:
+        A = torch.randint(-3, 4, (K, M), generator=g).to(torch.bfloat16).cuda()
+        B = torch.randint(-3, 4, (K, N), generator=g).to(torch.bfloat16).cuda()
+        Cc = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        probs.append((A, B, Cc, M, N, K, M, N, N, True, True))
+        wants.append(A.float().T @ B.float())
+    for _ in range(2):
+        hip.gemm_grouped(probs, dynamic_tiles=True)
+    torch.cuda.synchronize()
+    for (A, B, Cc, *_), w in zip(probs, wants):
+        assert torch.equal(Cc, w)
 
 
 def test_cast_and_colsum_helpers(hip):

@@ -471,6 +471,32 @@ def test_train_cli_two_rank_resume_restores_each_ranks_regulariser_streams(tmp_p
     assert states["full", 0]["host_rng"] != states["full", 1]["host_rng"]
 
 
+@pytest.mark.timeout(900)
+def test_bench_two_rank_rehearsal_reports_the_exchange(tmp_path):
+    """bench.py under torch.distributed.run with two ranks (both on the one card, gloo standing in for RCCL -- the driver's
+    N > 1 runs use one GPU per rank over RCCL): the JSON line carries what the N > 1 readings need -- the exposed optimizer /
+    exchange tail and, per gradient bucket, how long the optimizer stream waited for its all-reduce -- non-null, with the
+    bucket list covering the 360.8 MB payload of the base model."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, SSAK_BENCH_SHARE_GPU="1", SSAK_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3",
+                        "--batch", "4"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    tail = d["optimizer_tail"]
+    assert tail["stream"] == "side" and tail["exposed_us_per_step"] is not None and tail["exposed_us_per_step"] >= 0
+    ex = d["exchange"]
+    assert ex["payload_bytes_per_step"] == 4 * 90_195_872 and len(ex["bucket_bytes"]) == 15
+    waits = tail["bucket_wait_us"]
+    assert waits is not None and len(waits) == len(ex["bucket_bytes"]) and all(w >= 0 for w in waits)
+    assert d["roofline"]["primary"]["frac"] > 0 and d["build"]["lib_sha256"]
+
+
 def test_train_step_is_bitwise_reproducible():
     """No float atomics on the path: two runs from the same seed (dropout, LayerDrop and SpecAugment ON) end in bit-identical
     parameters and losses -- bias gradients, the SpecAugment embedding gradient and the clip norm are all fixed-order sums."""

@@ -35,12 +35,10 @@ def timeit(fn, n=50):
 fl = 4.0 * B * nh * F * F * 64
 for p in (0.0, 0.1):
     fwd = lambda: h.check(lib.ssak_attention_fwd(ptr(qkv), ptr(ctx), ptr(lse), None, B, F, nh, H, p, 1, 3, st()))
-    bwd = lambda: h.check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), None, ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H, p, 1, 3, st()))
+    bwd = lambda mode=1: h.check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), None, ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H, p, 1, 3, mode, st()))
     tf = timeit(fwd)
     out = [f"p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s)"]
-    for mode, name in ((0, "wave-spec."), (2, "fused"), (1, "two-kernel")):
-        h.attention_bwd_mode(mode)
-        tb = timeit(bwd)
+    for mode, name in ((2, "fused"), (1, "two-kernel")):
+        tb = timeit(lambda: bwd(mode))
         out.append(f"bwd {name:10s} {tb:7.1f} us ({2 * fl / tb / 1e6:6.1f} TF/s)")
-    h.attention_bwd_mode(1)
     print("   ".join(out))

@@ -10,6 +10,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stamp  # noqa: E402
+
 d, out_path = sys.argv[1], sys.argv[2]
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)  # the newest pass (the directory keeps older ones)
@@ -34,5 +37,5 @@ for k, c in acc.items():
         e["wave_wait_share"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
     res[k] = e
 order = sorted(res, key=lambda k: -sum(v for n, v in acc[k].items() if n in ("SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")) or -res[k]["launches"])
-json.dump({"source": f.split("gpurun_out/")[-1], "kernels": {k: res[k] for k in order[:top]}}, open(out_path, "w"), indent=1)
+json.dump({"stamp": stamp.current(), "source": f.split("gpurun_out/")[-1], "kernels": {k: res[k] for k in order[:top]}}, open(out_path, "w"), indent=1)
 print("wrote", min(top, len(res)), "of", len(res), "kernels to", out_path)

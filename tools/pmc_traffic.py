@@ -12,6 +12,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stamp  # noqa: E402
+
 
 def agg(d, cname):
     f = max(glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"), key=os.path.getmtime)  # the newest pass (the directory keeps older ones)
@@ -26,7 +29,8 @@ def agg(d, cname):
 
 
 fe, wr = agg("pmc_fetch", "FETCH_SIZE"), agg("pmc_write", "WRITE_SIZE")
-out = {"command": "python3 bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline", "fetch_correction": 2.0, "kernels": {}}
+out = {"stamp": stamp.current(), "command": "python3 bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline", "fetch_correction": 2.0,
+       "kernels": {}}
 for k in fe:
     n, v = fe[k]
     nw, vw = wr.get(k, [0, 0.0])
