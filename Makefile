@@ -7,12 +7,14 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := ssak_amd/csrc
-OBJ := build/obj
-LIB := ssak_amd/lib/libssak_hip.so
+OBJ ?= build/obj
+LIB ?= ssak_amd/lib/libssak_hip.so
+# experiment builds next to the product: make OBJ=build/obj_x LIB=tools/ab_x.so EXTRA=-DSOME_VARIANT
+EXTRA ?=
 # `make DEV=1`: development switches read from the environment (SSAK_GEMM_P8, SSAK_ATTN_TILE, ...) are compiled in; the
 # release library has none (common.h: SSAK_DEV_ENV)
 DEVFLAGS := $(if $(DEV),-DSSAK_DEV,)
-HIPFLAGS := $(DEVFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-atomic-optimizer-strategy=None
+HIPFLAGS := $(DEVFLAGS) $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-atomic-optimizer-strategy=None
 SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%,$(OBJ)/%.o,$(SRCS))
 

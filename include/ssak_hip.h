@@ -117,6 +117,16 @@ size_t ssak_ctc_align_workspace_bytes(int F, int L);
 int ssak_ctc_forced_align(const float* emission, const int32_t* tokens, int F, int V, int L, int blank, const float* col0,
                           float* trellis, int32_t* path_token, float* path_logp, int32_t* path_info /*[2]*/, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* The same for B utterances in ONE launch (one workgroup each): what tools/align_audio_transcript.py:121-335
+ * (split_long_audio_kaldifolder) does utterance by utterance through compute_alignment.  Padded layouts: emission
+ * [B, Fmax, V], frame_lens [B] (NULL = Fmax), tokens [B, Lmax], token_lens [B] (NULL = Lmax), col0 [B, Fmax+1] or NULL,
+ * trellis [B, Fmax+1, Lmax+1] or NULL (utterance b fills the top-left (F_b+1) x (L_b+1) corner; callers that only cut audio
+ * at word boundaries do not need it), path_token / path_logp [B, Fmax], path_info [B, 2] (as above; -3 = a length outside
+ * [1, Fmax] / [1, Lmax]).  Every utterance's results are bit-identical to its single-utterance call. */
+size_t ssak_ctc_align_batch_workspace_bytes(int B, int Fmax, int Lmax);
+int ssak_ctc_forced_align_batch(const float* emission, const int32_t* frame_lens, const int32_t* tokens, const int32_t* token_lens,
+                                int B, int Fmax, int V, int Lmax, int blank, const float* col0, float* trellis, int32_t* path_token,
+                                float* path_logp, int32_t* path_info /*[B,2]*/, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- dense contraction (MFMA bf16, fp32 accumulate) -----------------------------------------
  * The one GEMM behind every Linear / Conv1d / attention product of a3-a10.  C = alpha * op(A) * op(B)
@@ -135,7 +145,11 @@ int ssak_ctc_forced_align(const float* emission, const int32_t* tokens, int F, i
 /* The feed-forward pair of the encoder layers (Wav2Vec2FeedForward, modeling_wav2vec2.py:565-572, and its autograd): the
  * forward GEMM computes y = dropout(gelu(x)) and, instead of the pre-activation x, saves the backward's whole elementwise
  * factor f = gelu'(x) * keep / (1 - p) to `aux_out` (same element offsets as C); the backward GEMM then only multiplies,
- * C *= aux_in -- no exp, no reciprocal and no mask hash in the epilogue that used to be the slowest of the layer. */
+ * C *= aux_in -- no exp, no reciprocal and no mask hash in the epilogue that used to be the slowest of the layer.
+ * ssak_gemm_bf16 stores the factor as ONE BYTE per element (aux buffers are uint8 [.., ldc]): code 26 = exactly 0 (also a
+ * dropped element), otherwise gelu'(x) on the uniform grid (code - 26) * 1.26 / 254 over [-0.129, 1.136] (rounding error
+ * <= 0.0025, bf16's own error for |f| >= 0.6); 1 / (1 - p) is applied when the codes are read, so the SSAK_EPI_MUL_AUX product
+ * is given the forward's drop_p (it draws no mask).  ssak_gemm_f32 keeps a float factor with mask and scale folded in. */
 #define SSAK_EPI_GELU_SAVE_GRAD 3
 #define SSAK_EPI_MUL_AUX 4
 typedef struct {

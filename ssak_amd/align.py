@@ -77,6 +77,59 @@ def forced_align(emission: torch.Tensor, tokens: Sequence[int], blank_id: int = 
     return trellis.to(src_dev), path
 
 
+def forced_align_batch(emissions: Sequence[torch.Tensor], tokens_list: Sequence[Sequence[int]], blank_id: int = 0,
+                       first_as_garbage: bool = False, want_trellis: bool = False, device=None):
+    """Many utterances in ONE launch (``ssak_ctc_forced_align_batch``: one workgroup per utterance).  ``emissions[i]`` is
+    [F_i, V] float32 log-probabilities, ``tokens_list[i]`` its token ids.  Returns a list of (trellis [F_i+1, L_i+1] or None,
+    path or None) -- every entry identical to what :func:`forced_align` gives for that utterance alone."""
+    n = len(emissions)
+    assert n == len(tokens_list) and n > 0
+    dev = torch.device(device) if device is not None else (emissions[0].device if emissions[0].is_cuda else torch.device("cuda:0"))
+    V = int(emissions[0].shape[1])
+    Fs = [int(e.shape[0]) for e in emissions]
+    Ls = [len(t) for t in tokens_list]
+    if min(Ls) == 0:
+        raise IndexError("forced alignment needs a non-empty transcript")
+    Fmax, Lmax = max(Fs), max(Ls)
+    em = torch.zeros((n, Fmax, V), dtype=torch.float32)
+    tok = torch.zeros((n, Lmax), dtype=torch.int32)
+    col0 = torch.zeros((n, Fmax + 1), dtype=torch.float32) if first_as_garbage else None
+    for i, (e, t) in enumerate(zip(emissions, tokens_list)):
+        e = e.detach().to(device="cpu", dtype=torch.float32)
+        assert e.shape[1] == V
+        em[i, :Fs[i]] = e
+        th = torch.as_tensor(list(t), dtype=torch.int32)
+        if int(th.min()) < 0 or int(th.max()) >= V:
+            raise IndexError(f"token id outside the emission's {V} classes")
+        tok[i, :Ls[i]] = th
+        if first_as_garbage:  # column 0 of the garbage variant (:38), with the reference's torch ops
+            col0[i, 1:Fs[i] + 1] = (1 - e[:, int(th[0])].exp()).log()
+    em_d, tok_d = em.to(dev), tok.to(dev)
+    fl = torch.tensor(Fs, dtype=torch.int32, device=dev)
+    tl = torch.tensor(Ls, dtype=torch.int32, device=dev)
+    col0_d = col0.to(dev) if col0 is not None else None
+    trellis = torch.empty((n, Fmax + 1, Lmax + 1), dtype=torch.float32, device=dev) if want_trellis else None
+    path_token = torch.empty((n, Fmax), dtype=torch.int32, device=dev)
+    path_logp = torch.empty((n, Fmax), dtype=torch.float32, device=dev)
+    info = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    ws = torch.empty(hip.lib.ssak_ctc_align_batch_workspace_bytes(n, Fmax, Lmax), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        hip.check(hip.lib.ssak_ctc_forced_align_batch(hip.ptr(em_d), hip.ptr(fl), hip.ptr(tok_d), hip.ptr(tl), n, Fmax, V, Lmax,
+                                                      int(blank_id), hip.ptr(col0_d), hip.ptr(trellis), hip.ptr(path_token),
+                                                      hip.ptr(path_logp), hip.ptr(info), hip.ptr(ws), ws.numel(), hip.stream()))
+    info_h = info.cpu().numpy()
+    pt_h, pl_h = path_token.cpu().numpy(), path_logp.cpu().numpy()
+    out = []
+    for i in range(n):
+        cnt, first = int(info_h[i, 0]), int(info_h[i, 1])
+        path = None
+        if cnt >= 0:
+            sc = np.exp(pl_h[i, first:first + cnt])
+            path = [Point(int(pt_h[i, first + k]), first + k, float(sc[k])) for k in range(cnt)]
+        out.append((trellis[i, :Fs[i] + 1, :Ls[i] + 1] if want_trellis else None, path))
+    return out
+
+
 def get_trellis(emission, tokens, blank_id=0, first_as_garbage=False):
     """The Viterbi trellis [F+1, L+1] (:27-70).  The kernel walks the best path in the same launch; it travels WITH the
     returned tensor (attribute ``ssak_alignment``: the token sequence, the blank id and the path) so that :func:`backtrack` on
@@ -168,16 +221,8 @@ def loose_get_char_index(dictionary, c, default):
     return default if i is None else i
 
 
-def compute_alignment(audio, transcript, model, add_before_after=None, first_as_garbage=False, plot=False, verbose=False):
-    """(labels, emission, trellis, char_segments, word_segments) as align_transcriptions.py:294-402."""
-    from .infer import compute_log_probas
-    if plot:
-        raise NotImplementedError("plotting is outside the device path")
-    emission = compute_log_probas(model, audio)
-    labels, blank_id = get_model_vocab(model)
-    if transcript is None:
-        ids, n = hip.ctc_greedy_decode(emission.to(model[0].device)[None].contiguous(), None, blank_id)
-        transcript = "".join(labels[i] for i in ids[0, :int(n[0])].cpu().tolist())
+def _transcript_tokens(transcript, labels, blank_id, add_before_after=None):
+    """(characters, words or None, token ids, labels cut to the emission's classes) of compute_alignment (:318-356)."""
     if isinstance(transcript, str):
         transcript_characters, transcript_words = transcript, None
     else:
@@ -189,30 +234,84 @@ def compute_alignment(audio, transcript, model, add_before_after=None, first_as_
     if add_before_after:
         assert len(add_before_after) == 1 and add_before_after in labels
         transcript_characters = add_before_after + transcript_characters + add_before_after
-    labels = labels[:emission.shape[1]]
     dictionary = {c: i for i, c in enumerate(labels)}
     tokens = [loose_get_char_index(dictionary, c, space_id) for c in transcript_characters]
     tokens = [i for i in tokens if i is not None]
-    trellis = get_trellis(emission, tokens, blank_id=blank_id, first_as_garbage=first_as_garbage)
-    path = backtrack(trellis, emission, tokens, blank_id=blank_id)
+    return transcript_characters, transcript_words, tokens
+
+
+def _segments_from_path(path, transcript_characters, transcript_words, add_before_after=None):
+    """(char_segments, word_segments) from the best path (:364-402)."""
     char_segments = merge_repeats(transcript_characters, path)
     if add_before_after:
         assert char_segments[0].label == add_before_after and char_segments[-1].label == add_before_after
         char_segments = char_segments[1:-1]
-        trellis = trellis[:, [0] + list(range(2, trellis.shape[1] - 1))]
-        transcript_characters = transcript_characters[1:-1]
     if transcript_words is None:
-        word_segments = merge_words(char_segments)
-    else:
-        # the caller's own word list: word k owns the character segments [offset_k, offset_k + len(word_k)), the single
-        # separator between words is skipped; timing and score come from its letters when it has any
-        # (spaces / punctuation only count for a word made of nothing else)
-        word_segments = []
-        offset = 0
-        for word in transcript_words:
-            chars = char_segments[offset:offset + len(word)]
-            offset += len(word) + 1
-            assert "".join(c.label for c in chars) == word
-            letters = [c for c in chars if c.label not in " " + _PUNCTUATION] or chars
-            word_segments.append(Segment(word, letters[0].start, letters[-1].end, _pooled_score(letters)))
+        return char_segments, merge_words(char_segments)
+    # the caller's own word list: word k owns the character segments [offset_k, offset_k + len(word_k)), the single
+    # separator between words is skipped; timing and score come from its letters when it has any
+    # (spaces / punctuation only count for a word made of nothing else)
+    word_segments = []
+    offset = 0
+    for word in transcript_words:
+        chars = char_segments[offset:offset + len(word)]
+        offset += len(word) + 1
+        assert "".join(c.label for c in chars) == word
+        letters = [c for c in chars if c.label not in " " + _PUNCTUATION] or chars
+        word_segments.append(Segment(word, letters[0].start, letters[-1].end, _pooled_score(letters)))
+    return char_segments, word_segments
+
+
+def compute_alignment(audio, transcript, model, add_before_after=None, first_as_garbage=False, plot=False, verbose=False):
+    """(labels, emission, trellis, char_segments, word_segments) as align_transcriptions.py:294-402."""
+    from .infer import compute_log_probas
+    if plot:
+        raise NotImplementedError("plotting is outside the device path")
+    emission = compute_log_probas(model, audio)
+    labels, blank_id = get_model_vocab(model)
+    if transcript is None:
+        ids, n = hip.ctc_greedy_decode(emission.to(model[0].device)[None].contiguous(), None, blank_id)
+        transcript = "".join(labels[i] for i in ids[0, :int(n[0])].cpu().tolist())
+    labels = labels[:emission.shape[1]]
+    transcript_characters, transcript_words, tokens = _transcript_tokens(transcript, labels, blank_id, add_before_after)
+    trellis = get_trellis(emission, tokens, blank_id=blank_id, first_as_garbage=first_as_garbage)
+    path = backtrack(trellis, emission, tokens, blank_id=blank_id)
+    char_segments, word_segments = _segments_from_path(path, transcript_characters, transcript_words, add_before_after)
+    if add_before_after:
+        trellis = trellis[:, [0] + list(range(2, trellis.shape[1] - 1))]
     return labels, emission, trellis, char_segments, word_segments
+
+
+def compute_alignment_batch(audios, transcripts, model, first_as_garbage=False, emissions=None):
+    """compute_alignment for many utterances with ONE alignment launch.  Returns, per utterance, either
+    (num_frames, char_segments, word_segments) or the exception compute_alignment would have raised for it (the caller of the
+    reference's loop catches per utterance, tools/align_audio_transcript.py:337-346).
+
+    Emissions are computed per utterance for group-norm ("base") models -- those run without attention mask, so padding an
+    utterance inside a batch would change its own logits -- and may be supplied by the caller (``emissions``)."""
+    from .infer import compute_log_probas
+    labels, blank_id = get_model_vocab(model)
+    if emissions is None:
+        emissions = [compute_log_probas(model, a) for a in audios]
+    results = [None] * len(transcripts)
+    jobs = []
+    for i, (em, tr) in enumerate(zip(emissions, transcripts)):
+        try:
+            lab = labels[:em.shape[1]]
+            chars, words, tokens = _transcript_tokens(tr, lab, blank_id)
+            if not tokens:
+                raise IndexError("forced alignment needs a non-empty transcript")
+            jobs.append((i, chars, words, tokens))
+        except Exception as err:  # noqa: BLE001 -- reported per utterance, like the reference's loop
+            results[i] = err
+    if jobs:
+        aligned = forced_align_batch([emissions[i] for i, *_ in jobs], [t for *_, t in jobs], blank_id, first_as_garbage)
+        for (i, chars, words, _), (_, path) in zip(jobs, aligned):
+            try:
+                if path is None:
+                    raise RuntimeError("Failed to align (not enough tokens for the duration?)")
+                cs, wsg = _segments_from_path(path, chars, words)
+                results[i] = (int(emissions[i].shape[0]), cs, wsg)
+            except Exception as err:  # noqa: BLE001
+                results[i] = err
+    return results

@@ -23,20 +23,69 @@ struct AlignParams {
   const float* em;      // [F, V] log-probabilities
   const int32_t* tokens;  // [L]
   const float* col0;    // [F+1] trellis column 0 given by the caller (first_as_garbage) or NULL = blank cumsum
-  float* trellis;       // [F+1, L+1]
+  float* trellis;       // [F+1, ld] with ld >= L+1, or NULL (batched callers that only want the path)
+  float* lastcol;       // [F+1] trellis column L (the backtrack's argmax reads it; kept whether or not the trellis is)
   uint8_t* bp;          // [F, L] codes, then [F] codes along the path
   int32_t* path_token;  // [F] indexed by time
   float* path_logp;     // [F] indexed by time
   int32_t* path_info;   // [2]: number of points (-1 = failed to align), time index of the first point
   int F, V, L, blank;
+  int tld;              // row stride of the trellis
 };
 
-__global__ __launch_bounds__(1024) void align_kernel(const AlignParams p) {
-  extern __shared__ float rows[];  // 2 x (L + 1) floats (>= 4 KiB: the backtrack's code band reuses it)
+// One launch, many utterances (tools/align_audio_transcript.py aligns a Kaldi folder: the kernel is one workgroup per
+// utterance and the chip has 256 CUs).  Padded layouts: emission [B, Fmax, V], tokens [B, Lmax], col0 [B, Fmax+1],
+// trellis [B, Fmax+1, Lmax+1] (utterance b uses the top-left (F_b+1) x (L_b+1) corner), paths [B, Fmax], info [B, 2].
+struct AlignBatch {
+  const float* em;
+  const int32_t* frame_lens;  // [B] or NULL (= Fmax)
+  const int32_t* tokens;
+  const int32_t* token_lens;  // [B] or NULL (= Lmax)
+  const float* col0;
+  float* trellis;
+  float* lastcol;             // [B, Fmax+1]
+  uint8_t* bp;                // [B] x (Fmax * Lmax + Fmax)
+  int32_t* path_token;
+  float* path_logp;
+  int32_t* path_info;
+  int Fmax, V, Lmax, blank;
+};
+
+__device__ __forceinline__ void align_one(const AlignParams& p, float* rows);
+
+__global__ __launch_bounds__(1024) void align_kernel(const AlignBatch q) {
+  extern __shared__ float rows[];  // 2 x (Lmax + 1) floats (>= 4 KiB: the backtrack's code band reuses it)
+  const int b = blockIdx.x;
+  AlignParams p;
+  p.F = q.frame_lens ? q.frame_lens[b] : q.Fmax;
+  p.L = q.token_lens ? q.token_lens[b] : q.Lmax;
+  p.V = q.V;
+  p.blank = q.blank;
+  p.tld = q.Lmax + 1;
+  p.em = q.em + (long)b * q.Fmax * q.V;
+  p.tokens = q.tokens + (long)b * q.Lmax;
+  p.col0 = q.col0 ? q.col0 + (long)b * (q.Fmax + 1) : nullptr;
+  p.trellis = q.trellis ? q.trellis + (long)b * (q.Fmax + 1) * (q.Lmax + 1) : nullptr;
+  p.lastcol = q.lastcol + (long)b * (q.Fmax + 1);
+  p.bp = q.bp + (long)b * ((long)q.Fmax * q.Lmax + q.Fmax);
+  p.path_token = q.path_token + (long)b * q.Fmax;
+  p.path_logp = q.path_logp + (long)b * q.Fmax;
+  p.path_info = q.path_info + 2 * b;
+  if (p.F < 1 || p.F > q.Fmax || p.L < 1 || p.L > q.Lmax) {  // lengths outside the padded layout: refuse this utterance
+    if (threadIdx.x == 0) {
+      p.path_info[0] = -3;
+      p.path_info[1] = 0;
+    }
+    return;
+  }
+  align_one(p, rows);
+}
+
+__device__ __forceinline__ void align_one(const AlignParams& p, float* rows) {
   __shared__ float red_v[16];
   __shared__ int red_i[16];
   const int tid = threadIdx.x, NT = blockDim.x;
-  const int F = p.F, V = p.V, L = p.L, W = L + 1;
+  const int F = p.F, V = p.V, L = p.L, W = L + 1, TW = p.tld;
   const int K = (L + NT - 1) / NT;
   float* r0 = rows;
   float* r1 = rows + W;
@@ -66,14 +115,15 @@ __global__ __launch_bounds__(1024) void align_kernel(const AlignParams p) {
   // row 0: trellis[0, 0] = 0 (or the caller's), trellis[0, 1:] = -inf
   for (int j = tid + 1; j < W; j += NT) {
     r0[j] = -INFINITY;
-    p.trellis[j] = -INFINITY;
+    if (p.trellis) p.trellis[j] = -INFINITY;
+    if (j == L) p.lastcol[0] = -INFINITY;
   }
   double run = 0.0;  // thread 0: running sum of the blank log-probability
   if (tid == 0) {
     float c = p.col0 ? p.col0[0] : 0.f;
     if (0 >= inf_from) c = INFINITY;
     r0[0] = c;
-    p.trellis[0] = c;
+    if (p.trellis) p.trellis[0] = c;
   }
   __syncthreads();
   for (int t = 0; t < F; ++t) {
@@ -87,7 +137,7 @@ __global__ __launch_bounds__(1024) void align_kernel(const AlignParams p) {
       const int s = tid + NT * i;
       etn[i] = (i < K && s < L && t + 1 < F) ? p.em[(long)(t + 1) * V + tok[i]] : 0.f;
     }
-    float* trow = p.trellis + (long)(t + 1) * W;
+    float* trow = p.trellis ? p.trellis + (long)(t + 1) * TW : nullptr;
     uint8_t* brow = p.bp + (long)t * L;
 #pragma unroll
     for (int i = 0; i < ALIGN_MAX_K; ++i) {
@@ -98,7 +148,8 @@ __global__ __launch_bounds__(1024) void align_kernel(const AlignParams p) {
         const float stayed = fmaxf(stay_blank, stay_tok);
         const float v = fmaxf(stay_blank, fmaxf(stay_tok, change));
         nxt[s + 1] = v;
-        trow[s + 1] = v;
+        if (trow) trow[s + 1] = v;
+        if (s + 1 == L) p.lastcol[t + 1] = v;
         brow[s] = (uint8_t)((change > stayed ? 1 : 0) | (change < stayed ? 2 : 0));
       }
     }
@@ -112,7 +163,7 @@ __global__ __launch_bounds__(1024) void align_kernel(const AlignParams p) {
       }
       if (t + 1 >= inf_from) c = INFINITY;
       nxt[0] = c;
-      trow[0] = c;
+      if (trow) trow[0] = c;
     }
 #pragma unroll
     for (int i = 0; i < ALIGN_MAX_K; ++i) et[i] = etn[i];
@@ -122,7 +173,7 @@ __global__ __launch_bounds__(1024) void align_kernel(const AlignParams p) {
   float best = -INFINITY;
   int best_i = 0x7fffffff;
   for (int r = tid; r <= F; r += NT) {
-    const float v = p.trellis[(long)r * W + L];
+    const float v = p.lastcol[r];
     if (v > best || (v == best && r < best_i)) {
       best = v;
       best_i = r;
@@ -223,9 +274,33 @@ __global__ __launch_bounds__(1024) void align_kernel(const AlignParams p) {
 
 }  // namespace
 
+static size_t align_ws_per_utt(int F, int L) {
+  // a code per trellis cell + the codes along the path, then the trellis' last column (F + 1 floats, 4-byte aligned)
+  return (((size_t)F * (size_t)L + (size_t)F + 3) & ~(size_t)3) + (size_t)(F + 1) * sizeof(float);
+}
+
 extern "C" size_t ssak_ctc_align_workspace_bytes(int F, int L) {
   if (F <= 0 || L <= 0) return 0;
-  return (size_t)F * (size_t)L + (size_t)F;  // a code per trellis cell + the codes along the path
+  return align_ws_per_utt(F, L);
+}
+
+extern "C" size_t ssak_ctc_align_batch_workspace_bytes(int B, int Fmax, int Lmax) {
+  if (B <= 0 || Fmax <= 0 || Lmax <= 0) return 0;
+  return (size_t)B * align_ws_per_utt(Fmax, Lmax);
+}
+
+static int align_launch(const AlignBatch& q, int B, hipStream_t st) {
+  const int L = q.Lmax;
+  const int nt = std::min(1024, std::max(64, (L + 63) / 64 * 64));
+  const size_t lds = std::max<size_t>(2 * (size_t)(L + 1) * sizeof(float), 64 * 64);  // trellis rows, later the code band
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (ALIGN_MAX_K * 1024 + 1) * 4));
+    attr_done = true;
+  }
+  align_kernel<<<B, nt, lds, st>>>(q);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
 }
 
 extern "C" int ssak_ctc_forced_align(const float* emission, const int32_t* tokens, int F, int V, int L, int blank, const float* col0,
@@ -236,15 +311,25 @@ extern "C" int ssak_ctc_forced_align(const float* emission, const int32_t* token
   SSAK_REQUIRE(L <= ALIGN_MAX_K * 1024, "forced_align: transcript of %d tokens exceeds %d", L, ALIGN_MAX_K * 1024);
   SSAK_REQUIRE(blank >= 0 && blank < V, "forced_align: blank id %d outside the vocabulary of %d", blank, V);
   SSAK_REQUIRE(workspace && workspace_bytes >= ssak_ctc_align_workspace_bytes(F, L), "forced_align: workspace too small");
-  AlignParams p{emission, tokens, col0, trellis, (uint8_t*)workspace, path_token, path_logp, path_info, F, V, L, blank};
-  const int nt = std::min(1024, std::max(64, (L + 63) / 64 * 64));
-  const size_t lds = std::max<size_t>(2 * (size_t)(L + 1) * sizeof(float), 64 * 64);  // trellis rows, later the code band
-  static bool attr_done = false;
-  if (!attr_done) {
-    SSAK_HIP(hipFuncSetAttribute((const void*)align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (ALIGN_MAX_K * 1024 + 1) * 4));
-    attr_done = true;
-  }
-  align_kernel<<<1, nt, lds, (hipStream_t)stream>>>(p);
-  SSAK_LAUNCH_CHECK();
-  return SSAK_OK;
+  const size_t codes = ((size_t)F * L + F + 3) & ~(size_t)3;
+  AlignBatch q{emission, nullptr, tokens, nullptr, col0, trellis, (float*)((char*)workspace + codes), (uint8_t*)workspace,
+               path_token, path_logp, path_info, F, V, L, blank};
+  return align_launch(q, 1, (hipStream_t)stream);
+}
+
+extern "C" int ssak_ctc_forced_align_batch(const float* emission, const int32_t* frame_lens, const int32_t* tokens,
+                                           const int32_t* token_lens, int B, int Fmax, int V, int Lmax, int blank, const float* col0,
+                                           float* trellis, int32_t* path_token, float* path_logp, int32_t* path_info,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(emission && tokens && path_token && path_logp && path_info, "forced_align_batch: null pointer");
+  SSAK_REQUIRE(B >= 1 && Fmax >= 1 && V >= 1 && Lmax >= 1, "forced_align_batch: B=%d Fmax=%d V=%d Lmax=%d must be >= 1", B, Fmax, V, Lmax);
+  SSAK_REQUIRE(Lmax <= ALIGN_MAX_K * 1024, "forced_align_batch: transcripts of up to %d tokens exceed %d", Lmax, ALIGN_MAX_K * 1024);
+  SSAK_REQUIRE(blank >= 0 && blank < V, "forced_align_batch: blank id %d outside the vocabulary of %d", blank, V);
+  SSAK_REQUIRE(workspace && workspace_bytes >= ssak_ctc_align_batch_workspace_bytes(B, Fmax, Lmax), "forced_align_batch: workspace too small");
+  // workspace: B code blocks of (Fmax * Lmax + Fmax) bytes, then B last-column rows of Fmax + 1 floats
+  const size_t codes = ((size_t)B * ((size_t)Fmax * Lmax + Fmax) + 3) & ~(size_t)3;
+  SSAK_REQUIRE(codes + (size_t)B * (Fmax + 1) * sizeof(float) <= workspace_bytes, "forced_align_batch: workspace too small");
+  AlignBatch q{emission, frame_lens, tokens, token_lens, col0, trellis, (float*)((char*)workspace + codes), (uint8_t*)workspace,
+               path_token, path_logp, path_info, Fmax, V, Lmax, blank};
+  return align_launch(q, B, (hipStream_t)stream);
 }

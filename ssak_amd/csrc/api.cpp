@@ -88,7 +88,7 @@ void register_classes() {
       {"attn_bwd_dq_kernel + attn_bwd_dkv_kernel (fused attention backward)", SSAK_BOUND_MFMA},
       {"ln_fwd_kernel (residual + dropout + LayerNorm)", SSAK_BOUND_HBM},
       {"ln_bwd_kernel (LayerNorm backward + column partials)", SSAK_BOUND_HBM},
-      {"conv0_moments + conv0_channel_stats + conv0_kernel (conv0 + GroupNorm + GELU)", SSAK_BOUND_HBM},
+      {"conv0_moments_kernel + conv0_channel_stats_kernel + conv0_mfma_kernel (conv0 + GroupNorm + GELU)", SSAK_BOUND_HBM},
       {"adamw_kernel (clip + AdamW + bf16 shadow)", SSAK_BOUND_HBM},
       {"sumsq_kernel (gradient norm)", SSAK_BOUND_HBM},
       {"ctc_lsm + ctc_lat + ctc_grad (CTC loss + gradient)", SSAK_BOUND_LATENCY},

@@ -29,6 +29,7 @@ struct GemmParams {
   long bias_s2;
   uint32_t ext_a, ext_b;  // bytes addressable from one batch slice of A / B (buffer descriptor extent)
   float* colsum;          // [wave-tile rows][N] column sums of the stored values (bias gradient of the producing Linear) or null
+  float fq_a, fq_b;       // SSAK_EPI_MUL_AUX: factor = code * fq_a + fq_b (step * scale, -zero * step * scale)
   int dynamic;            // ssak_gemm_desc.dynamic_tiles: draw tiles from ticket counters (persistent kernels)
   int* tile_ctr;          // persistent kernels: [0] = tickets handed out past the first round, [1] = workgroups done (or null: static)
   // K-tile visiting order of the persistent kernel for a Toeplitz A (conv as GEMM: lda = stride * C < K = k * C, so K tile kt
@@ -46,6 +47,32 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---- 8-bit code of the feed-forward backward factor (SSAK_EPI_GELU_SAVE_GRAD writes it, SSAK_EPI_MUL_AUX reads it) ----------
+// f = gelu'(x) * keep / (1 - p).  gelu' lies in [-0.129, 1.129]: a uniform grid of step 1.26 / 254 with its zero point ON the
+// grid (code 26 <-> exactly 0, which is also the code of a dropped element) covers [-0.129, 1.136] with a rounding error of at
+// most 0.0025 -- what bf16 does for |f| >= 0.6, about 2.5 x bf16's error on average (RMS 1.4e-3 against a factor of ~0.5; the
+// dX product it scales is exact, so the gradient picks up ~0.3 % of uncorrelated noise next to the ~1.5 % of the bf16 engine).
+// The dropout scale 1 / (1 - p) is applied at decode.  One byte per element: the forward product's second store stream and
+// the backward product's factor read are 49 MB instead of 98 MB per layer at the train-step shape.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+constexpr float FQ_ZERO = 26.f, FQ_STEP = 1.26f / 254.f, FQ_INV = 254.f / 1.26f;
+// four codes in one dword (byte k = element k); g = gelu'(x), already zeroed where dropped; v_cvt_pk_u8_f32 rounds to nearest
+// even and saturates to [0, 255]
+__device__ __forceinline__ uint32_t fq_pack4(float g0, float g1, float g2, float g3) {
+  uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g0, FQ_INV, FQ_ZERO), 0u, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g1, FQ_INV, FQ_ZERO), 1u, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g2, FQ_INV, FQ_ZERO), 2u, w);
+  return __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g3, FQ_INV, FQ_ZERO), 3u, w);
+}
+// f = (code - 26) * step * scale as one fma per element: a = step * scale, b = -26 * step * scale
+__device__ __forceinline__ void fq_unpack4(uint32_t w, float a, float b, float (&f)[4]) {
+  f[0] = fmaf((float)(w & 0xffu), a, b);
+  f[1] = fmaf((float)((w >> 8) & 0xffu), a, b);
+  f[2] = fmaf((float)((w >> 16) & 0xffu), a, b);
+  f[3] = fmaf((float)(w >> 24), a, b);
+}
+__device__ __forceinline__ uint8_t fq_pack1(float g) { return (uint8_t)(__builtin_amdgcn_cvt_pk_u8_f32(fmaf(g, FQ_INV, FQ_ZERO), 0u, 0u) & 0xffu); }
+__device__ __forceinline__ float fq_unpack1(uint8_t c, float a, float b) { return fmaf((float)c, a, b); }
 // bias for this lane's NI column groups, loaded BEFORE the K loop (vector loads; the round trip then overlaps the
 // main loop instead of being exposed at the tail of every workgroup: measured 19 us of 133 on the FFN shape)
 template <int NI>
@@ -155,9 +182,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           v[r + 1] = y[1];
         }
       } else if (p.epilogue == SSAK_EPI_MUL_AUX) {
-        const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(p.aux_in + o);
+        const u32x2 w2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(p.aux_in) + o);  // 8 one-byte codes
+        float f0[4], f1[4];
+        fq_unpack4(w2[0], p.fq_a, p.fq_b, f0);
+        fq_unpack4(w2[1], p.fq_a, p.fq_b, f1);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= (float)a8[r];
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= f0[r];
+          v[4 + r] *= f1[r];
+        }
       } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
         const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(p.aux_in + o);
 #pragma unroll
@@ -173,18 +206,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           const uint32_t w = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o + 2 * h);
           v[2 * h] = ((w & 0xffffu) >= p.drop_thresh) ? v[2 * h] * p.drop_scale : 0.f;
           v[2 * h + 1] = ((w >> 16) >= p.drop_thresh) ? v[2 * h + 1] * p.drop_scale : 0.f;
-          if (save_grad) {
-            gd[2 * h] = ((w & 0xffffu) >= p.drop_thresh) ? gd[2 * h] * p.drop_scale : 0.f;
-            gd[2 * h + 1] = ((w >> 16) >= p.drop_thresh) ? gd[2 * h + 1] * p.drop_scale : 0.f;
+          if (save_grad) {  // (the factor's code carries the mask; its 1 / (1 - p) is applied at decode)
+            gd[2 * h] = ((w & 0xffffu) >= p.drop_thresh) ? gd[2 * h] : 0.f;
+            gd[2 * h + 1] = ((w >> 16) >= p.drop_thresh) ? gd[2 * h + 1] : 0.f;
           }
         }
       }
-      if (save_grad && p.aux_out) {
-        bf16x8 q;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) q[r] = (bf16)gd[r];
-        *reinterpret_cast<bf16x8*>(p.aux_out + o) = q;
-      }
+      if (save_grad && p.aux_out)
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint8_t*>(p.aux_out) + o) =
+            (u32x2){fq_pack4(gd[0], gd[1], gd[2], gd[3]), fq_pack4(gd[4], gd[5], gd[6], gd[7])};
       if (p.out_f32) {
         float* dst = reinterpret_cast<float*>(p.C) + o;
         if (p.accumulate) {
@@ -253,7 +283,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     } else if (p.epilogue == SSAK_EPI_MUL_AUX) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < p.N) v[r] *= (float)p.aux_in[o + r];
+        if (n + r < p.N) v[r] *= fq_unpack1(reinterpret_cast<const uint8_t*>(p.aux_in)[o + r], p.fq_a, p.fq_b);
     } else if (p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
       if (full) {
         const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(p.aux_in + o);
@@ -274,16 +304,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       v[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[2] * p.drop_scale : 0.f;
       v[3] = ((w1 >> 16) >= p.drop_thresh) ? v[3] * p.drop_scale : 0.f;
       if (save_grad) {
-        gd[0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[0] * p.drop_scale : 0.f;
-        gd[1] = ((w0 >> 16) >= p.drop_thresh) ? gd[1] * p.drop_scale : 0.f;
-        gd[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[2] * p.drop_scale : 0.f;
-        gd[3] = ((w1 >> 16) >= p.drop_thresh) ? gd[3] * p.drop_scale : 0.f;
+        gd[0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[0] : 0.f;
+        gd[1] = ((w0 >> 16) >= p.drop_thresh) ? gd[1] : 0.f;
+        gd[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[2] : 0.f;
+        gd[3] = ((w1 >> 16) >= p.drop_thresh) ? gd[3] : 0.f;
       }
     }
     if (save_grad && p.aux_out) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < p.N) p.aux_out[o + r] = (bf16)gd[r];
+        if (n + r < p.N) reinterpret_cast<uint8_t*>(p.aux_out)[o + r] = fq_pack1(gd[r]);
     }
     if (p.out_f32) {
       float* dst = reinterpret_cast<float*>(p.C) + o;
@@ -325,7 +355,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // up with the 16 consecutive columns 16*lq.. of row lm = two 16-byte stores, the four lanes of a row cover one 128-B
 // line.  No LDS traffic, no barrier, ~40 VALU + 2 stores per 16 rows on the plain path (the LDS round trip it replaces
 // measured 4.6 us per 256x256 tile whatever the number of workgroups, tools/probes/p8_probe.hip).
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 __device__ __forceinline__ void xpose4(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3) {
   u32x2 t = __builtin_amdgcn_permlane32_swap(r0, r2, false, false);
   r0 = t[0];
@@ -341,6 +370,40 @@ __device__ __forceinline__ void xpose4(uint32_t& r0, uint32_t& r1, uint32_t& r2,
   r3 = t[1];
 }
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+// one 16-byte store of the LDS-free epilogue: NON-TEMPORAL.  A round of tiles writes 25-64 MB at once and nothing on this CU
+// reads it back; leaving those lines in the XCD's L2 (a plain store does) pushes the operand panels out, which the next
+// tiles then fetch again.  Same-box A/B of the train step (profiles/r03_ab_epilogue_store_policy.log, three alternations):
+// plain 2 019 / 2 023, `nt` 2 031 / 2 033 utterances/s (+0.5 %: the N = 768 forward products 1 991 -> 1 958 us per step);
+// write-through `sc1` stores 1 890 (-6.5 %: every store a fabric write of its own).  -DSSAK_EPI_STORE=0 / 1 build the plain /
+// sc1 forms.
+#ifndef SSAK_EPI_STORE
+#define SSAK_EPI_STORE 2
+#endif
+__device__ __forceinline__ void epi_store16(void* dst, u32x4 v) {
+#if SSAK_EPI_STORE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#elif SSAK_EPI_STORE == 2
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+#else
+  *reinterpret_cast<u32x4*>(dst) = v;
+#endif
+}
+// store 16 rows x 64 columns of codes held as g[j][r] (accumulator layout) at dst + row lm, + 16 * lq: one 16-byte store per lane
+__device__ __forceinline__ void store_fq_rows(uint8_t* dst_lane, const float (&g)[4][4], bool rowok) {
+  uint32_t q[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = fq_pack4(g[j][0], g[j][1], g[j][2], g[j][3]);
+  xpose4(q[0], q[1], q[2], q[3]);
+  if (rowok) epi_store16(dst_lane, (u32x4){q[0], q[1], q[2], q[3]});
+}
+// ... and the way back: f[j][r] in the accumulator layout from the 16 bytes of this lane's row segment
+__device__ __forceinline__ void load_fq_rows(const uint8_t* src_lane, bool rowok, float a, float b, float (&f)[4][4]) {
+  u32x4 w = rowok ? *reinterpret_cast<const u32x4*>(src_lane) : (u32x4){0u, 0u, 0u, 0u};
+  uint32_t q[4] = {w[0], w[1], w[2], w[3]};
+  xpose4(q[0], q[1], q[2], q[3]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fq_unpack4(q[j], a, b, f[j]);
+}
 // store 16 rows x 64 columns of bf16 held as v[j][r] (accumulator layout) at dst + row lm, columns 16*lq..
 __device__ __forceinline__ void store_bf16_rows(bf16* dst_lane /* + row lm, + 16*lq */, const float (&v)[4][4], bool rowok = true) {
   uint32_t lo[4], hi[4];
@@ -354,14 +417,15 @@ __device__ __forceinline__ void store_bf16_rows(bf16* dst_lane /* + row lm, + 16
   xpose4(lo[0], lo[1], lo[2], lo[3]);
   xpose4(hi[0], hi[1], hi[2], hi[3]);
   if (rowok) {  // (after the swaps: those need every lane)
-    *reinterpret_cast<u32x4*>(dst_lane) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
-    *reinterpret_cast<u32x4*>(dst_lane + 8) = (u32x4){lo[2], hi[2], lo[3], hi[3]};
+    epi_store16(dst_lane, (u32x4){lo[0], hi[0], lo[1], hi[1]});
+    epi_store16(dst_lane + 8, (u32x4){lo[2], hi[2], lo[3], hi[3]});
   }
 }
 // true when the wave tile [wm0, wm0 + rows) x [wn0, wn0 + 64) of this workgroup can take gemm_epilogue_direct
 __device__ __forceinline__ bool epilogue_direct_ok(const GemmParams& p, int bm0, int bn0, int wm0, int wn0, int rows, long coff) {
   (void)rows;  // tile rows beyond M are masked per lane by the epilogue itself
-  return bn0 + wn0 + 64 <= p.N && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (coff & 7) == 0 &&
+  const bool fq = p.epilogue == SSAK_EPI_GELU_SAVE_GRAD || p.epilogue == SSAK_EPI_MUL_AUX;  // 16-byte row segments of one-byte codes
+  return bn0 + wn0 + 64 <= p.N && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (coff & 7) == 0 && (!fq || ((p.ldc | coff) & 15) == 0) &&
          (((uintptr_t)p.aux_in | (uintptr_t)p.aux_out | (uintptr_t)p.C) & 15) == 0;
 }
 // EPI: -1 = the general-purpose form (epilogue mode read from the parameters: NONE / GELU / MUL_GELU_GRAD); SSAK_EPI_GELU_SAVE_GRAD
@@ -460,13 +524,12 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
           v[j][r + 1] = y[1];
         }
     } else if (EPI == SSAK_EPI_MUL_AUX) {
-      bf16x4 a[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = rowok ? *reinterpret_cast<const bf16x4*>(p.aux_in + oa + 16 * j) : (bf16x4){};
+      float f[4][4];  // one 16-byte load of this lane's row segment of codes, transposed back to the accumulator layout
+      load_fq_rows(reinterpret_cast<const uint8_t*>(p.aux_in) + orow + 16 * lq, rowok, p.fq_a, p.fq_b, f);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[j][r] *= (float)a[j][r];
+        for (int r = 0; r < 4; ++r) v[j][r] *= f[j][r];
     } else if (GENERAL && p.epilogue == SSAK_EPI_MUL_GELU_GRAD) {
       bf16x4 a[4];
 #pragma unroll
@@ -489,15 +552,15 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
         v[j][1] = ((w0 >> 16) >= p.drop_thresh) ? v[j][1] * p.drop_scale : 0.f;
         v[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[j][2] * p.drop_scale : 0.f;
         v[j][3] = ((w1 >> 16) >= p.drop_thresh) ? v[j][3] * p.drop_scale : 0.f;
-        if (save_grad) {
-          gd[j][0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[j][0] * p.drop_scale : 0.f;
-          gd[j][1] = ((w0 >> 16) >= p.drop_thresh) ? gd[j][1] * p.drop_scale : 0.f;
-          gd[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[j][2] * p.drop_scale : 0.f;
-          gd[j][3] = ((w1 >> 16) >= p.drop_thresh) ? gd[j][3] * p.drop_scale : 0.f;
+        if (save_grad) {  // (the factor's code carries the mask; its 1 / (1 - p) is applied at decode)
+          gd[j][0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[j][0] : 0.f;
+          gd[j][1] = ((w0 >> 16) >= p.drop_thresh) ? gd[j][1] : 0.f;
+          gd[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[j][2] : 0.f;
+          gd[j][3] = ((w1 >> 16) >= p.drop_thresh) ? gd[j][3] : 0.f;
         }
       }
     }
-    if (save_grad && p.aux_out) store_bf16_rows(p.aux_out + orow + 16 * lq, gd, rowok);
+    if (save_grad && p.aux_out) store_fq_rows(reinterpret_cast<uint8_t*>(p.aux_out) + orow + 16 * lq, gd, rowok);
     if (WITH_COLSUM && p.colsum) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)

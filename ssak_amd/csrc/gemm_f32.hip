@@ -162,6 +162,7 @@ extern "C" int ssak_gemm_f32(const ssak_gemm_desc* d, const void* A, const void*
   p.epilogue = d->epilogue;
   p.accumulate = d->accumulate;
   p.drop_thresh = thresh_of(d->drop_p);
+  if (d->epilogue == SSAK_EPI_MUL_AUX) p.drop_thresh = 0;  // the float factor carries mask AND scale; drop_p only matters to the bf16 form's codes
   p.drop_scale = p.drop_thresh ? 1.f / (1.f - (float)p.drop_thresh / 65536.f) : 1.f;
   p.drop_stream = d->drop_stream;
   p.drop_seed = d->drop_seed;

@@ -991,7 +991,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
                           c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
     }
     TRY(GemmX<EXACT>(M, I, H).a(BF(lb.x1), H).b(W + L.w1, H).c(BF(lb.f1), I).with_bias(P + L.b1)
-            .epi(tr ? SSAK_EPI_GELU_SAVE_GRAD : SSAK_EPI_GELU, nullptr, tr ? BF(lb.f1pre) : nullptr)  // f1pre := gelu'(pre) * mask / (1 - p)
+            .epi(tr ? SSAK_EPI_GELU_SAVE_GRAD : SSAK_EPI_GELU, nullptr, tr ? BF(lb.f1pre) : nullptr)  // f1pre := 8-bit codes of gelu'(pre) * mask (float values incl. 1 / (1 - p) in the exact mode)
             .drop(tr ? c.activation_dropout : 0.f, ds_act(l), seed).run(st));
     TRY(GemmX<EXACT>(M, H, I).a(BF(lb.f1), I).b(W + L.w2, I).c(BF(p.tmpH), H).with_bias(P + L.b2).run(st));
     if (!stable) {
@@ -1236,7 +1236,8 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     const AT* dy2 = dY;
     wq.push(GemmX<EXACT>(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
     TRY(GemmX<EXACT>(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
-            .epi(SSAK_EPI_MUL_AUX, BF(lb.f1pre))  // the forward saved the whole factor (GELU' and the dropout mask)
+            .epi(SSAK_EPI_MUL_AUX, BF(lb.f1pre))  // the forward saved the whole factor (GELU' and the dropout mask) as 8-bit codes
+            .drop(c.activation_dropout, ds_act(l), seed)  // (which 1 / (1 - p) the codes decode with; no mask is drawn here)
             .colsum(Gd + L.b1).run(st, ffn_part, ffn_part_floats * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
     wq.push(GemmX<EXACT>(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
     AT* dX = BF(p.dB);

@@ -72,6 +72,8 @@ def _load():
         "ssak_ctc_wer": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "ssak_ctc_align_workspace_bytes": (sz, [i32, i32]),
         "ssak_ctc_forced_align": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "ssak_ctc_align_batch_workspace_bytes": (sz, [i32, i32, i32]),
+        "ssak_ctc_forced_align_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp]),
         "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),

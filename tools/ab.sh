@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of two builds on the SAME box (the pool's boxes differ by several per cent): alternates bench.py runs of the current
-# libssak_hip.so and of the build named by $SSAK_AB_BASE (default build/ab_base.so, kept OUTSIDE the package so that it never
+# libssak_hip.so and of the build named by $SSAK_AB_BASE (default tools/ab_base.so (git-ignored like every .so), kept OUTSIDE the package so that it never
 # ships next to the product library; it must have the ABI of the current binding, ssak_amd/hip.py refuses another one),
-# printing utt/s, ms/step and the top kernel slots.  Make the baseline with: git stash; make; cp ssak_amd/lib/libssak_hip.so build/ab_base.so; git stash pop; make
-BASE=${SSAK_AB_BASE:-$PWD/build/ab_base.so}
+# printing utt/s, ms/step and the top kernel slots.  Make the baseline with: git stash; make; cp ssak_amd/lib/libssak_hip.so tools/ab_base.so; git stash pop; make
+BASE=${SSAK_AB_BASE:-$PWD/tools/ab_base.so}
 N=${1:-3}
 show='import json,sys
 d=json.loads(sys.stdin.read()); r=d["roofline"]

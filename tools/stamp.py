@@ -2,6 +2,7 @@
 
     python tools/stamp.py write        (build container, before a gpurun call: records the commit -- the GPU box has no .git)
     python tools/stamp.py show
+    python tools/stamp.py fetch r03    (build container, after the gpurun call: gpurun_out/r03_* -> profiles/, hashes checked)
 
 ``source_sha256`` = hash over the files the library is built from (ssak_amd/csrc/*, include/*, Makefile), ``lib_sha256`` = the
 built libssak_hip.so.  tools/profile_round.sh embeds ``current()`` in every artefact it writes, bench.py prints it in its JSON
@@ -57,8 +58,25 @@ def current() -> dict:
     return {"commit": commit, "sources_modified_since_commit": dirty, "source_sha256": src, "lib_sha256": lib_sha256()}
 
 
+def fetch(round_name: str):
+    """Build container, after a gpurun call ran tools/profile_round.sh: copy the round's artefacts from gpurun_out/ (what
+    gpurun brings back) into profiles/, checking every file against the hashes the GPU box recorded."""
+    import shutil
+    src = os.path.join(ROOT, "gpurun_out")
+    st = json.load(open(os.path.join(src, f"{round_name}_stamp.json")))
+    for name, sha in st["files"].items():
+        data = open(os.path.join(src, name), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == sha, f"gpurun_out/{name} is not the file the profile run wrote"
+    for name in list(st["files"]) + [f"{round_name}_stamp.json"]:
+        shutil.copyfile(os.path.join(src, name), os.path.join(ROOT, "profiles", name))
+    print("profiles/: fetched", len(st["files"]) + 1, "files of", round_name, "measured on", st["stamp"]["commit"][:10],
+          "library", st["stamp"]["lib_sha256"][:12])
+
+
 def main():
     cmd = sys.argv[1] if len(sys.argv) > 1 else "show"
+    if cmd == "fetch":
+        return fetch(sys.argv[2])
     st = current()
     if cmd == "write":
         os.makedirs(os.path.dirname(COMMIT_FILE), exist_ok=True)
