@@ -26,6 +26,17 @@ REF = "/root/reference"
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
+def _spacing_tables(src: str):
+    """lang_spec_sub / default_sub of tools/align_audio_transcript.py:34-53 evaluated from the file's text (data tables)."""
+    ns = {"re": re}
+    a = src.index("lang_spec_sub = {")
+    b = src.index("DEFAULT_ALIGN_MODELS_TORCH")
+    exec(src[a:b], ns)
+    d = dict(ns["lang_spec_sub"])
+    d["default"] = ns["default_sub"]
+    return d
+
+
 def main():
     sys.path.insert(0, REF)
     from ssak.utils.misc import hashmd5, remove_commonprefix
@@ -75,6 +86,27 @@ def main():
             assert m, ln
             exp[m.group(1)] = m.group(2)
         ws[name] = dict(lines=lines, expected=exp)
+    # text clean-up of the alignment tool (tools/align_audio_transcript.py:78-118) built from the reference's importable pieces;
+    # its emoji / numbers-to-words steps (ssak.utils.text_utils: num2words) are not importable and not on this path
+    from ssak.utils.text_basic import collapse_whitespace, format_special_characters, remove_punctuations, remove_quotes
+    sys.path.insert(0, os.path.join(REF, "tools"))
+    lang_sub = {  # the punctuation-spacing tables of tools/align_audio_transcript.py:34-53, read from the file (it cannot be imported: soxbindings)
+        k: v for k, v in _spacing_tables(open(os.path.join(REF, "tools/align_audio_transcript.py")).read()).items()}
+    strs = ["Bonjour  «le monde» … ça va ?", "l’été – déjà ! Oui:non;peut-être,ok.Fin", "e\u0301te\u0301 a\u0300 la plage", "``quoted'' 'single' \"double\"",
+            "<noise> euh , d ' accord <laugh>", "tiret - isolé - fin -", "1ᵉʳ et 2ᵉ · point", "Œuvre æther", "espaces\u00a0insécables\u202fici",
+            "What?No!Yes:ok", "fin.Début Autre.suite", "a,b ,c , d", "bonjour", "", "   "]
+    cases = []
+    for t in strs:
+        for lang in ("fr", "en"):
+            x = remove_quotes(format_special_characters(t, remove_ligatures=False))
+            x = remove_special_words(x)
+            for a, b in lang_sub.get(lang, lang_sub["default"]):
+                x = re.sub(a, b, x)
+            cases.append([t, lang, collapse_whitespace(x)])
+    out["align_text_normalization"] = cases
+    out["align_word_normalization"] = [[w, lig, pun, (lambda y: (remove_punctuations(y) or y))(format_special_characters(w, remove_ligatures=lig)) if pun
+                                        else format_special_characters(w, remove_ligatures=lig)]
+                                       for w in ["Œuvre,", "(mot)", "...", "l'été.", "straße", "a-b", "«quoi»", "ok ,"] for lig in (False, True) for pun in (False, True)]
     ws["other_forms"] = dict(lines=["a /data/a.wav", "b flac -c -d -s -f /data/b.flac |", "c sox '/data/with space/c.wav' -t wav - |",
                                     "d /usr/bin/sox $DATAPATH/d.mp3 -t wav -r 16000 -b 16 - |"],
                              expected={"a": "/data/a.wav", "b": "/data/b.flac", "c": "/data/with space/c.wav", "d": "$DATAPATH/d.mp3"})

@@ -318,3 +318,44 @@ def test_best_model_tracker_and_checkpoint_rotation(tmp_path):
     assert state["best_metric"] == 0.4 and state["best_model_checkpoint"].endswith("checkpoint-50")
     assert state["early_stopping_patience_counter"] == 3
     assert T.EARLY_STOPPING_PATIENCE == 15  # the reference's patience
+
+
+def test_alignment_tool_text_normalisation_matches_the_reference(gold_json):
+    """The transcript clean-up of ssak_amd.tools.align_audio_transcript (tools/align_audio_transcript.py:78-118 in the
+    reference) against strings produced by IMPORTING the reference's ssak.utils.text_basic and evaluating its
+    punctuation-spacing tables (oracle/gen_golden_host.py): typographic quotes, composed accents, ellipsis, special words,
+    French / default spacing, ligatures and punctuation stripping at word level."""
+    from ssak_amd.tools import align_audio_transcript as T
+    z = gold_json("host_strings.json")
+    assert len(z["align_text_normalization"]) >= 30
+    for text, lang, want in z["align_text_normalization"]:
+        assert T.custom_text_normalization(text, lang=lang) == want, (text, lang)
+    for word, lig, punc, want in z["align_word_normalization"]:
+        got = T.custom_word_normalization(word, "fr", remove_digits=False, remove_punc=punc, remove_ligatures=lig, remove_etset=False)
+        assert got == " ".join(want.split()), (word, lig, punc)
+
+
+def test_alignment_tool_cut_decision_pure_function():
+    """cut_at_word_boundaries against oracle/align_tool_ref.cut_lines (the reference's add_segment loop restated) on random word
+    timings: same pieces, same printed times, plain and refine modes, punctuation-only words, pieces longer than max_duration."""
+    from oracle import align_ref as AR
+    from oracle import align_tool_ref as OT
+    from ssak_amd.align import Segment
+    from ssak_amd.tools import align_audio_transcript as T
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        n = int(rng.integers(1, 40))
+        F = int(rng.integers(50, 1500))
+        cuts = np.sort(rng.integers(0, F, 2 * n))
+        words = ["w%d" % i if rng.random() > 0.1 else "," for i in range(n)]
+        if words[0] == ",":
+            words[0] = "w0"
+        segs = [(w, int(cuts[2 * i]), int(cuts[2 * i + 1]) + 1, float(rng.random())) for i, w in enumerate(words)]
+        audio_len = F * 320 + int(rng.integers(0, 320))
+        for refine in (None, 0.25):
+            maxd = float(rng.choice([0.5, 2.0, 4.0, 30.0]))
+            got = T.cut_at_word_boundaries([Segment(*s) for s in segs], words, F, audio_len, 16000, maxd, refine)
+            want = OT.cut_lines("u", "rec", "spk", 1.5, words, [AR.Segment(*s) for s in segs], F, audio_len, 16000, maxd, refine)
+            lines = [f"u_cut{i:02} rec {1.5 + a:.3f} {1.5 + b:.3f}\n" for i, a, b, _ in got if b > a]
+            assert lines == want["segments"], (trial, refine)
+            assert [f"u_cut{i:02} {t}\n" for i, a, b, t in got if b > a] == want["text"]
