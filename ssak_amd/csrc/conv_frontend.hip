@@ -372,7 +372,8 @@ __global__ void conv0_stats_finalize_kernel(const double* __restrict__ partial, 
 // ---- feature-encoder backward (--no_freeze, ssak/train/transformers/wav2vec_train.py:326-327 off) -------------------
 // input gradient of a channels-last Conv1d(k, s, no padding) from the column form dxcol [B, Tout, k, C]:
 //   dx[u] = sum over taps kk with (u - kk) % s == 0 and t = (u - kk) / s in [0, Tout) of dxcol[t][kk]
-__global__ void col2im_kernel(const bf16* __restrict__ dxcol, bf16* __restrict__ dx, int Tin, int Tout, int C, int k, int s,
+template <typename T_>
+__global__ void col2im_kernel(const T_* __restrict__ dxcol, T_* __restrict__ dx, int Tin, int Tout, int C, int k, int s,
                               long n8) {
   const int hc = C >> 3;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -386,21 +387,12 @@ __global__ void col2im_kernel(const bf16* __restrict__ dxcol, bf16* __restrict__
       if (d < 0 || d % s) continue;
       const int t = d / s;
       if (t >= Tout) continue;
-      const uint4 q = reinterpret_cast<const uint4*>(dxcol)[(((long)b * Tout + t) * k + kk) * hc + c];
-      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+      float q[8];
+      chunk_to_f(ld8<T_>(dxcol + ((((long)b * Tout + t) * k + kk) * hc + c) * 8), q);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[2 * j] += __uint_as_float(w[j] << 16);
-        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
-      }
+      for (int j = 0; j < 8; ++j) acc[j] += q[j];
     }
-    uint32_t o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16x2 t2 = {(bf16)acc[2 * j], (bf16)acc[2 * j + 1]};
-      o[j] = __builtin_bit_cast(uint32_t, t2);
-    }
-    reinterpret_cast<uint4*>(dx)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    st8<T_>(dx + 8 * i, f_to_chunk8<T_>(acc));
   }
 }
 
@@ -416,10 +408,10 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nb, long n
 // conv0 + GroupNorm + GELU backward, recomputing the 10-tap dot products like the forward does.
 //   PASS 0: per (b, c) partial sums of g = dy * gelu'(y) and g * xhat over this workgroup's frames
 //   PASS 1: dv = gamma * rstd * (g - mean_t(g) - xhat * mean_t(g xhat)); partial dW[c][tap] = sum_t dv * x[5t + tap]
-template <int PASS>
+template <int PASS, typename DT>
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const bf16* __restrict__ dy, const double* __restrict__ sums,
+                                                        const DT* __restrict__ dy, const double* __restrict__ sums,
                                                         const double* __restrict__ gsums, float* __restrict__ partial, int T,
                                                         int T0, int C) {
   constexpr int FR0 = FR_STATS, NS0 = (FR0 - 1) * ST0 + KS0;
@@ -459,14 +451,15 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     float xv[KS0];
 #pragma unroll
     for (int k = 0; k < KS0; ++k) xv[k] = xs[f * ST0 + k];
-    const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(dy + ((size_t)b * T0 + f0 + f) * C + q * 4);
+    float d4[4];
+    chunk_to_f(ld4<DT>(dy + ((size_t)b * T0 + f0 + f) * C + q * 4), d4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < KS0; ++k) v = fmaf(wr[j][k], xv[k], v);
       const float xh = (v - mu[j]) * rs[j];
-      const float g = (float)d4[j] * gelu_grad_f(xh * ga[j] + be[j]);
+      const float g = d4[j] * gelu_grad_s<DT>(xh * ga[j] + be[j]);
       if (PASS == 0) {
         acc[j] += g;
         acc[4 + j] = fmaf(g, xh, acc[4 + j]);
@@ -665,7 +658,8 @@ namespace {
 // dw[c][k] = sum_{b,t} d[b,t,c] * x[b, stride t + k].  Workgroup = a contiguous range of frames of one utterance; thread =
 // two channels, 2 * ksize accumulators in registers; the frame's taps are read once per workgroup into LDS.
 constexpr int C0W_BLOCKS_PER_UTT = 32;
-__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const bf16* __restrict__ d, const float* __restrict__ x, float* __restrict__ partial,
+template <typename DT>
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const DT* __restrict__ d, const float* __restrict__ x, float* __restrict__ partial,
                                                           int T, int T0, int C, int ksize, int stride) {
   __shared__ float xs[64 * 5 + 16];  // the samples of 64 frames (stride 5, kernel 10)
   const int b = blockIdx.y, blk = blockIdx.x;
@@ -687,8 +681,8 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const bf16* __restrict
     __syncthreads();
     for (int c2 = threadIdx.x; c2 < C / 2; c2 += 256)  // (C <= 512: one pass)
       for (int tt = 0; tt < nt; ++tt) {
-        const bf16x2 dv = *reinterpret_cast<const bf16x2*>(d + ((size_t)b * T0 + t0 + tt) * C + 2 * c2);
-        const float d0 = (float)dv[0], d1 = (float)dv[1];
+        const DT* dp = d + ((size_t)b * T0 + t0 + tt) * C + 2 * c2;
+        const float d0 = (float)dp[0], d1 = (float)dp[1];
 #pragma unroll
         for (int k = 0; k < 10; ++k)
           if (k < ksize) {
@@ -720,11 +714,12 @@ __global__ void conv0_wgrad_sum_kernel(const float* __restrict__ partial, int ns
 
 size_t k_conv0_wgrad_scratch_floats(int B, int C, int ksize) { return (size_t)B * C0W_BLOCKS_PER_UTT * C * ksize; }
 
-int k_conv0_wgrad(const bf16* d, const float* x, float* dw, float* scratch, int B, int T, int T0, int C, int ksize, int stride,
-                  hipStream_t st) {
+template <typename DT>
+int k_conv0_wgrad_t(const DT* d, const float* x, float* dw, float* scratch, int B, int T, int T0, int C, int ksize, int stride,
+                    hipStream_t st) {
   SSAK_REQUIRE(ksize <= 10 && stride * 64 + ksize <= 64 * 5 + 16 && C <= 512 && (C & 1) == 0,
                "conv0_wgrad: kernel %d / stride %d / C %d outside what is built (k <= 10, stride <= 5, C <= 512)", ksize, stride, C);
-  conv0_wgrad_kernel<<<dim3(C0W_BLOCKS_PER_UTT, B), 256, 0, st>>>(d, x, scratch, T, T0, C, ksize, stride);
+  conv0_wgrad_kernel<DT><<<dim3(C0W_BLOCKS_PER_UTT, B), 256, 0, st>>>(d, x, scratch, T, T0, C, ksize, stride);
   SSAK_LAUNCH_CHECK();
   conv0_wgrad_sum_kernel<<<ssak_cdiv(C * ksize, 256), 256, 0, st>>>(scratch, B * C0W_BLOCKS_PER_UTT, C * ksize, dw);
   SSAK_LAUNCH_CHECK();
@@ -836,10 +831,11 @@ int k_posconv_pack_t(const T* h, T* pg, int B, int F, int H, int G, int K, hipSt
   return SSAK_OK;
 }
 
-int k_col2im(const bf16* dxcol, bf16* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st) {
+template <typename T_>
+int k_col2im_t(const T_* dxcol, T_* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st) {
   SSAK_REQUIRE((C & 7) == 0, "col2im: C must be a multiple of 8");
   const long n8 = (long)B * Tin * C / 8;
-  col2im_kernel<<<min(8192, ssak_cdiv(n8, 256)), 256, 0, st>>>(dxcol, dx, Tin, Tout, C, k, s, n8);
+  col2im_kernel<T_><<<min(8192, ssak_cdiv(n8, 256)), 256, 0, st>>>(dxcol, dx, Tin, Tout, C, k, s, n8);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -856,15 +852,16 @@ size_t k_conv0_bwd_scratch_floats(int B, int T0, int C) {
 }
 
 // dy: gradient w.r.t. the conv0 block output (post GELU) [B, T0, C] bf16; sums: the forward's [B][2C] statistics
-int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, const float* beta, const bf16* dy,
-                        const double* sums, float* scratch, float* dw, float* dgamma, float* dbeta, int B, int T, int T0, int C,
-                        hipStream_t st) {
+template <typename DT>
+int k_conv0_gn_gelu_bwd_t(const float* x, const float* w, const float* gamma, const float* beta, const DT* dy,
+                          const double* sums, float* scratch, float* dw, float* dgamma, float* dbeta, int B, int T, int T0, int C,
+                          hipStream_t st) {
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0_bwd: C=%d must divide into 256 threads as quads", C);
   const int nblk = ssak_cdiv(T0, FR_STATS);
   double* gsums = reinterpret_cast<double*>(scratch);  // [B][C][2]
   float* partial = scratch + (size_t)B * C * 2 * 2 + 16;
   dim3 grid(nblk, B);
-  conv0_bwd_kernel<0><<<grid, 256, 256 * 9 * sizeof(float), st>>>(x, w, gamma, beta, dy, sums, nullptr, partial, T, T0, C);
+  conv0_bwd_kernel<0, DT><<<grid, 256, 256 * 9 * sizeof(float), st>>>(x, w, gamma, beta, dy, sums, nullptr, partial, T, T0, C);
   SSAK_LAUNCH_CHECK();
   conv0_bwd_gsums_kernel<<<dim3(ssak_cdiv(2 * C, 256), B), 256, 0, st>>>(partial, nblk, C, gsums);
   SSAK_LAUNCH_CHECK();
@@ -873,10 +870,10 @@ int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, cons
   constexpr int lds1 = 256 * (4 * KS0 + 1) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    SSAK_HIP(hipFuncSetAttribute((const void*)conv0_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+    SSAK_HIP(hipFuncSetAttribute((const void*)conv0_bwd_kernel<1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
     attr_done = true;
   }
-  conv0_bwd_kernel<1><<<grid, 256, lds1, st>>>(x, w, gamma, beta, dy, sums, gsums, partial, T, T0, C);
+  conv0_bwd_kernel<1, DT><<<grid, 256, lds1, st>>>(x, w, gamma, beta, dy, sums, gsums, partial, T, T0, C);
   SSAK_LAUNCH_CHECK();
   conv0_bwd_dw_kernel<<<ssak_cdiv(C * KS0, 256), 256, 0, st>>>(partial, B * nblk, C, dw);
   SSAK_LAUNCH_CHECK();
@@ -889,7 +886,11 @@ int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, cons
   template int k_conv0_bias_t<T>(const float*, const float*, const float*, T*, int, int, int, int, int, int, hipStream_t);     \
   template int k_conv_weight_rearrange_t<T>(const float*, T*, int, int, int, hipStream_t);                                     \
   template int k_posconv_prepare_t<T>(const float*, const float*, T*, T*, float*, int, int, int, hipStream_t);                 \
-  template int k_posconv_pack_t<T>(const T*, T*, int, int, int, int, int, hipStream_t);
+  template int k_posconv_pack_t<T>(const T*, T*, int, int, int, int, int, hipStream_t);                                        \
+  template int k_col2im_t<T>(const T*, T*, int, int, int, int, int, int, hipStream_t);                                        \
+  template int k_conv0_wgrad_t<T>(const T*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);         \
+  template int k_conv0_gn_gelu_bwd_t<T>(const float*, const float*, const float*, const float*, const T*, const double*,      \
+                                        float*, float*, float*, float*, int, int, int, int, hipStream_t);
 SSAK_INSTANTIATE_CONV_KERNELS(bf16)
 SSAK_INSTANTIATE_CONV_KERNELS(float)
 

@@ -114,15 +114,18 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
 // dw [C][ksize] += sum over frames of d[b,t,c] * x[b, stride*t + k] (conv0 weight gradient of the layer-norm feature encoder,
 // Cin = 1); scratch >= k_conv0_wgrad_scratch_floats() floats; deterministic (per-workgroup partials, fixed-order sum)
 size_t k_conv0_wgrad_scratch_floats(int B, int C, int ksize);
-int k_conv0_wgrad(const bf16* d, const float* x, float* dw, float* scratch, int B, int T, int T0, int C, int ksize, int stride,
+template <typename DT>
+int k_conv0_wgrad_t(const DT* d, const float* x, float* dw, float* scratch, int B, int T, int T0, int C, int ksize, int stride,
                   hipStream_t st);
 template <typename T>
 int k_conv0_bias_t(const float* x, const float* w, const float* bias, T* out, int B, int Tn, int T0, int C, int ksize,
                    int stride, hipStream_t st);
-int k_col2im(const bf16* dxcol, bf16* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st);
+template <typename T_>
+int k_col2im_t(const T_* dxcol, T_* dx, int B, int Tin, int Tout, int C, int k, int s, hipStream_t st);
 int k_sum_slabs(const float* slabs, int nb, long n, float* out, hipStream_t st);
 size_t k_conv0_bwd_scratch_floats(int B, int T0, int C);
-int k_conv0_gn_gelu_bwd(const float* x, const float* w, const float* gamma, const float* beta, const bf16* dy,
+template <typename DT>
+int k_conv0_gn_gelu_bwd_t(const float* x, const float* w, const float* gamma, const float* beta, const DT* dy,
                         const double* sums, float* scratch, float* dw, float* dgamma, float* dbeta, int B, int T, int T0, int C,
                         hipStream_t st);
 template <typename T>
@@ -143,10 +146,15 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
                     bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode /* SSAK_ATTN_BWD_* */, hipStream_t st);
 
 // whisper_frontend.hip
-int k_mel_to_cl(const float* mel, bf16* cl, int B, int C, int T, int RS, int lead, hipStream_t st);
-int k_add_rowvec(const bf16* x, const bf16* pos, bf16* out, int B, int F, int H, hipStream_t st);
-int k_copy_rows_padded(const bf16* src, bf16* dst, int B, int F, int RS, int H, hipStream_t st);
-int k_col2im_k3s2(const bf16* dxcol, const bf16* pre, bf16* out, int B, int F, int Tin, int RS1, int H, hipStream_t st);
+// (T_ = bf16, or float in the fp32-exact mode)
+template <typename T_>
+int k_mel_to_cl_t(const float* mel, T_* cl, int B, int C, int T, int RS, int lead, hipStream_t st);
+template <typename T_>
+int k_add_rowvec_t(const T_* x, const T_* pos, T_* out, int B, int F, int H, hipStream_t st);
+template <typename T_>
+int k_copy_rows_padded_t(const T_* src, T_* dst, int B, int F, int RS, int H, hipStream_t st);
+template <typename T_>
+int k_col2im_k3s2_t(const T_* dxcol, const T_* pre, T_* out, int B, int F, int Tin, int RS1, int H, hipStream_t st);
 int k_conv_wgrad_unrearrange(const float* dwr, float* g, int Co, int Ci, int k, hipStream_t st);
 
 // optim.hip

@@ -257,7 +257,6 @@ void build_param_table(ssak_w2v2* e) {
 
 int check_config(const ssak_w2v2_config& c) {
   if (c.arch == 1) {
-    SSAK_REQUIRE(!c.exact, "whisper: the fp32-exact mode is built for the wav2vec2 topologies");
     SSAK_REQUIRE(c.num_mel_bins > 0 && c.num_mel_bins % 8 == 0 && c.max_source_positions > 0, "whisper: num_mel_bins must be a multiple of 8");
     SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "whisper: head_dim must be a multiple of 8");
     SSAK_REQUIRE(c.hidden_size % 8 == 0 && c.intermediate_size % 8 == 0 && c.vocab_size % 8 == 0, "whisper: d_model / ffn / vocab must be multiples of 8");
@@ -265,7 +264,6 @@ int check_config(const ssak_w2v2_config& c) {
     return SSAK_OK;
   }
   SSAK_REQUIRE(c.arch == 0, "w2v2: arch must be 0 (wav2vec2) or 1 (whisper encoder)");
-  SSAK_REQUIRE(!c.exact || c.freeze_feature_encoder, "w2v2: the fp32-exact mode is built for the frozen feature encoder");
   SSAK_REQUIRE(c.num_conv_layers >= 2 && c.num_conv_layers <= 8, "w2v2: num_conv_layers %d unsupported", c.num_conv_layers);
   SSAK_REQUIRE(c.feat_extract_norm == 0 || c.feat_extract_norm == 1, "w2v2: feat_extract_norm must be 0 (group) or 1 (layer)");
   SSAK_REQUIRE(c.hidden_size % c.num_heads == 0 && (c.hidden_size / c.num_heads) % 8 == 0, "w2v2: head_dim must be a multiple of 8");
@@ -618,8 +616,9 @@ extern "C" int ssak_w2v2_create(const ssak_w2v2_config* cfg, ssak_w2v2** out) {
   const long H = c.hidden_size, K = c.num_conv_pos_embeddings;
   const long cg = c.arch == 1 ? 8 : H / c.num_conv_pos_embedding_groups;
   if (c.arch == 1) {
-    SSAK_HIP(hipMalloc((void**)&e->conv_w[1], (size_t)H * 3 * c.num_mel_bins * sizeof(bf16)));
-    SSAK_HIP(hipMalloc((void**)&e->conv_w[2], (size_t)H * 3 * H * sizeof(bf16)));
+    const size_t wsz = c.exact ? sizeof(float) : sizeof(bf16);
+    SSAK_HIP(hipMalloc((void**)&e->conv_w[1], (size_t)H * 3 * c.num_mel_bins * wsz));
+    SSAK_HIP(hipMalloc((void**)&e->conv_w[2], (size_t)H * 3 * H * wsz));
     *out = e;
     return SSAK_OK;
   }
@@ -737,8 +736,13 @@ extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
   if (c.arch == 1) {
     if (full) TRY(k_cast_f32_bf16(e->P, e->W, e->n_total, st));
     // the conv weights are trainable here: their [Co][k][Ci] GEMM layouts follow every optimizer step
-    TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_c1w, (bf16*)e->conv_w[1], c.hidden_size, c.num_mel_bins, 3, st));
-    TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_c2w, (bf16*)e->conv_w[2], c.hidden_size, c.hidden_size, 3, st));
+    if (c.exact) {
+      TRY(k_conv_weight_rearrange_t<float>(e->P + e->p_c1w, (float*)e->conv_w[1], c.hidden_size, c.num_mel_bins, 3, st));
+      TRY(k_conv_weight_rearrange_t<float>(e->P + e->p_c2w, (float*)e->conv_w[2], c.hidden_size, c.hidden_size, 3, st));
+    } else {
+      TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_c1w, (bf16*)e->conv_w[1], c.hidden_size, c.num_mel_bins, 3, st));
+      TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_c2w, (bf16*)e->conv_w[2], c.hidden_size, c.hidden_size, 3, st));
+    }
     return SSAK_OK;
   }
   if (full) {
@@ -755,7 +759,10 @@ extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
   if (!full && !c.freeze_feature_encoder) {  // trainable feature encoder: the conv GEMM layouts follow the optimizer
     long cin2 = c.conv_dim[0];
     for (int i = 1; i < c.num_conv_layers; ++i) {
-      TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_conv_w[i], (bf16*)e->conv_w[i], c.conv_dim[i], (int)cin2, c.conv_kernel[i], st));
+      if (c.exact)
+        TRY(k_conv_weight_rearrange_t<float>(e->P + e->p_conv_w[i], (float*)e->conv_w[i], c.conv_dim[i], (int)cin2, c.conv_kernel[i], st));
+      else
+        TRY(k_conv_weight_rearrange_t<bf16>(e->P + e->p_conv_w[i], (bf16*)e->conv_w[i], c.conv_dim[i], (int)cin2, c.conv_kernel[i], st));
       cin2 = c.conv_dim[i];
     }
   }
@@ -843,20 +850,20 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   int32_t* flens = nullptr;
   const bool stable = whisper || c.do_stable_layer_norm != 0;
   if (whisper) {
-   if constexpr (!EXACT) {
+   {
     // ---- a14 front end: mel [B, NM, Tin] -> channels-last padded -> conv1+GELU -> conv2(s2)+GELU -> + positions
     const int NM = c.num_mel_bins, Tin = p.Tin, RS1 = p.RS1;
     SSAK_REQUIRE(!lens, "whisper: fixed-length windows, no attention mask (modeling_whisper.py:605-607)");
     SSAK_HIP(hipMemsetAsync(ws + p.melcl, 0, ((size_t)B * RS1 + 8) * NM * sizeof(AT), st));
     SSAK_HIP(hipMemsetAsync(ws + p.h1pad, 0, ((size_t)B * RS1 + 8) * H * sizeof(AT), st));
-    TRY(k_mel_to_cl(input_values, BF(p.melcl), B, NM, Tin, RS1, 1, st));
+    TRY(k_mel_to_cl_t<AT>(input_values, BF(p.melcl), B, NM, Tin, RS1, 1, st));
     TRY(GemmX<EXACT>(Tin, H, 3 * NM).a(BF(p.melcl), NM).b(e->conv_w[1], 3 * NM).c(BF(p.h1pad) + H, H)
             .batch(B, 1, (long)RS1 * NM, 0, 0, 0, (long)RS1 * H, 0).with_bias(P + e->p_c1b)
             .epi(SSAK_EPI_GELU, nullptr, BF(p.pre1) + H).run(st));
     TRY(GemmX<EXACT>(F, H, 3 * H).a(BF(p.h1pad), 2 * H).b(e->conv_w[2], 3 * H).c(BF(p.we), H)
             .batch(B, 1, (long)RS1 * H, 0, 0, 0, (long)F * H, 0).with_bias(P + e->p_c2b)
             .epi(SSAK_EPI_GELU, nullptr, BF(p.wpre2)).run(st));
-    TRY(k_add_rowvec(BF(p.we), W + e->p_pos, BF(p.h1), B, F, H, st));
+    TRY(k_add_rowvec_t<AT>(BF(p.we), W + e->p_pos, BF(p.h1), B, F, H, st));
     // residual stream r = dropout(conv + pos); x0 = self_attn_layer_norm of layer 0
     TRY(k_layernorm_fwd_t<AT>(BF(p.h1), nullptr, P + e->lp[0].ln1w, P + e->lp[0].ln1b, BF(p.h1), BF(p.x[0]), FP(p.stE),
                         FP(p.stE) + M, M, H, c.layer_norm_eps, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
@@ -1312,20 +1319,20 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
                         Gd + e->lp[0].ln1b, FP(p.lnpart), M, H, none, none, st, DS(c.hidden_dropout, DS_ENCIN)));
   }
   if (whisper) {
-   if constexpr (!EXACT) {
+   {
     // ---- a14 front end backward: r = dropout(gelu(conv2(gelu(conv1(mel)))) + pos); positions are fixed
     const int NM = c.num_mel_bins, Tin = p.Tin, RS1 = p.RS1, RS2 = p.RS2;
     AT* dpre2 = BF(p.dY);
     TRY(k_gelu_grad_mul_t<AT>(dh1, BF(p.wpre2), dpre2, (long)M * H, st));
     TRY(k_colsum_t<AT>(dpre2, H, M, H, Gd + e->p_c2b, st, FP(p.lnpart), cs_floats));
-    TRY(k_copy_rows_padded(dpre2, BF(p.dpre2pad), B, F, RS2, H, st));
+    TRY(k_copy_rows_padded_t<AT>(dpre2, BF(p.dpre2pad), B, F, RS2, H, st));
     // dW2[n][tap*H + c] = sum over rows kk = b*RS2 + t of dy[kk][n] * h1pad[2*kk + tap][c]   (one long-K GEMM)
     TRY(GemmX<EXACT>(H, 3 * H, B * RS2).a(BF(p.dpre2pad), H, true).b(BF(p.h1pad), 2 * H, true).c(FP(p.dwr), 3 * H, true)
             .run_wgrad(st, slab, p.slab_bytes));
     TRY(k_conv_wgrad_unrearrange(FP(p.dwr), Gd + e->p_c2w, H, H, 3, st));
     // input gradient in column form, then col2im (+ GELU' of conv1's pre-activation)
     TRY(GemmX<EXACT>(M, 3 * H, H).a(dpre2, H).b(e->conv_w[2], 3 * H, true).c(BF(p.dxcol), 3 * H).run(st));
-    TRY(k_col2im_k3s2(BF(p.dxcol), BF(p.pre1), BF(p.dpre1pad), B, F, Tin, RS1, H, st));
+    TRY(k_col2im_k3s2_t<AT>(BF(p.dxcol), BF(p.pre1), BF(p.dpre1pad), B, F, Tin, RS1, H, st));
     TRY(k_colsum_t<AT>(BF(p.dpre1pad), H, B * RS1, H, Gd + e->p_c1b, st, FP(p.lnpart), cs_floats));
     TRY(GemmX<EXACT>(H, 3 * NM, B * RS1).a(BF(p.dpre1pad), H, true).b(BF(p.melcl), NM, true).c(FP(p.dwr), 3 * NM, true)
             .run_wgrad(st, slab, p.slab_bytes));
@@ -1376,7 +1383,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   AT* dfeat = p.fe_train ? (((nc - 1) & 1) ? BF(p.fe_db) : BF(p.fe_da)) : BF(p.ln0);  // frozen: scratch, never read
   TRY(k_layernorm_bwd_t<AT>(BF(p.dln0), nullptr, BF(p.feat), FP(p.st0), FP(p.st0) + M, P + e->p_fpln_w, nullptr, dfeat, nullptr,
                       Gd + e->p_fpln_w, Gd + e->p_fpln_b, FP(p.lnpart), M, C, none, none, st));
-  if constexpr (!EXACT) if (p.fe_train) {
+  if (p.fe_train) {
     const bool ln_fe = c.feat_extract_norm == 1;
     // ---- a3 backward (--no_freeze): conv stack in reverse.  Per layer: GELU', weight gradient as per-utterance
     // K-major GEMMs on the overlapping-row operand (slabs summed in a fixed order), input gradient in column form
@@ -1402,17 +1409,17 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       TRY(k_conv_wgrad_unrearrange(FP(p.fe_dwr), Gd + e->p_conv_w[i], Co, Ci, k, st));
       TRY(GemmX<EXACT>(Ti, k * Ci, Co).a(BF(p.fe_dp), Co).b(e->conv_w[i], (long)k * Ci, true).c(BF(p.fe_dxcol), (long)k * Ci)
               .batch(B, 1, (long)Ti * Co, 0, 0, 0, (long)Ti * k * Ci, 0).run(st));
-      TRY(k_col2im(BF(p.fe_dxcol), dprev, B, Tp, Ti, Ci, k, s, st));
+      TRY(k_col2im_t<AT>(BF(p.fe_dxcol), dprev, B, Tp, Ti, Ci, k, s, st));
     }
     if (ln_fe) {
       const int C0 = c.conv_dim[0], T0 = p.Tl[0];
       TRY(k_layernorm_bwd_t<AT>(BF(p.fe_da), nullptr, BF(p.cpre[0]), FP(p.fe_st[0]), FP(p.fe_st[0]) + (size_t)B * T0, P + e->p_cln_w[0], nullptr,
                           BF(p.fe_dp), BF(p.fe_dp), Gd + e->p_cln_w[0], Gd + e->p_cln_b[0], FP(p.lnpart), B * T0, C0, none, none, st, none,
                           c.conv_bias ? Gd + e->p_conv_b[0] : nullptr, P + e->p_cln_b[0]));
-      TRY(k_conv0_wgrad(BF(p.fe_dp), e->last_input, Gd + e->p_conv_w[0], FP(p.fe_c0), B, p.T, T0, C0, c.conv_kernel[0],
+      TRY(k_conv0_wgrad_t<AT>(BF(p.fe_dp), e->last_input, Gd + e->p_conv_w[0], FP(p.fe_c0), B, p.T, T0, C0, c.conv_kernel[0],
                         c.conv_stride[0], st));
     } else {
-      TRY(k_conv0_gn_gelu_bwd(e->last_input, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0], BF(p.fe_da),
+      TRY(k_conv0_gn_gelu_bwd_t<AT>(e->last_input, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0], BF(p.fe_da),
                               (const double*)(ws + p.stats0), FP(p.fe_c0), Gd + e->p_conv_w[0], Gd + e->p_cln_w[0],
                               Gd + e->p_cln_b[0], B, p.T, p.Tl[0], c.conv_dim[0], st));
     }

@@ -61,15 +61,18 @@ class WhisperEncoderForCTC(Wav2Vec2ForCTC):
 
     """``model(input_features [B, 80, 2*frames], labels=...)`` -> ``.loss`` / ``.logits [B, frames, V]``."""
 
-    def __init__(self, config: WhisperCTCConfig, device: str = "cuda:0", seed: int = 69):
+    def __init__(self, config: WhisperCTCConfig, device: str = "cuda:0", seed: int = 69, exact: bool = False):
+        """``exact``: the fp32-exact verification mode of the engine (float activations, fp32 matrix products)."""
         if not torch.cuda.is_available():
             raise RuntimeError("ssak_amd needs an MI355X: there is no CPU fallback for the acoustic model")
         self.config = config
         self.device = torch.device(device)
         self.training = False
         self.freeze = True
+        self.exact = bool(exact)
         c = hip.W2V2Config()
         c.arch = 1
+        c.exact = int(self.exact)
         c.vocab_size = (config.vocab_size + 7) // 8 * 8
         c.hidden_size, c.num_layers = config.d_model, config.encoder_layers
         c.num_heads, c.intermediate_size = config.encoder_attention_heads, config.encoder_ffn_dim
