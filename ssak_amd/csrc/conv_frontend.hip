@@ -158,6 +158,9 @@ __global__ __launch_bounds__(256) void conv0_bias_kernel(const float* __restrict
 //   in LDS (64 B per frame), the weight fragments once per wave in registers.  Orientation out^T[channel][frame] = W X^T: a
 //   lane then holds four consecutive channels of one frame, which go through a wave-private, XOR-swizzled LDS tile
 //   ([16 frames][128 channels], 8-byte writes) and leave as 16-byte stores of whole 256-byte row segments.
+#ifndef C0M_HALF_SWAP
+#define C0M_HALF_SWAP 1  // (0: the round-2 store tile, for A/B builds)
+#endif
 constexpr int C0M_FR = 128;
 constexpr int C0M_NS = (C0M_FR - 1) * ST0 + KS0;  // 645 input samples
 typedef __attribute__((ext_vector_type(2))) float c0_f32x2;
@@ -271,15 +274,19 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
       for (int ct = 0; ct < 8; ++ct) {
         const c0_f32x2 o0 = y[2 * ct] * q[2 * ct], o1 = y[2 * ct + 1] * q[2 * ct + 1];
         const bf16x4 o = {(bf16)o0[0], (bf16)o0[1], (bf16)o1[0], (bf16)o1[1]};
-        // row lc of the wave's tile, channels 16 ct + 4 g .. + 3: 16-byte chunk 2 ct + (g >> 1), half (g & 1)
-        *reinterpret_cast<bf16x4*>(ost + lc * 256 + (((2 * ct + (g >> 1)) ^ lc) << 4) + (g & 1) * 8) = o;
+        // row lc of the wave's tile, channels 16 ct + 4 g .. + 3: 16-byte chunk 2 ct + (g >> 1), half (g & 1).  The sixteen
+        // lanes of a store group (one g, lc = 0..15) write 8 bytes each = all 32 banks exactly when their 8-byte slots differ:
+        // the chunk swizzle alone sends rows lc and lc + 8 to the same slot (2-way conflict on every store: rocprofv3 counted
+        // SQ_LDS_BANK_CONFLICT = 24 % of the LDS cycles), so rows 8..15 also swap the two halves of a chunk (undone at the read)
+        *reinterpret_cast<bf16x4*>(ost + lc * 256 + (((2 * ct + (g >> 1)) ^ lc) << 4) + (((g & 1) ^ (C0M_HALF_SWAP ? lc >> 3 : 0)) << 3)) = o;
       }
     }
     // the tile leaves as whole 256-byte row segments: lane = (row 4 pass + g, chunk lc)
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = 4 * pass + g;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ost + r * 256 + ((lc ^ r) << 4));
+      f32x4 v = *reinterpret_cast<const f32x4*>(ost + r * 256 + ((lc ^ r) << 4));
+      if (C0M_HALF_SWAP && pass >= 2) v = (f32x4){v[2], v[3], v[0], v[1]};  // rows 8..15 were stored with their chunk halves swapped
       const int frame = f0 + 16 * ft + r;
       if (frame < T0) *reinterpret_cast<f32x4*>(out + ((size_t)b * T0 + frame) * C + 128 * wave + 8 * lc) = v;
     }

@@ -4,10 +4,15 @@
 // (transformers modeling_wav2vec2.py:1705-1728; configured by ssak/train/transformers/wav2vec_train.py:319,325)
 // and behind argmax + batch_decode's collapse (ssak/infer/transformers_infer.py:84-85).
 //
-// One 512-thread workgroup per utterance.  Waves 0-3 run the alpha recursion forwards while waves 4-7 run
-// the beta recursion backwards, one workgroup barrier per frame; the current lattice row lives in LDS
-// (ping-pong), the full lattices go to an L2-resident scratch.  The gradient pass then walks the frames one
-// wave per frame, lanes over lattice states, summing posteriors per symbol with LDS float atomics.
+// Three launches per step: ctc_lsm (log-softmax, one wave per (utterance, frame) over the whole chip), ctc_lat<SPL> (the
+// alpha / beta recursion, WAVE-RESIDENT: one workgroup per utterance, alpha on wave 0 and beta on wave 1, a lane owns
+// SPL = 4 / 8 / 16 consecutive lattice states in registers, the neighbour's edge state arrives by one DPP wave shift per
+// frame, no LDS and no barrier inside the frame loop, log-probabilities gathered 8 frames ahead into a register ring) and
+// ctc_grad (one wave per (utterance, frame), lanes over lattice states; posteriors per symbol are summed in wave-private LDS
+// bins with LDS float atomics -- order within a wave-instruction is fixed by the hardware, so runs are bit-reproducible in
+// practice, but it is an atomic, not a fixed-order tree).  Label sequences beyond 511 tokens fall back to the monolithic
+// kernel at the end of this file: one 512-thread workgroup per utterance, waves 0-3 alpha / waves 4-7 beta, one barrier per
+// frame, lattice rows in LDS (ping-pong), full lattices in an L2-resident scratch.
 // Latency-bound by construction (F sequential frames); all arithmetic fp32 in the log domain.
 #include <stdlib.h>
 

@@ -259,6 +259,12 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     }
     c.g = 0;
     const int zs = id / per_z, rem = id % per_z;
+    // (Row-major over the tiles: an XCD's 32 concurrent workgroups then share 2.7 row panels x all column panels.  An 8 x 4
+    // "supertile" walk for the wide feed-forward outputs -- the same 8 row panels revisited with the next 4 column panels each
+    // round, so that activations are fetched once per XCD and only a third of the weight matrix is live per round -- was
+    // measured in round 3 and is SLOWER: feed-forward up 1 166 -> 1 268 us per step, dX 1 121 -> 1 160
+    // (profiles/r03_ab_supertile_walk_slower.log): with 8 distinct row panels in flight per XCD a row panel is shared by 4
+    // workgroups instead of 12.)
     const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
     c.split = zs % p.split_k;
     c.z = zs / p.split_k;

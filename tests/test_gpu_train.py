@@ -498,7 +498,8 @@ def test_bench_two_rank_rehearsal_reports_the_exchange(tmp_path):
 
 
 def test_train_step_is_bitwise_reproducible():
-    """No float atomics on the path: two runs from the same seed (dropout, LayerDrop and SpecAugment ON) end in bit-identical
+    """No GLOBAL float atomics on the path (the CTC gradient sums posteriors in wave-private LDS bins with LDS atomics, whose
+    order is fixed within a wave-instruction): two runs from the same seed (dropout, LayerDrop and SpecAugment ON) end in bit-identical
     parameters and losses -- bias gradients, the SpecAugment embedding gradient and the clip norm are all fixed-order sums."""
     from oracle import w2v2_ref as R
     from ssak_amd.config import Wav2Vec2Config
