@@ -392,3 +392,47 @@ def test_exact_no_freeze_feature_encoder_gradients(topology):
     assert (model.param("wav2vec2.feature_extractor.conv_layers.3.conv.weight") - w_before).abs().max().item() > 0
     out2 = model(torch.tensor(x), lengths=None if lens is None else torch.tensor(lens), labels=torch.tensor(labels))
     assert out2.loss.item() != out.loss.item()
+
+
+def test_exact_bucketed_mixed_length_epoch_vs_oracle():
+    """BASELINE config 5's data path at tiny dimensions, end to end in the fp32-exact mode: XLSR topology (layer-norm feature
+    encoder with bias, stable LayerNorm, attention mask), 14 utterances with durations log-uniform in [0.25 s, 1.2 s], batches
+    built by length grouping (HF LengthGroupedSampler: ssak_amd.data.length_grouped_batches), padded to the longest with masks,
+    the short last batch trained -- one epoch of optimizer steps (AdamW, clip 1.0, warm-up) against eager torch fp32 from the same
+    init: every step's loss within 1e-4 (7 x 4 different padded shapes: a new workspace plan per batch)."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.data import length_grouped_batches
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer, linear_warmup_lr
+    oc = R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True).deterministic()
+    p0 = R.init_params(oc, 29)
+    rng = np.random.default_rng(12)
+    lens = [int(16000 * np.exp(rng.uniform(np.log(0.25), np.log(1.2)))) for _ in range(14)]
+    waves = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    texts = [list(rng.integers(1, 32, max(1, n // 4000))) for n in lens]
+    batches = length_grouped_batches(lens, 4, np.random.RandomState(7), mega_factor=2)
+    assert sorted(sum(batches, [])) == list(range(14)) and [len(b) for b in batches].count(4) >= 2 and min(len(b) for b in batches) < 4
+    lr, warm = 3e-4, 2
+    names = R.trainable_names(oc)
+    q = {n: (t.clone().requires_grad_(n in names)) for n, t in p0.items()}
+    opt = torch.optim.AdamW([q[n] for n in names], lr=lr, weight_decay=0.0)
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc), exact=True).train()
+    model.load_state_dict(p0)
+    tr = Trainer(model, AdamW(model, lr=lr, warmup_steps=warm, total_steps=1000, max_grad_norm=1.0))
+    worst = 0.0
+    for s, idx in enumerate(batches):
+        bl = [lens[i] for i in idx]
+        x = R.zero_mean_unit_var_norm([waves[i] for i in idx])
+        lab = R.pad_labels([texts[i] for i in idx])
+        for g in opt.param_groups:
+            g["lr"] = linear_warmup_lr(lr, s, warm, 1000)
+        loss, _ = R.forward(q, oc, torch.tensor(x), bl, torch.tensor(lab))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([q[n] for n in names], 1.0)
+        opt.step()
+        got = float(tr.train_step(torch.tensor(x).cuda(), torch.tensor(bl).cuda(), torch.tensor(lab).cuda(), raw=False).item())
+        worst = max(worst, abs(got - loss.item()) / abs(loss.item()))
+    print("exact bucketed epoch:", len(batches), "steps, shapes", sorted({(len(b), max(lens[i] for i in b)) for b in batches})[:3], "... max rel", worst)
+    assert worst < 1e-4
