@@ -174,6 +174,8 @@ def main():
     trainer = Trainer(model, opt, measure_stall=True)
     if os.environ.get("SSAK_TILE_ORDER") == "1":  # development switch: ticket tile order without a process group
         model.set_option(hip.W2V2_OPT_DYNAMIC_TILES, 1)
+    if os.environ.get("SSAK_BENCH_POSCONV_GEMM") == "1":  # A/B switch: the positional convolution as the Toeplitz GEMM of rounds 1-2
+        model.set_option(hip.W2V2_OPT_POSCONV_DIRECT, 0)
     trainer.broadcast_parameters()
 
     T = int(round(args.seconds * 16000))

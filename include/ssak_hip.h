@@ -337,9 +337,13 @@ int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begi
 /* Per-handle execution options (nothing here changes results beyond rounding; no process-wide switches):
  * SSAK_W2V2_OPT_DYNAMIC_TILES  0 / 1: ssak_gemm_desc.dynamic_tiles of every product the engine launches -- the data-parallel
  *                              trainers set it, RCCL's kernels share the chip with the persistent GEMMs;
- * SSAK_W2V2_OPT_ATTENTION_BWD  SSAK_ATTN_BWD_*: the form of the fused attention backward. */
+ * SSAK_W2V2_OPT_ATTENTION_BWD  SSAK_ATTN_BWD_*: the form of the fused attention backward;
+ * SSAK_W2V2_OPT_POSCONV_DIRECT  1 (default) / 0: the grouped positional convolution as a direct convolution with its input
+ *                              window resident in LDS (group widths 48 and 64) or as the Toeplitz GEMM of rounds 1-2 (kept for
+ *                              other geometries and as the comparison path of the tests). */
 #define SSAK_W2V2_OPT_DYNAMIC_TILES 1
 #define SSAK_W2V2_OPT_ATTENTION_BWD 2
+#define SSAK_W2V2_OPT_POSCONV_DIRECT 3
 int ssak_w2v2_set_option(ssak_w2v2* h, int option, int value);
 /* The gradient ranges ssak_w2v2_backward announces, in announcement order, from the configuration alone (host arithmetic, no
  * device): head matrix, one range per encoder layer from the last to the first (a layer's q|k|v|out|ffn matrices are

@@ -6,7 +6,7 @@
 // GEMM instantiation registers a slot under its own name (as rocprofv3 prints it) the first time it is launched.
 enum : int {
   PROF_ATTN_FWD = 0, PROF_ATTN_BWD, PROF_LN_FWD, PROF_LN_BWD, PROF_CONV0, PROF_ADAMW, PROF_SUMSQ, PROF_CTC, PROF_WAVE_NORM,
-  PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX,
+  PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX, PROF_POSCONV_DIRECT,
   PROF_CLASS_SLOTS
 };
 constexpr int PROF_MAX_SLOTS = 128;
@@ -144,6 +144,12 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens
                     const DropSpec& drop, hipStream_t st);
 int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const int32_t* klens, const bf16* dctx, float* delta,
                     bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode /* SSAK_ATTN_BWD_* */, hipStream_t st);
+
+// posconv.hip: the grouped positional convolution as a direct convolution (input window resident in LDS)
+bool k_posconv_direct_supported(int H, int G, int K);
+int k_posconv_frag_weights(const bf16* w, bf16* wfrag, int H, int G, int K, hipStream_t st);
+int k_posconv_direct(const bf16* x, long rows_per_group, int row0, const bf16* w, const float* bias, bf16* out, bf16* pre, int B, int F,
+                     int H, int G, int K, int gelu, hipStream_t st);
 
 // whisper_frontend.hip
 // (T_ = bf16, or float in the fp32-exact mode)

@@ -106,6 +106,8 @@ struct ssak_w2v2 {
   void* conv_w[8] = {nullptr};
   void* pc_wf = nullptr;
   void* pc_wb = nullptr;
+  bf16* pc_wf_frag = nullptr;  // fragment-ordered copies for the direct positional-conv kernel (posconv.hip)
+  bf16* pc_wb_frag = nullptr;
   float* pc_norms = nullptr;  // [2K]: ||v||^2 per tap | scratch
   Plan plan;
   bool have_fwd = false;
@@ -122,6 +124,7 @@ struct ssak_w2v2 {
   // per-handle execution options (ssak_w2v2_set_option)
   int dynamic_tiles = 0;
   int attn_bwd_mode = SSAK_ATTN_BWD_DEFAULT;
+  int posconv_direct = 1;
 };
 
 namespace {
@@ -630,6 +633,10 @@ extern "C" int ssak_w2v2_create(const ssak_w2v2_config* cfg, ssak_w2v2** out) {
   }
   SSAK_HIP(hipMalloc((void**)&e->pc_wf, (size_t)H * K * cg * esz));
   SSAK_HIP(hipMalloc((void**)&e->pc_wb, (size_t)H * K * cg * esz));
+  if (!c.exact && k_posconv_direct_supported((int)H, c.num_conv_pos_embedding_groups, (int)K)) {
+    SSAK_HIP(hipMalloc((void**)&e->pc_wf_frag, (size_t)H * K * cg * sizeof(bf16)));
+    SSAK_HIP(hipMalloc((void**)&e->pc_wb_frag, (size_t)H * K * cg * sizeof(bf16)));
+  }
   SSAK_HIP(hipMalloc((void**)&e->pc_norms, (size_t)(2 + c.hidden_size) * K * sizeof(float)));  // norms | dot | [H][K] partials
   *out = e;
   return SSAK_OK;
@@ -641,6 +648,8 @@ extern "C" void ssak_w2v2_destroy(ssak_w2v2* e) {
     if (e->conv_w[i]) (void)hipFree(e->conv_w[i]);
   if (e->pc_wf) (void)hipFree(e->pc_wf);
   if (e->pc_wb) (void)hipFree(e->pc_wb);
+  if (e->pc_wf_frag) (void)hipFree(e->pc_wf_frag);
+  if (e->pc_wb_frag) (void)hipFree(e->pc_wb_frag);
   if (e->pc_norms) (void)hipFree(e->pc_norms);
   delete e;
 }
@@ -681,6 +690,8 @@ extern "C" int ssak_w2v2_set_option(ssak_w2v2* e, int option, int value) {
   } else if (option == SSAK_W2V2_OPT_ATTENTION_BWD) {
     SSAK_REQUIRE(value >= SSAK_ATTN_BWD_DEFAULT && value <= SSAK_ATTN_BWD_FUSED, "w2v2_set_option: attention backward form %d", value);
     e->attn_bwd_mode = value;
+  } else if (option == SSAK_W2V2_OPT_POSCONV_DIRECT) {
+    e->posconv_direct = value ? 1 : 0;
   } else {
     ssak_set_error("w2v2_set_option: unknown option %d", option);
     return SSAK_ERR_INVALID;
@@ -769,9 +780,14 @@ extern "C" int ssak_w2v2_sync_weights(ssak_w2v2* e, int full, void* stream) {
   if (c.exact)
     TRY(k_posconv_prepare_t<float>(e->P + e->p_pc_g, e->P + e->p_pc_v, (float*)e->pc_wf, (float*)e->pc_wb, e->pc_norms, c.hidden_size,
                                    c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
-  else
+  else {
     TRY(k_posconv_prepare_t<bf16>(e->P + e->p_pc_g, e->P + e->p_pc_v, (bf16*)e->pc_wf, (bf16*)e->pc_wb, e->pc_norms, c.hidden_size,
                                   c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
+    if (e->pc_wf_frag) {
+      TRY(k_posconv_frag_weights((const bf16*)e->pc_wf, e->pc_wf_frag, c.hidden_size, c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
+      TRY(k_posconv_frag_weights((const bf16*)e->pc_wb, e->pc_wb_frag, c.hidden_size, c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings, st));
+    }
+  }
   return SSAK_OK;
 }
 
@@ -931,14 +947,22 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   TRY(k_specaug_fwd_t<AT>(BF(p.h0), spec_mask, flens, P + e->p_mse, B, F, H, st));
   // ---- a6: positional conv (grouped, weight-normed) + GELU, residual, LayerNorm, dropout
   TRY(k_posconv_pack_t<AT>(BF(p.h0), BF(p.pgx), B, F, H, G, K, st));
-  TRY(GemmX<EXACT>(F, cg, K * cg)
-          .a(BF(p.pgx), cg)
-          .b(e->pc_wf, (long)K * cg)
-          .c(BF(p.pc), H)
-          .batch(B, G, (long)(F + K) * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
-          .with_bias(P + e->p_pc_b, cg)
-          .epi(SSAK_EPI_GELU, nullptr, BF(p.pc_pre))
-          .run(st));
+  bool pc_direct = false;
+  if constexpr (!EXACT) pc_direct = e->posconv_direct && e->pc_wf_frag != nullptr;
+  if (pc_direct) {
+    // direct convolution: the 512 + 127 input rows of a workgroup's frames stay in LDS (posconv.hip)
+    if constexpr (!EXACT)
+      TRY(k_posconv_direct(BF(p.pgx), p.pg_rows, 0, e->pc_wf_frag, P + e->p_pc_b, BF(p.pc), BF(p.pc_pre), B, F, H, G, K, 1, st));
+  } else {
+    TRY(GemmX<EXACT>(F, cg, K * cg)
+            .a(BF(p.pgx), cg)
+            .b(e->pc_wf, (long)K * cg)
+            .c(BF(p.pc), H)
+            .batch(B, G, (long)(F + K) * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
+            .with_bias(P + e->p_pc_b, cg)
+            .epi(SSAK_EPI_GELU, nullptr, BF(p.pc_pre))
+            .run(st));
+  }
   if (!stable) {
     // post-LN (base): x0 = dropout(LN(h0 + pos))                                       (modeling_wav2vec2.py:694-697)
     TRY(k_layernorm_fwd_t<AT>(BF(p.pc), BF(p.h0), P + e->p_eln_w, P + e->p_eln_b, BF(p.h1), BF(p.x[0]), FP(p.stE), FP(p.stE) + M,
@@ -1359,12 +1383,19 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     TRY(k_posconv_weight_bwd(FP(p.dwf), P + e->p_pc_g, P + e->p_pc_v, e->pc_norms, Gd + e->p_pc_g, Gd + e->p_pc_v, H, G, K, st));
     // input gradient: correlation of dy with the flipped, transposed taps
     const int shift = 2 * (K / 2) - K + 1;  // 1 for even K (SamePad drops the last frame), 0 for odd
-    TRY(GemmX<EXACT>(F, cg, K * cg)
-            .a(BF(p.pgdy) + (long)shift * cg, cg)
-            .b(e->pc_wb, (long)K * cg)
-            .c(BF(p.dB), H)
-            .batch(B, G, (long)RS * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
-            .run(st));
+    bool pc_direct = false;
+    if constexpr (!EXACT) pc_direct = e->posconv_direct && e->pc_wf_frag != nullptr;
+    if (pc_direct) {
+      if constexpr (!EXACT)
+        TRY(k_posconv_direct(BF(p.pgdy), p.pg_rows, shift, e->pc_wb_frag, nullptr, BF(p.dB), nullptr, B, F, H, G, K, 0, st));
+    } else {
+      TRY(GemmX<EXACT>(F, cg, K * cg)
+              .a(BF(p.pgdy) + (long)shift * cg, cg)
+              .b(e->pc_wb, (long)K * cg)
+              .c(BF(p.dB), H)
+              .batch(B, G, (long)RS * cg, p.pg_rows * cg, 0, (long)cg * K * cg, (long)F * H, cg)
+              .run(st));
+    }
   }
   AT* dh0 = (dh1 == BF(p.dA)) ? BF(p.dC) : BF(p.dA);
   TRY(k_add_t<AT>(dh1, BF(p.dB), dh0, (long)M * H, st));

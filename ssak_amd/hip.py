@@ -339,7 +339,7 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
 
 
 ATTN_BWD_DEFAULT, ATTN_BWD_TWO_KERNEL, ATTN_BWD_FUSED = 0, 1, 2
-W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD = 1, 2
+W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD, W2V2_OPT_POSCONV_DIRECT = 1, 2, 3
 
 
 def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0,

@@ -307,3 +307,56 @@ def test_no_freeze_layer_norm_feature_encoder_gradients(mods):
     worst = _check_grads(model, fe, 8e-2)
     print("no_freeze (layer-norm FE) worst FE grad", worst)
     _check_grads(model, {n: g.numpy() for n, g in grads.items() if not n.startswith("wav2vec2.feature_extractor.")}, 6e-2)
+
+
+@pytest.mark.parametrize("geometry", ["base_cg48", "xlsr_cg64"])
+def test_positional_conv_direct_kernel_equals_toeplitz_gemm(mods, geometry):
+    """The grouped positional convolution as a direct convolution with its input window resident in LDS (posconv.hip; group
+    widths 48 = wav2vec2-base and 64 = XLSR-large, 128 taps) against the Toeplitz-GEMM form of rounds 1-2 on the same engine
+    (per-handle option SSAK_W2V2_OPT_POSCONV_DIRECT): same logits and the same gradients -- the positional convolution's own
+    (weight_g / weight_v / bias) and everything upstream of it (feature projection), which only the input-gradient pass
+    reaches -- to bf16 summation-order noise, on ragged utterances whose frame counts (499, 312, 77 / 150) exercise the edge tile, and
+    both against the CPU oracle at the usual bf16 bars."""
+    import ssak_amd.hip as hip
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    if geometry == "base_cg48":
+        oc = R.W2V2Config.base(num_hidden_layers=1).deterministic()
+        lens = None
+        n_samples = [160000, 100000, 25000]
+    else:
+        oc = R.W2V2Config.xlsr_large(num_hidden_layers=1).deterministic()
+        lens = [48200, 24900]
+        n_samples = lens
+    p = R.init_params(oc, 41)
+    rng = np.random.default_rng(9)
+    if lens is None:  # group-norm model: no attention mask -> equal lengths per batch; run the three lengths as three batches
+        batches = [(R.zero_mean_unit_var_norm([rng.standard_normal(n).astype(np.float32)] * 2), None) for n in n_samples]
+    else:
+        batches = [(R.zero_mean_unit_var_norm([rng.standard_normal(n).astype(np.float32) for n in lens]), lens)]
+    labels = R.pad_labels([list(rng.integers(1, 32, 6)), list(rng.integers(1, 32, 4))])
+    names = ["wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original0", "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1",
+             "wav2vec2.encoder.pos_conv_embed.conv.bias", "wav2vec2.feature_projection.projection.weight", "wav2vec2.feature_projection.layer_norm.weight"]
+    for x, ln in batches:
+        outs = []
+        for direct in (1, 0):
+            model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).train()
+            model.set_option(hip.W2V2_OPT_POSCONV_DIRECT, direct)
+            model.load_state_dict(p)
+            out = model(torch.tensor(x), lengths=None if ln is None else torch.tensor(ln), labels=torch.tensor(labels))
+            model.grads[:model.num_trainable].fill_(float("nan"))
+            model.backward()
+            outs.append((out.logits.float().cpu().numpy(), out.frame_lens, {n: model.grad(n).cpu().numpy().copy() for n in names}))
+        (lg1, fl, g1), (lg0, _, g0) = outs
+        nf = [lg1.shape[1]] * lg1.shape[0] if fl is None else fl.cpu().numpy()
+        for b, f in enumerate(nf):
+            assert rel_l2(lg1[b, :f], lg0[b, :f]) < 5e-3, (geometry, x.shape, b)
+        for n in names:
+            assert np.isfinite(g1[n]).all()
+            assert rel_l2(g1[n], g0[n]) < 1e-2, (geometry, x.shape, n, rel_l2(g1[n], g0[n]))
+    # the last batch against the CPU oracle
+    x, ln = batches[-1]
+    loss, logits, grads = R.loss_and_grads(p, oc, torch.tensor(x), ln, torch.tensor(labels))
+    for b, f in enumerate(nf):
+        assert rel_l2(lg1[b, :f], logits[b, :f].numpy()) < 2e-2
+    for n in names:
+        assert rel_l2(g1[n], grads[n].numpy()) < 6e-2, n
