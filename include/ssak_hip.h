@@ -178,7 +178,26 @@ typedef struct {
                  kernel for a while -- the RCCL all-reduce of a data-parallel step -- take fewer tiles instead of finishing
                  last.  Alone on the chip the static order is a few percent faster (no ticket round trip at the start of a
                  launch); results are bit-identical either way.  (A grouped launch reads it from descs[0].) */
+  const void* b_fragments; /* optional (NULL = none): the FRAGMENT-ORDERED copy of this product's B operand made by
+                 ssak_gemm_fragment_b for the same N, K -- for a B that is a weight, static between optimizer steps.  When the
+                 library picks the persistent kernel's "B-direct" form for the shape (ssak_gemm_uses_fragments), every wave
+                 loads its B fragments from this copy straight into registers and B never enters LDS (the LDS form is bound by
+                 LDS read bandwidth; N = 768 products of the train step run 5-25 % faster); otherwise it is ignored and B is
+                 read.  Both must describe the same matrix: results are bit-identical either way.  Not with B batch strides. */
 } ssak_gemm_desc;
+/* Fragment-ordered copy of a B operand ([N, K] K-contiguous, or [K, N] with b_kmajor; ldb as in the descriptor):
+ * out[(cb * nkt + kt)][j][kk][lane][8] = B(n = 64 cb + 16 j + (lane & 15), k = 64 kt + 32 kk + 8 (lane >> 4) + e), zeros
+ * beyond N / K, cb < 4 * ceil(N / 256), nkt = ceil(K / 64): the 8 KB one wave column needs for one 64-deep K tile are
+ * contiguous and each `v_mfma_f32_16x16x32_bf16` operand is one 1-KiB wave-level load of whole cache lines. */
+size_t ssak_gemm_fragment_b_bytes(int N, int K);
+int ssak_gemm_fragment_b(const void* B, long ldb, int N, int K, int b_kmajor, void* out, void* stream);
+/* The same for `n` matrices in ONE launch (host arrays of length n): the engine refreshes the copies of every kept layer's
+ * weights once per train step. */
+int ssak_gemm_fragment_b_batched(int n, const void* const* B, const long* ldb, const int* N, const int* K, const int* b_kmajor,
+                                 void* const* out, void* stream);
+/* 1 when ssak_gemm_bf16 would take the B-direct form for this descriptor if b_fragments were given (callers that keep the
+ * copies fresh only for products that use them), else 0. */
+int ssak_gemm_uses_fragments(const ssak_gemm_desc* desc);
 int ssak_gemm_bf16(const ssak_gemm_desc* desc /*host*/, const void* A, const void* B, void* C, const float* bias,
                    const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes, void* stream);
 /* The same contraction with float operands, float results and float aux buffers on the fp32 matrix pipe
@@ -340,10 +359,20 @@ int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begi
  * SSAK_W2V2_OPT_ATTENTION_BWD  SSAK_ATTN_BWD_*: the form of the fused attention backward;
  * SSAK_W2V2_OPT_POSCONV_DIRECT  1 (default) / 0: the grouped positional convolution as a direct convolution with its input
  *                              window resident in LDS (group widths 48 and 64) or as the Toeplitz GEMM of rounds 1-2 (kept for
- *                              other geometries and as the comparison path of the tests). */
+ *                              other geometries and as the comparison path of the tests);
+ * SSAK_W2V2_OPT_FRAGMENT_WEIGHTS  0 (default) / 1: every TRAINING forward makes fragment-ordered copies of the kept encoder
+ *                              layers' projection weights (one batched launch after the optimizer's event, ssak_gemm_fragment_b)
+ *                              and the forward / input-gradient products the library would run in its B-direct form take
+ *                              them through ssak_gemm_desc.b_fragments; evaluation forwards never do (the copies would go
+ *                              stale when the caller rewrites the shadow).  Bit-identical results; engine-owned memory (~2 x
+ *                              the bf16 size of the layers' matrices).  OFF by default: with the operands warm the B-direct
+ *                              form is 5-25 % faster on the N = 768 products, but in the train step a layer's weights are read
+ *                              once per step -- from HBM -- and the gain is gone (3 591 -> 3 664 us per step for the six
+ *                              products, + 160 us for the copies: profiles/r03_ab_fragments.log). */
 #define SSAK_W2V2_OPT_DYNAMIC_TILES 1
 #define SSAK_W2V2_OPT_ATTENTION_BWD 2
 #define SSAK_W2V2_OPT_POSCONV_DIRECT 3
+#define SSAK_W2V2_OPT_FRAGMENT_WEIGHTS 4
 int ssak_w2v2_set_option(ssak_w2v2* h, int option, int value);
 /* The gradient ranges ssak_w2v2_backward announces, in announcement order, from the configuration alone (host arithmetic, no
  * device): head matrix, one range per encoder layer from the last to the first (a layer's q|k|v|out|ffn matrices are

@@ -18,7 +18,7 @@ void ssak_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int ssak_version(void) { return 300; }  // round 3: per-call / per-handle / per-stream switches (ABI change)
+extern "C" int ssak_version(void) { return 301; }  // round 3: per-call / per-handle / per-stream switches; ssak_gemm_desc.b_fragments
 extern "C" const char* ssak_last_error(void) { return g_err; }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around launches, on the launch's own stream ----

@@ -774,7 +774,39 @@ GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
   return best_def;
 }
 
+// The B-direct form of the persistent kernel (gemm_p8.hip) for this product and plan?  Measured on the train step's shapes
+// (tools/probes/p8_loop.hip, profiles/r03_gemm_bdirect_probe*.log): 192-row tiles (the N = 768 products) gain 3-25 %, 256-row
+// tiles gain for deep K and narrow N (K = 3072, N = 768: +15 %) and LOSE for wide outputs (N = 3072: -5..-9 %, the weight no
+// longer fits the XCD's L2 next to the activations and every wave row fetches it again) and for the conv stack.
+bool fragments_pay(const ssak_gemm_desc* d, const GemmPlan& plan) {
+  if (!plan.p8 || plan.split != 1 || d->a_kmajor || d->out_f32 || d->accumulate || d->colsum || d->drop_p > 0.f) return false;
+  if (d->sb1 || d->sb2 || d->lda < d->K) return false;  // one weight for every batch; no Toeplitz A (conv stack)
+  if (d->epilogue != SSAK_EPI_NONE) return false;
+  if ((size_t)ssak_cdiv(d->N, 256) * 4 * ssak_cdiv(d->K, BK) * 8192 >= (1ull << 31)) return false;
+  if (plan.bm == 192) return d->N <= 2304;
+  if (plan.bm == 256) return d->K >= 2048 && d->N <= 1024;
+  return false;
+}
+
 }  // namespace
+
+extern "C" int ssak_gemm_uses_fragments(const ssak_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  const bool partial_a = d->a_kmajor ? (d->M & 7) : (d->K & 7);
+  const bool partial_b = d->b_kmajor ? (d->N & 7) : (d->K & 7);
+  const bool dma = d->pads_are_zero || !(partial_a || partial_b);
+  return fragments_pay(d, plan_gemm(d, dma, 0)) ? 1 : 0;
+}
+extern "C" size_t ssak_gemm_fragment_b_bytes(int N, int K) { return N > 0 && K > 0 ? k_gemm_fragment_b_bytes(N, K) : 0; }
+extern "C" int ssak_gemm_fragment_b_batched(int n, const void* const* B, const long* ldb, const int* N, const int* K, const int* b_kmajor,
+                                            void* const* out, void* stream) {
+  SSAK_REQUIRE(n >= 0 && (n == 0 || (B && ldb && N && K && b_kmajor && out)), "gemm_fragment_b: null pointer");
+  if (n == 0) return SSAK_OK;
+  return k_gemm_fragment_b_batched(n, B, ldb, N, K, b_kmajor, out, (hipStream_t)stream);
+}
+extern "C" int ssak_gemm_fragment_b(const void* B, long ldb, int N, int K, int b_kmajor, void* out, void* stream) {
+  return ssak_gemm_fragment_b_batched(1, &B, &ldb, &N, &K, &b_kmajor, &out, stream);
+}
 
 extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                               const void* aux_in, void* aux_out, void* workspace, size_t workspace_bytes,
@@ -898,7 +930,14 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
         p.kperm_n2 = n2;
       }
     }
-    rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
+    if (d->b_fragments && fragments_pay(d, plan)) {
+      SSAK_REQUIRE(((uintptr_t)d->b_fragments & 15) == 0, "gemm: b_fragments must be 16-byte aligned");
+      p.B = (const bf16*)d->b_fragments;
+      p.ext_b = (uint32_t)k_gemm_fragment_b_bytes(d->N, d->K);
+      rc = ssak_gemm_p8bd_launch(&p, p8_bm, st);
+    } else {
+      rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
+    }
   } else if (d->N > 64 && dma && d->M >= 256 && !d->a_kmajor && !d->b_kmajor && big_tiles >= 2048 && !env_no_big && !g_no_big_tile) {
     p.tiles_m = ssak_cdiv(d->M, 256);
     p.tiles_n = ssak_cdiv(d->N, 128);

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_common.h"
@@ -98,6 +99,9 @@ struct P8Stager {
 #if defined(P8_ABL) && (P8_ABL & 1)
     if (kt >= 2) return;  // ablation: no LDS-DMA inside the main loop
 #endif
+#if defined(P8_ABL) && (P8_ABL & 32)
+    if (NSEG == 4 && kt >= 2) return;  // ablation: no LDS-DMA of the B operand inside the main loop
+#endif
     // k-rows / k-chunks of this tile that exist (uniform): all 64, a K tail, or none (dummy past the last tile)
     const int klim = kt < kt_end ? min(K - kt * BK, BK) : 0;
     // advance to the next K tile of the visiting order: step kt -> kt + 1 moves by + p (even step of a pair), 1 - p (odd) or 1
@@ -115,7 +119,7 @@ struct P8Stager {
 };
 
 // per-lane fragment offsets inside a piece; w0 = first piece row of this wave's panel, NF 16-row groups
-template <bool KM, int NF>
+template <bool KM, int NF, bool IS_B = false>
 struct P8Frag {
   int off[KM ? NF : 1];
   __device__ __forceinline__ void init(int w0, int lane) {
@@ -135,6 +139,9 @@ struct P8Frag {
   __device__ __forceinline__ bf16x8 read(const char* piece, int i, int kk) const {
 #if defined(P8_ABL) && (P8_ABL & 2)
     return __builtin_bit_cast(bf16x8, (f32x4){(float)i, (float)kk, 1.f, 2.f});  // ablation: no fragment reads
+#endif
+#if defined(P8_ABL) && (P8_ABL & 16)
+    if (IS_B) return __builtin_bit_cast(bf16x8, (f32x4){(float)i, (float)kk, 1.f, 2.f});  // ablation: no B fragment reads
 #endif
     if (!KM) {
       return *reinterpret_cast<const bf16x8*>(piece + ((off[0] ^ (kk << 6)) + i * 2048));
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
   P8Stager<A_KM, SEGA, 2 * SEGA, A_KM ? 16 : 4 * MH, 2> sa;
   P8Stager<B_KM, 32, 64, 16, 4> sb;
   P8Frag<A_KM, MH> fra;
-  P8Frag<B_KM, 2> frb;
+  P8Frag<B_KM, 2, true> frb;
   fra.init(wr * SEGA, lane);
   frb.init(wc * 32, lane);
   // piece slots of buffer b: AT = 0, AB = 1, BL = 2, BR = 3
@@ -503,6 +510,315 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// "B-direct" form of the same kernel for products whose B operand is a WEIGHT (static between optimizer steps): B never
+// enters LDS.  tools/probes/p8_loop.hip's ablations say why: the loop above is bound by LDS read bandwidth -- per 64-deep K
+// tile a workgroup reads 192 KB of fragments (A: 16, B: 8 ds_read_b128 per wave) and takes 64 KB of LDS-DMA writes, 256 KB at
+// 128 B/clk = the 2 048 cycles its 512 MFMAs take, and the first load phase of a K tile (16 reads per wave) alone exceeds the
+// partner wave's 512 MFMA cycles; with the B fragment reads removed the same loop runs 13-26 % faster (8192^3: 1 194 -> 1 505
+// TFLOP/s).  Here every wave loads its B fragments straight from global memory into registers, one K tile ahead, from a
+// FRAGMENT-ORDERED copy of the weight (k_gemm_fragment_b: the 8 KB a wave column needs for one K tile are contiguous, one
+// 1-KiB wave-instruction per fragment -- whole cache lines, the layout that made the direct positional convolution fast).  LDS
+// then carries only A: four 32 KB stages (AT / AB pieces as above), 128 KB of fragment reads + 32 KB of DMA per K tile.
+//   LA(t): read AT(t) | load B(t+1) groups 0, 1 -> the other register set | DMA AB(t+3) | vmcnt(8) | barrier | 8 MH MFMAs | barrier
+//   LB(t): read AB(t) | load B(t+1) groups 2, 3                           | DMA AT(t+3) |          | barrier | 8 MH MFMAs | barrier
+// (six vector-memory instructions per load phase: with all eight B loads in LA the four waves of a load phase queued 40 KiB
+// behind the CU's one address unit -- longer than the partner's MFMA phase.)  One counted wait per K tile: everything older
+// than the 8 youngest vector-memory instructions has landed = B(t) and every DMA issued before LB(t-1).  Hazards as above
+// (waited in load phase w -> read in phase >= w + 1; a slot last read in load phase r is re-staged in load phase r + 1).
+constexpr int P8BD_STAGE = 2 * P8_PIECE;  // AT + AB of one K tile
+
+// B[n][k] (k-contiguous, ldb) or B[k][n] (b_km) -> frag[(cb * nkt + kt)][j][kk][lane][8]:  n = 64 cb + 16 j + (lane & 15),
+// k = 64 kt + 32 kk + 8 (lane >> 4) + e; zeros beyond N / K; cb < nb64 (a multiple of 4: whole 256-column tiles).
+// One workgroup per 8 KB block of one matrix of the batch: the 64 x 64 source tile goes through LDS (whole 128-byte lines
+// in, 4 KB contiguous runs out; the K-major orientation is transposed on the way).
+struct FragJob {
+  const bf16* B;
+  bf16* out;
+  long ldb;
+  int N, K, b_km, nkt, blk0;  // blk0: first workgroup of this matrix
+};
+constexpr int FRAG_JOBS_CAP = 80;
+struct FragJobs {
+  int n, total;
+  FragJob j[FRAG_JOBS_CAP];
+};
+static_assert(sizeof(FragJobs) <= 4096, "kernel arguments are limited to 4 KiB");
+__global__ __launch_bounds__(256) void gemm_fragment_b_kernel(const FragJobs jobs) {
+  constexpr int PITCH = 72;  // elements: 144-byte rows keep 16-byte alignment and spread the banks
+  __shared__ __attribute__((aligned(16))) bf16 tile[64 * PITCH];
+  int ji = 0;
+  for (int k = 1; k < jobs.n; ++k) ji = (int)blockIdx.x >= jobs.j[k].blk0 ? k : ji;
+  const FragJob& J = jobs.j[ji];
+  const int blk = (int)blockIdx.x - J.blk0;
+  const int kt = blk % J.nkt, cb = blk / J.nkt;
+  const int n0 = 64 * cb, k0 = 64 * kt;
+  const bool aligned = ((uintptr_t)J.B & 15) == 0 && (J.ldb & 7) == 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (int)threadIdx.x / 8 + 32 * i, c8 = ((int)threadIdx.x & 7) * 8;  // tile row, first element of the 16-byte chunk
+    // kc: row = n, chunk along k;  km: row = k, chunk along n
+    const int gr = (J.b_km ? k0 : n0) + r, gc = (J.b_km ? n0 : k0) + c8;
+    const int rows = J.b_km ? J.K : J.N, cols = J.b_km ? J.N : J.K;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+    if (gr < rows) {
+      const bf16* src = J.B + (long)gr * J.ldb + gc;
+      if (gc + 8 <= cols && aligned) {
+        v = *reinterpret_cast<const bf16x8*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (gc + e < cols) v[e] = src[e];
+      }
+    }
+    *reinterpret_cast<bf16x8*>(tile + r * PITCH + c8) = v;
+  }
+  __syncthreads();
+  bf16* const dst = J.out + (long)blk * 4096;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (int)threadIdx.x + 256 * i;  // 16-byte chunk of the block
+    const int lane = c & 63, kk = (c >> 6) & 1, jj = c >> 7;
+    const int nl = 16 * jj + (lane & 15), kl = 32 * kk + 8 * (lane >> 4);
+    bf16x8 v;
+    if (!J.b_km) {
+      v = *reinterpret_cast<const bf16x8*>(tile + nl * PITCH + kl);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[(kl + e) * PITCH + nl];
+    }
+    *reinterpret_cast<bf16x8*>(dst + c * 8) = v;
+  }
+}
+
+template <int MH, int EPI>
+__global__ __launch_bounds__(P8_THREADS) void gemm_p8bd_kernel(const GemmParams p) {
+  constexpr int BM = 64 * MH, SEGA = 16 * MH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int per_z = p.tiles_m * p.tiles_n;
+  const int ntiles = per_z * p.nz;
+  const int nkt = (p.K + BK - 1) / BK;
+  auto decode = [&](int t) {
+    P8Tile c;
+    const int id = xcd_remap(t, ntiles);
+    c.g = 0;
+    const int zs = id / per_z, rem = id % per_z;
+    const int tm = rem / p.tiles_n, tn = rem % p.tiles_n;
+    c.split = 0;
+    c.z = zs;
+    c.z1 = c.z / p.nb2;
+    c.z2 = c.z % p.nb2;
+    c.bm0 = tm * BM;
+    c.bn0 = tn * 256;
+    c.kt0 = 0;
+    c.kt1 = nkt;
+    return c;
+  };
+  const int kpp = p.kperm_p, kpn = p.kperm_n2;
+  P8Stager<false, SEGA, 2 * SEGA, 4 * MH, 2> sa;
+  P8Frag<false, MH> fra;
+  fra.init(wr * SEGA, lane);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.ext_b, 0x00020000);
+  const int b_voff = lane * 16;
+  uint32_t b_col = 0;  // byte offset of this wave column's first K tile in the fragment-ordered B
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+  // fragments of column groups 2 * HALF, 2 * HALF + 1 (HALF = 2: all four) of the K tile visited at `step`
+  auto load_b = [&](bf16x8(&dst)[4][2], int step, auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
+#if defined(P8BD_ABL) && (P8BD_ABL & 1)
+    if (step >= 2) return;  // ablation: no B loads inside the main loop
+#endif
+    int kta = step < 2 * kpn ? (step >> 1) + ((step & 1) ? kpp : 0) : step - kpn;  // K tile of this step (P8Stager::issue's order)
+    kta = min(kta, nkt - 1);                                                         // past the end: a valid tile nobody uses
+    const uint32_t so = b_col + (uint32_t)kta * 8192u;
+#pragma unroll
+    for (int j = (HALF == 1 ? 2 : 0); j < (HALF == 0 ? 2 : 4); ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int f = j * 2 + kk;
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_voff + (f & 3) * 1024, so + (f >> 2) * 4096, 0);
+        dst[j][kk] = __builtin_bit_cast(bf16x8, v);
+      }
+  };
+  using Half0 = std::integral_constant<int, 0>;
+  using Half1 = std::integral_constant<int, 1>;
+  using Both = std::integral_constant<int, 2>;
+  const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.bias, 0, p.bias ? (int)((((long)p.nb2 - 1) * p.bias_s2 + p.N) * 4) : 0, 0x00020000);
+  char* const bias_lds = smem + P8_PIPE + wave * 1024;
+  // (B loaded TWO K tiles ahead into a ring of three register sets -- to cover the HBM latency of weights that are read once per
+  // train step -- was built for the 192-row form and is slower, warm or cold: 29 priming instructions and 96 fragment registers;
+  // profiles/r03_gemm_bdirect_cold2.log.)
+  bf16x8 fb0[4][2], fb1[4][2];
+  // bias, AT(0), AB(0), B(0) -> fb0, AT(1), AB(1), AT(2), AB(2): 21 vector-memory instructions per wave
+  auto prime = [&](const P8Tile& c) {
+    {
+      const long col = c.z2 * p.bias_s2 + c.bn0 + wc * 64 + 4 * lane;
+      const uint32_t o = lane < 16 ? (uint32_t)(col * 4) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lds_void*)bias_lds, 16, o, 0, 0, 0);
+    }
+    sa.init(p.A + c.z1 * p.sa1 + c.z2 * p.sa2, p.lda, c.bm0, p.M, 0, p.ext_a);
+    b_col = (uint32_t)(((long)(c.bn0 >> 6) + wc) * nkt) * 8192u;
+    sa.template issue<0>(smem + 0 * P8_PIECE, 0, nkt, p.K, kpp, kpn);
+    sa.template issue<1>(smem + 1 * P8_PIECE, 0, nkt, p.K, kpp, kpn);
+    load_b(fb0, 0, Both{});
+    sa.template issue<0>(smem + P8BD_STAGE + 0 * P8_PIECE, 1, nkt, p.K, kpp, kpn);
+    sa.template issue<1>(smem + P8BD_STAGE + 1 * P8_PIECE, 1, nkt, p.K, kpp, kpn);
+    sa.template issue<0>(smem + 2 * P8BD_STAGE + 0 * P8_PIECE, 2, nkt, p.K, kpp, kpn);
+    sa.template issue<1>(smem + 2 * P8BD_STAGE + 1 * P8_PIECE, 2, nkt, p.K, kpp, kpn);
+  };
+  const int epi_vm = (((p.epilogue == SSAK_EPI_GELU || p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) && p.aux_out)) ? 8 * MH : 4 * MH;
+  const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD && p.epilogue != SSAK_EPI_MUL_AUX && !p.colsum;
+
+  int* const tile_ctr = p.tile_ctr ? p.tile_ctr + (blockIdx.x & 7) : nullptr;
+  int* const ticket_lds = reinterpret_cast<int*>(smem + P8_PIPE + 8 * 1024);
+  int ticket = 0;
+  int t_first = blockIdx.x;
+  if (tile_ctr) {
+    if (threadIdx.x == 0) *ticket_lds = atomicAdd(tile_ctr, 1);
+    __syncthreads();
+    t_first = 8 * __builtin_amdgcn_readfirstlane(*ticket_lds) + (int)(blockIdx.x & 7);
+    __syncthreads();
+  }
+  bool primed = false;
+  P8Tile cur_t = decode(min(t_first, ntiles - 1));
+  for (int t = t_first; t < ntiles;) {
+    const P8Tile c = cur_t;
+    const bool was_primed = primed;
+    if (!primed) {
+      prime(c);
+      wait_vmcnt<18>();  // AT(0) landed (this wave's share): AB(0), B(0) and the six pieces of tiles 1, 2 may still fly
+    } else if (epi_vm == 8 * MH) {
+      wait_vmcnt<8 * MH>();  // everything older than the previous epilogue's stores
+    } else {
+      wait_vmcnt<4 * MH>();
+    }
+    P8_BARRIER();
+    if (wr == 1) P8_BARRIER();  // wave row 1 runs one barrier behind wave row 0
+    if (tile_ctr && threadIdx.x == 0) ticket = atomicAdd(tile_ctr, 1);
+
+    f32x4 acc[2 * MH][4];
+#pragma unroll
+    for (int i = 0; i < 2 * MH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[MH][2];
+    // one K tile: `cur` holds B(step), `nxt` receives B(step + 1)
+    auto ktile = [&](bf16x8(&cur)[4][2], bf16x8(&nxt)[4][2], int step) {
+      char* const st_cur = smem + (step & 3) * P8BD_STAGE;
+      char* const st_new = smem + ((step + 3) & 3) * P8BD_STAGE;
+      // ---- LA
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(st_cur, i, kk);
+      P8_FENCE();
+      load_b(nxt, step + 1, Half0{});
+      sa.template issue<1>(st_new + P8_PIECE, step + 3, nkt, p.K, kpp, kpn);  // AB(t+3)
+      // B(t) and everything older: B(t)'s second half was loaded in LB(t-1), 2 + 6 instructions ago (K tile 0: in the priming
+      // sequence, followed by AB(2)).  After early priming the previous tile's epilogue stores sit in between and stay in flight.
+      if (step == 0 && was_primed) {
+        if (epi_vm == 8 * MH) wait_vmcnt<8 + 8 * MH>();
+        else wait_vmcnt<8 + 4 * MH>();
+      } else {
+#if defined(P8BD_ABL) && (P8BD_ABL & 1)
+        wait_vmcnt<4>();
+#else
+        wait_vmcnt<8>();
+#endif
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // this wave's fragment reads are done
+      P8_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MH; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_BARRIER();
+      // ---- LB
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fa[i][kk] = fra.read(st_cur + P8_PIECE, i, kk);
+      P8_FENCE();
+      // (the loads first: LA(t+1)'s wait reaches back to them and must not force a DMA issued half a K tile before it)
+      load_b(nxt, step + 1, Half1{});
+      sa.template issue<0>(st_new, step + 3, nkt, p.K, kpp, kpn);  // AT(t+3)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      P8_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MH; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j][kk], fa[i][kk], acc[MH + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_BARRIER();
+    };
+    int step = 0;
+    for (; step + 1 < nkt; step += 2) {
+      ktile(fb0, fb1, step);
+      ktile(fb1, fb0, step + 1);
+    }
+    if (step < nkt) ktile(fb0, fb1, step);
+    if (wr == 0) P8_BARRIER();
+    wait_vmcnt<0>();  // drain the trailing dummies before LDS is released
+    // the last K tile's B loads (a clamped tile nobody multiplies) must stay in the instruction stream: the counted waits
+    // above count them
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) asm volatile("" ::"v"(fb0[j][kk]), "v"(fb1[j][kk]));
+    if (tile_ctr && threadIdx.x == 0) *ticket_lds = ticket;
+
+    __syncthreads();
+    const int t_next = tile_ctr ? 8 * __builtin_amdgcn_readfirstlane(*ticket_lds) + (int)(blockIdx.x & 7) : t + (int)gridDim.x;
+    BiasRegs<4> bias_regs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + (16 * j + 4 * (lane >> 4)) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias_regs.v[j][r] = b4[r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    P8_FENCE();
+    const bool interior = c.bn0 + 256 <= p.N && epilogue_direct_ok(p, c.bm0, c.bn0, 0, 0, BM, c.z1 * p.sc1 + c.z2 * p.sc2);
+    primed = false;
+    if (t_next < ntiles) {
+      cur_t = decode(t_next);
+      if (interior && epi_early && c.bm0 + BM <= p.M) {
+        prime(cur_t);
+        primed = true;
+      }
+    }
+    if (interior) {
+      gemm_epilogue_direct<2 * MH, EPI>(p, acc, bias_regs, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, 0);
+    } else {
+      char* const lds_wave = smem + wave * 16384;
+      gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[0]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA, wc * 64, lane, c.z, c.z1, c.z2, 0);
+      gemm_epilogue<MH, 4>(p, reinterpret_cast<f32x4(&)[MH][4]>(acc[MH]), bias_regs, lds_wave, c.bm0, c.bn0, wr * 2 * SEGA + SEGA, wc * 64, lane, c.z, c.z1, c.z2, 0);
+      __syncthreads();
+    }
+    t = t_next;
+  }
+  if (p.tile_ctr && threadIdx.x == 0) {
+    if (atomicAdd(p.tile_ctr + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicExch(p.tile_ctr + i, 0);
+    }
+  }
+}
+
 // Ticket counters (eight per-XCD counters + the count of finished workgroups): one 64-byte slot per (device, stream).  Launches on a stream run in order and every launch leaves its slot
 // at zero, so a slot is reused without a reset; different streams never share one.
 int p8_ticket_slot(hipStream_t st, int** out) {
@@ -565,14 +881,53 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
   q.tile_ctr = nullptr;
   if (ntiles > n_cu && n_cu % 8 == 0 && p.dynamic)
     if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
+#ifdef P8BD_SLOT_PER_SHAPE
+  char nms[112];
+  snprintf(nms, sizeof(nms), "gemm_p8_kernel<%d, %s, %s, false, %d> N=%d K=%d", MH, A_KM ? "true" : "false", B_KM ? "true" : "false", EPI, p.N, p.K);
+  const int slot = ssak_prof_register(nms, SSAK_BOUND_MFMA);
+#else
   static int slot = -1;
   if (slot < 0) {
     char nm[112];
     snprintf(nm, sizeof(nm), "gemm_p8_kernel<%d, %s, %s, false, %d>", MH, A_KM ? "true" : "false", B_KM ? "true" : "false", EPI);
     slot = ssak_prof_register(nm, SSAK_BOUND_MFMA);
   }
+#endif
   ProfScope prof_scope(slot, 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q, none);  // one persistent workgroup per CU
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
+template <int MH, int EPI>
+int launch_p8bd(const GemmParams& p, hipStream_t st) {
+  auto kern = gemm_p8bd_kernel<MH, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
+    attr_done = true;
+  }
+  const long ntiles = (long)p.tiles_m * p.tiles_n * p.nz;
+  int n_cu = 0;
+  if (int rc = p8_num_cu(&n_cu)) return rc;
+  GemmParams q = p;
+  q.tile_ctr = nullptr;
+  if (ntiles > n_cu && n_cu % 8 == 0 && p.dynamic)
+    if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
+#ifdef P8BD_SLOT_PER_SHAPE  // development: one timing slot per (N, K)
+  char nms[112];
+  snprintf(nms, sizeof(nms), "gemm_p8bd_kernel<%d, %d> N=%d K=%d", MH, EPI, p.N, p.K);
+  const int slot = ssak_prof_register(nms, SSAK_BOUND_MFMA);
+#else
+  static int slot = -1;
+  if (slot < 0) {
+    char nm[112];
+    snprintf(nm, sizeof(nm), "gemm_p8bd_kernel<%d, %d>", MH, EPI);
+    slot = ssak_prof_register(nm, SSAK_BOUND_MFMA);
+  }
+#endif
+  ProfScope prof_scope(slot, 2.0 * p.M * p.N * (double)p.K * p.nz, st);
+  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q);
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -639,6 +994,50 @@ int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStrea
   if (bm == 256) return dispatch_p8<4>(p, a_km, b_km, st);
   if (bm == 192) return dispatch_p8<3>(p, a_km, b_km, st);
   return dispatch_p8<2>(p, a_km, b_km, st);
+}
+
+// B-direct form (B = the fragment-ordered copy made by k_gemm_fragment_b; A K-contiguous, bf16 out, no split-K).  The caller
+// (gemm.hip) has checked the shape; tiles_m / tiles_n are counted for bm x 256 tiles.
+template <int MH>
+int dispatch_p8bd(const GemmParams& p, hipStream_t st) {
+  const bool plain = p.epilogue == SSAK_EPI_NONE && !p.drop_thresh && !p.colsum && !p.out_f32 && !p.accumulate && p.split_k <= 1;
+  if (plain) return launch_p8bd<MH, P8_EPI_PLAIN_BF16>(p, st);
+  ssak_set_error("gemm_p8bd: only the plain bf16 epilogue (bias) is built for the fragment-ordered B form (epilogue %d)", p.epilogue);
+  return SSAK_ERR_INVALID;
+}
+int ssak_gemm_p8bd_launch(const void* params, int bm, hipStream_t st) {
+  const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
+  if (bm == 256) return dispatch_p8bd<4>(p, st);
+  if (bm == 192) return dispatch_p8bd<3>(p, st);
+  return dispatch_p8bd<2>(p, st);
+}
+size_t k_gemm_fragment_b_bytes(int N, int K) { return (size_t)ssak_cdiv(N, 256) * 4 * ssak_cdiv(K, BK) * 8192; }
+int k_gemm_fragment_b_batched(int n, const void* const* B, const long* ldb, const int* N, const int* K, const int* b_km, void* const* out,
+                              hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += FRAG_JOBS_CAP) {
+    FragJobs jobs;
+    jobs.n = std::min(n - i0, FRAG_JOBS_CAP);
+    int blk = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+      FragJob& J = jobs.j[i];
+      SSAK_REQUIRE(B[i0 + i] && out[i0 + i] && N[i0 + i] > 0 && K[i0 + i] > 0, "gemm_fragment_b: bad matrix %d", i0 + i);
+      SSAK_REQUIRE(((uintptr_t)out[i0 + i] & 15) == 0, "gemm_fragment_b: the copy must be 16-byte aligned");
+      J.B = (const bf16*)B[i0 + i];
+      J.out = (bf16*)out[i0 + i];
+      J.ldb = ldb[i0 + i];
+      J.N = N[i0 + i];
+      J.K = K[i0 + i];
+      J.b_km = b_km[i0 + i];
+      J.nkt = ssak_cdiv(J.K, BK);
+      J.blk0 = blk;
+      blk += ssak_cdiv(J.N, 256) * 4 * J.nkt;
+    }
+    for (int i = jobs.n; i < FRAG_JOBS_CAP; ++i) jobs.j[i] = jobs.j[0];
+    jobs.total = blk;
+    gemm_fragment_b_kernel<<<blk, 256, 0, st>>>(jobs);
+    SSAK_LAUNCH_CHECK();
+  }
+  return SSAK_OK;
 }
 
 // Grouped launch of n <= 48 problems sharing K, layouts, alpha and output type (256-row tiles).  `params` carries the shared

@@ -172,6 +172,11 @@ int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, 
 // gemm_p8.hip: (256|192|128)x256-tile phase-interleaved GEMM; `params` is gemm_common.h's GemmParams with
 // tiles_m / tiles_n counted for bm x 256 tiles
 int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st);
+// B-direct form: params->B = the fragment-ordered copy (k_gemm_fragment_b_batched), params->ext_b its bytes
+int ssak_gemm_p8bd_launch(const void* params, int bm, hipStream_t st);
+size_t k_gemm_fragment_b_bytes(int N, int K);
+int k_gemm_fragment_b_batched(int n, const void* const* B, const long* ldb, const int* N, const int* K, const int* b_km, void* const* out,
+                              hipStream_t st);
 int ssak_gemm_p8_launch_grouped(const void* params, int n, const void* const* A, const void* const* B, void* const* C, const int* M,
                                 const int* N, const long* lda, const long* ldb, const long* ldc, const uint32_t* ext_a,
                                 const uint32_t* ext_b, int a_km, int b_km, hipStream_t st);

@@ -125,6 +125,20 @@ struct ssak_w2v2 {
   int dynamic_tiles = 0;
   int attn_bwd_mode = SSAK_ATTN_BWD_DEFAULT;
   int posconv_direct = 1;
+  int fragment_weights = 0;
+  // Fragment-ordered copies of the encoder layers' projection weights for the B-direct GEMM form (gemm_p8.hip): engine-owned,
+  // allocated by the first training forward and refreshed by every training forward (the optimizer rewrites the bf16 shadow
+  // between steps).  Per layer six copies: qkv | out | ffn-down in the forward orientation, qkv | out | ffn-up in the
+  // input-gradient orientation (the weight read K-major).
+  bf16* wfrag = nullptr;
+  size_t wfrag_layer = 0;      // elements per layer
+  size_t wfrag_off[6] = {0};   // element offsets inside a layer's block
+  bool wfrag_use[6] = {false}; // which of the six products take the B-direct form at wfrag_M rows
+  int wfrag_M = 0;
+  bool wfrag_valid = false;    // the copies match the shadow: set by a training forward, cleared by bind and evaluation forwards
+  const bf16* frag(int layer, int which) const {
+    return (wfrag_valid && wfrag_use[which] && keep[layer]) ? wfrag + (size_t)layer * wfrag_layer + wfrag_off[which] : nullptr;
+  }
 };
 
 namespace {
@@ -517,6 +531,11 @@ struct Gemm {
     aux_out = out;
     return *this;
   }
+  // fragment-ordered copy of B (ssak_gemm_desc.b_fragments; null = none)
+  Gemm& bfrag(const void* frag) {
+    if (!f32) d.b_fragments = frag;
+    return *this;
+  }
   Gemm& drop(float p, uint32_t stream, uint64_t seed) {
     d.drop_p = p;
     d.drop_stream = stream;
@@ -606,6 +625,63 @@ __global__ void frame_lens_kernel(const int32_t* __restrict__ lens, int B, int T
   flens[b] = L;
 }
 
+// The six per-layer products that can take fragment-ordered weights: N, K, orientation and the weight they read
+struct FragProduct {
+  int N, K, b_km;
+  long ldb;
+  long LayerP::*w;
+};
+int refresh_weight_fragments(ssak_w2v2* e, int M, const uint8_t* layer_keep, hipStream_t st) {
+  const ssak_w2v2_config& c = e->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size, L = c.num_layers;
+  const FragProduct pr[6] = {{3 * H, H, 0, H, &LayerP::wqkv}, {H, H, 0, H, &LayerP::wo}, {H, I, 0, I, &LayerP::w2},
+                             {H, 3 * H, 1, H, &LayerP::wqkv}, {H, H, 1, H, &LayerP::wo}, {H, I, 1, H, &LayerP::w1}};
+  if (!e->wfrag) {
+    size_t off = 0;
+    for (int i = 0; i < 6; ++i) {
+      e->wfrag_off[i] = off;
+      off += ssak_gemm_fragment_b_bytes(pr[i].N, pr[i].K) / sizeof(bf16);
+    }
+    e->wfrag_layer = off;
+    SSAK_HIP(hipMalloc((void**)&e->wfrag, (size_t)L * off * sizeof(bf16)));
+  }
+  if (e->wfrag_M != M) {
+    for (int i = 0; i < 6; ++i) {
+      ssak_gemm_desc d;
+      memset(&d, 0, sizeof(d));
+      d.M = M, d.N = pr[i].N, d.K = pr[i].K;
+      d.b_kmajor = pr[i].b_km;
+      d.lda = pr[i].K, d.ldb = pr[i].ldb, d.ldc = pr[i].N;
+      d.nb1 = d.nb2 = 1;
+      d.alpha = 1.f;
+      d.split_k = 1;
+      d.pads_are_zero = 1;
+      e->wfrag_use[i] = ssak_gemm_uses_fragments(&d) != 0;
+    }
+    e->wfrag_M = M;
+  }
+  std::vector<const void*> src;
+  std::vector<void*> dst;
+  std::vector<long> ldb;
+  std::vector<int> N, K, km;
+  for (int l = 0; l < L; ++l) {
+    if (layer_keep && !layer_keep[l]) continue;
+    for (int i = 0; i < 6; ++i) {
+      if (!e->wfrag_use[i]) continue;
+      src.push_back(e->W + e->lp[l].*(pr[i].w));
+      dst.push_back(e->wfrag + (size_t)l * e->wfrag_layer + e->wfrag_off[i]);
+      ldb.push_back(pr[i].ldb);
+      N.push_back(pr[i].N);
+      K.push_back(pr[i].K);
+      km.push_back(pr[i].b_km);
+    }
+  }
+  if (!src.empty())
+    TRY(ssak_gemm_fragment_b_batched((int)src.size(), src.data(), ldb.data(), N.data(), K.data(), km.data(), dst.data(), (void*)st));
+  e->wfrag_valid = true;
+  return SSAK_OK;
+}
+
 }  // namespace
 
 // =================================================================================================== C ABI
@@ -649,6 +725,7 @@ extern "C" void ssak_w2v2_destroy(ssak_w2v2* e) {
   if (e->pc_wf) (void)hipFree(e->pc_wf);
   if (e->pc_wb) (void)hipFree(e->pc_wb);
   if (e->pc_wf_frag) (void)hipFree(e->pc_wf_frag);
+  if (e->wfrag) (void)hipFree(e->wfrag);
   if (e->pc_wb_frag) (void)hipFree(e->pc_wb_frag);
   if (e->pc_norms) (void)hipFree(e->pc_norms);
   delete e;
@@ -680,6 +757,7 @@ extern "C" int ssak_w2v2_bind(ssak_w2v2* e, float* params, float* grads, void* s
   e->P = params;
   e->G = grads;
   e->W = (bf16*)shadow_bf16;
+  e->wfrag_valid = false;
   return SSAK_OK;
 }
 
@@ -692,6 +770,8 @@ extern "C" int ssak_w2v2_set_option(ssak_w2v2* e, int option, int value) {
     e->attn_bwd_mode = value;
   } else if (option == SSAK_W2V2_OPT_POSCONV_DIRECT) {
     e->posconv_direct = value ? 1 : 0;
+  } else if (option == SSAK_W2V2_OPT_FRAGMENT_WEIGHTS) {
+    e->fragment_weights = value ? 1 : 0;
   } else {
     ssak_set_error("w2v2_set_option: unknown option %d", option);
     return SSAK_ERR_INVALID;
@@ -975,6 +1055,12 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
   }
   // ---- a7: encoder layers with LayerDrop: post-LN (base, :591-608) or pre-LN "stable layer norm" (XLSR, :631-654)
   e->keep.assign(c.num_layers, 1);
+  e->wfrag_valid = false;
+  if constexpr (!EXACT) {
+    // fragment-ordered weights of the layers that will run, for the products that take the B-direct GEMM form (the optimizer's
+    // event has been waited for above: the shadow is final)
+    if (tr && e->fragment_weights) TRY(refresh_weight_fragments(e, M, layer_keep, st));
+  }
   e->hres.assign(c.num_layers + 1, p.h1);
   const float scale = 1.f / sqrtf((float)hd);
   for (int l = 0; l < c.num_layers; ++l) {
@@ -999,7 +1085,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
     }
     const AT* x = BF(p.x[l]);
     AT* qkv = BF(lb.qkv);
-    TRY(GemmX<EXACT>(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
+    TRY(GemmX<EXACT>(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).bfrag(e->frag(l, 0)).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
     if (p.fused_attn) {
       // scores never leave the MFMA accumulators (attention.hip); only ctx and the per-row log-sum-exp are written
       if constexpr (!EXACT)
@@ -1012,7 +1098,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
       TRY(GemmX<EXACT>(F, hd, F).a(BF(lb.Pd), Fp).b(qkv + 2 * H, 3 * H, true).c(BF(lb.ctx), H)
               .batch(B, nh, (long)nh * F * Fp, (long)F * Fp, (long)F * 3 * H, hd, (long)F * H, hd).run(st));
     }
-    TRY(GemmX<EXACT>(M, H, H).a(BF(lb.ctx), H).b(W + L.wo, H).c(BF(p.tmpH), H).with_bias(P + L.bo).run(st));
+    TRY(GemmX<EXACT>(M, H, H).a(BF(lb.ctx), H).b(W + L.wo, H).bfrag(e->frag(l, 1)).c(BF(p.tmpH), H).with_bias(P + L.bo).run(st));
     if (!stable) {
       TRY(k_layernorm_fwd_t<AT>(BF(p.tmpH), x, P + L.ln1w, P + L.ln1b, BF(lb.r1), BF(lb.x1), stl, stl + M, M, H,
                           c.layer_norm_eps, DS(c.hidden_dropout, ds_hid1(l)), none, st));
@@ -1024,7 +1110,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
     TRY(GemmX<EXACT>(M, I, H).a(BF(lb.x1), H).b(W + L.w1, H).c(BF(lb.f1), I).with_bias(P + L.b1)
             .epi(tr ? SSAK_EPI_GELU_SAVE_GRAD : SSAK_EPI_GELU, nullptr, tr ? BF(lb.f1pre) : nullptr)  // f1pre := 8-bit codes of gelu'(pre) * mask (float values incl. 1 / (1 - p) in the exact mode)
             .drop(tr ? c.activation_dropout : 0.f, ds_act(l), seed).run(st));
-    TRY(GemmX<EXACT>(M, H, I).a(BF(lb.f1), I).b(W + L.w2, I).c(BF(p.tmpH), H).with_bias(P + L.b2).run(st));
+    TRY(GemmX<EXACT>(M, H, I).a(BF(lb.f1), I).b(W + L.w2, I).bfrag(e->frag(l, 2)).c(BF(p.tmpH), H).with_bias(P + L.b2).run(st));
     if (!stable) {
       TRY(k_layernorm_fwd_t<AT>(BF(p.tmpH), BF(lb.x1), P + L.ln2w, P + L.ln2b, BF(lb.r2), BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M,
                           M, H, c.layer_norm_eps, DS(c.hidden_dropout, ds_hid2(l)), none, st));
@@ -1272,7 +1358,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
             .colsum(Gd + L.b1).run(st, ffn_part, ffn_part_floats * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
     wq.push(GemmX<EXACT>(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
     AT* dX = BF(p.dB);
-    TRY(GemmX<EXACT>(M, H, I).a(dI, I).b(W + L.w1, H, true).c(dX, H).run(st));
+    TRY(GemmX<EXACT>(M, H, I).a(dI, I).b(W + L.w1, H, true).bfrag(e->frag(l, 5)).c(dX, H).run(st));
     AT* dR1;
     if (!stable) {
       // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
@@ -1288,7 +1374,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     const AT* dy1 = dY1;
     wq.push(GemmX<EXACT>(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));  // (bo's gradient: summed by the LN backward)
     AT* dctx = free_buf(dR1, dX, nullptr);
-    TRY(GemmX<EXACT>(M, H, H).a(dy1, H).b(W + L.wo, H, true).c(dctx, H).run(st));
+    TRY(GemmX<EXACT>(M, H, H).a(dy1, H).b(W + L.wo, H, true).bfrag(e->frag(l, 4)).c(dctx, H).run(st));
     // attention backward per (utterance, head)
     AT* qkv = BF(lb.qkv);
     AT* dqkv = BF(p.dqkvb[set]);
@@ -1310,7 +1396,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     }
     wq.push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
     TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
-    TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).c(dX, H).run(st));
+    TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).bfrag(e->frag(l, 3)).c(dX, H).run(st));
     wq.ann_off[wq.n_ann++] = L.wqkv;
     ++wq.layers;
     // data parallelism (a gradient-ready callback is installed): launch when a second layer is queued, or when another layer

@@ -13,7 +13,7 @@ import torch
 
 _DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")
 _LIB_PATH = os.environ.get("SSAK_HIP_LIB") or _DEFAULT_LIB  # (the override names another build OF THE SAME ABI: A/B runs, instrumented builds)
-ABI_VERSION = 300  # ssak_version() of the library this binding's struct layouts and signatures were written for
+ABI_VERSION = 301  # ssak_version() of the library this binding's struct layouts and signatures were written for
 
 
 class GemmDesc(C.Structure):
@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
                 ("sc2", C.c_long), ("alpha", C.c_float), ("epilogue", C.c_int), ("out_f32", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
                 ("drop_seed", C.c_uint64), ("bias_s2", C.c_long), ("pads_are_zero", C.c_int), ("colsum", C.c_int),
-                ("dynamic_tiles", C.c_int)]
+                ("dynamic_tiles", C.c_int), ("b_fragments", C.c_void_p)]
 
 
 class W2V2Config(C.Structure):
@@ -77,6 +77,11 @@ def _load():
         "ssak_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "ssak_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp, vp, vp, vp]),
         "ssak_gemm_bf16_grouped": (i32, [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
+        "ssak_gemm_fragment_b_bytes": (sz, [i32, i32]),
+        "ssak_gemm_fragment_b": (i32, [vp, C.c_long, i32, i32, i32, vp, vp]),
+        "ssak_gemm_fragment_b_batched": (i32, [i32, C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(i32), C.POINTER(i32),
+                                              C.POINTER(i32), C.POINTER(vp), vp]),
+        "ssak_gemm_uses_fragments": (i32, [C.POINTER(GemmDesc)]),
         "ssak_conv0_workspace_bytes": (sz, [i32, i32, i32]),
         "ssak_conv0_gn_gelu": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
         "ssak_prof_enable": (i32, [vp, i32]),
@@ -255,11 +260,13 @@ def ctc_wer(hyp_ids: torch.Tensor, hyp_lens: torch.Tensor, labels: torch.Tensor,
 def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
          accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0, pads_are_zero=False, colsum_out=None,
-         dynamic_tiles=False):
-    """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h)."""
+         dynamic_tiles=False, b_fragments=None):
+    """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h).  ``b_fragments``: the
+    copy of B made by :func:`gemm_fragment_b` (used when the library picks the B-direct kernel, ignored otherwise)."""
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
                  sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k, float(drop_p),
-                 drop_stream, drop_seed, 0, int(pads_are_zero), int(colsum_out is not None), int(dynamic_tiles))
+                 drop_stream, drop_seed, 0, int(pads_are_zero), int(colsum_out is not None), int(dynamic_tiles),
+                 ptr(b_fragments))
     n_slabs = split_k if split_k > 0 else max(1, min(32, ((K + 63) // 64) // 4))  # 0 = library-sized split
     ws = _ws(n_slabs * nb1 * nb2 * M * N * 4, A.device) if n_slabs > 1 else None
     if colsum_out is not None:
@@ -268,6 +275,21 @@ def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=
     check(lib.ssak_gemm_bf16(C.byref(d), ptr(A), ptr(B), ptr(C_out), ptr(bias), ptr(aux_in), ptr(aux_out), ptr(ws),
                              0 if ws is None else ws.numel(), stream()))
     return C_out
+
+
+def gemm_fragment_b(B, N, K, *, ldb=None, b_kmajor=False):
+    """Fragment-ordered copy of a weight operand (``ssak_gemm_fragment_b``): a bf16 tensor of ``ssak_gemm_fragment_b_bytes``."""
+    ldb = ldb if ldb is not None else (N if b_kmajor else K)
+    out = torch.empty(lib.ssak_gemm_fragment_b_bytes(N, K) // 2, dtype=torch.bfloat16, device=B.device)
+    check(lib.ssak_gemm_fragment_b(ptr(B), ldb, N, K, int(b_kmajor), ptr(out), stream()))
+    return out
+
+
+def gemm_uses_fragments(M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, pads_are_zero=False):
+    d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda if lda is not None else (M if a_kmajor else K),
+                 ldb if ldb is not None else (N if b_kmajor else K), ldc if ldc is not None else N, 1, 1, 0, 0, 0, 0, 0, 0, 1.0,
+                 EPI_NONE, 0, 0, 1, 0.0, 0, 0, 0, int(pads_are_zero), 0, 0, None)
+    return bool(lib.ssak_gemm_uses_fragments(C.byref(d)))
 
 
 def gemm_f32(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
@@ -339,7 +361,7 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
 
 
 ATTN_BWD_DEFAULT, ATTN_BWD_TWO_KERNEL, ATTN_BWD_FUSED = 0, 1, 2
-W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD, W2V2_OPT_POSCONV_DIRECT = 1, 2, 3
+W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD, W2V2_OPT_POSCONV_DIRECT, W2V2_OPT_FRAGMENT_WEIGHTS = 1, 2, 3, 4
 
 
 def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0,

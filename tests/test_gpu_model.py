@@ -309,6 +309,43 @@ def test_no_freeze_layer_norm_feature_encoder_gradients(mods):
     _check_grads(model, {n: g.numpy() for n, g in grads.items() if not n.startswith("wav2vec2.feature_extractor.")}, 6e-2)
 
 
+def test_fragment_ordered_weights_change_no_bit(mods):
+    """SSAK_W2V2_OPT_FRAGMENT_WEIGHTS (default on): a training forward copies the kept layers' projection weights into the
+    B-direct GEMM's fragment order and six products per layer read them instead of staging the weight through LDS.  Same
+    accumulation order, so logits and every gradient must be BIT-identical to the option switched off -- with LayerDrop
+    (a dropped layer's copies are not refreshed and not read), dropout, and across an optimizer-style weight change between
+    two steps (the copies are refreshed by every training forward)."""
+    import ssak_amd.hip as hip
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    oc = R.W2V2Config.base(num_hidden_layers=3)
+    p = R.init_params(oc, 5)
+    rng = np.random.default_rng(3)
+    B = 32  # 32 x 499 frames, the train step: the N = 768 products run on 192-row tiles
+    x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(160000).astype(np.float32) for _ in range(B)]))
+    labels = torch.tensor(R.pad_labels([list(rng.integers(1, 32, 8)) for _ in range(B)]))
+    keep = np.array([1, 0, 1], dtype=np.uint8)
+    outs = []
+    for frag in (1, 0):
+        model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).train()
+        model.set_option(hip.W2V2_OPT_FRAGMENT_WEIGHTS, frag)
+        model.load_state_dict(p)
+        steps = []
+        for step in range(2):
+            out = model(x, labels=labels, layer_keep=keep if step == 0 else np.ones(3, dtype=np.uint8), dropout_seed=100 + step)
+            model.grads[:model.num_trainable].fill_(float("nan"))
+            model.backward()
+            steps.append((out.logits.clone(), model.grads[:model.num_trainable].clone()))
+            # an optimizer-style update of the bound buffers between the steps
+            model.params[:model.num_trainable].mul_(1.01)
+            model.sync_weights()
+        outs.append(steps)
+    assert hip.gemm_uses_fragments(B * 499, 768, 3072, pads_are_zero=True)
+    for (lg1, g1), (lg0, g0) in zip(*outs):
+        assert torch.isfinite(g1).all()
+        assert torch.equal(lg1, lg0)
+        assert torch.equal(g1, g0)
+
+
 @pytest.mark.parametrize("geometry", ["base_cg48", "xlsr_cg64"])
 def test_positional_conv_direct_kernel_equals_toeplitz_gemm(mods, geometry):
     """The grouped positional convolution as a direct convolution with its input window resident in LDS (posconv.hip; group

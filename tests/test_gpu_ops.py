@@ -529,6 +529,51 @@ def test_gemm_fused_column_sums(hip, M, N):
     assert bool(((cs - want).abs() <= tol).all()), float((cs - want).abs().max())
 
 
+@pytest.mark.parametrize("N,K,b_km", [(768, 3072, False), (300, 368, False), (768, 2304, True), (260, 72, True), (64, 64, False)])
+def test_gemm_fragment_b_layout(hip, N, K, b_km):
+    """ssak_gemm_fragment_b against its documented layout (include/ssak_hip.h): element (cb, kt, j, kk, lane, e) of the copy is
+    B(n = 64 cb + 16 j + (lane & 15), k = 64 kt + 32 kk + 8 (lane >> 4) + e), zero beyond N / K, for both stored orientations
+    and for extents that are not multiples of the tile (bit-exact: a copy)."""
+    g = torch.Generator().manual_seed(N + K)
+    Bl = torch.randn(N, K, generator=g).to(torch.bfloat16)  # logical [n][k]
+    ld = ((N if b_km else K) + 7) // 8 * 8 + 8              # a padded leading dimension
+    stored = torch.full((K if b_km else N, ld), 7.0, dtype=torch.bfloat16)
+    stored[:, :(N if b_km else K)] = Bl.t() if b_km else Bl
+    out = hip.gemm_fragment_b(stored.cuda(), N, K, ldb=ld, b_kmajor=b_km).cpu()
+    nb64, nkt = (N + 255) // 256 * 4, (K + 63) // 64
+    assert out.numel() == nb64 * nkt * 4096
+    pad = torch.zeros(nb64 * 64, nkt * 64, dtype=torch.bfloat16)
+    pad[:N, :K] = Bl
+    # [cb][j][nl][kt][kk][g][e] -> [cb][kt][j][kk][g][nl][e]   (lane = 16 g + nl)
+    want = pad.view(nb64, 4, 16, nkt, 2, 4, 8).permute(0, 3, 1, 4, 5, 2, 6).contiguous().view(-1)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+
+
+def test_gemm_b_direct_form_is_bit_identical(hip):
+    """The B-direct form of the persistent GEMM (fragment-ordered weights loaded straight into registers, B never in LDS;
+    ssak_gemm_desc.b_fragments) against the LDS form on the shapes that take it in the train step (M = 32 x 499 frames; qkv,
+    output and feed-forward-down projections and the three input-gradient products), plus a ragged M / a K tail and a bias:
+    same accumulation order -> the same bits.  Also: shapes the library keeps on the LDS form ignore the copy."""
+    g = torch.Generator().manual_seed(11)
+    took = 0
+    cases = [(15968, 2304, 768, False), (15968, 768, 768, False), (15968, 768, 3072, False), (15968, 768, 2304, True),
+             (15968, 768, 768, True), (15968, 768, 3072, True), (7777, 768, 3000, False), (15968, 3072, 768, False), (1000, 300, 368, False)]
+    for M, N, K, b_km in cases:
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+        Bs = (torch.randn(K, N, generator=g) if b_km else torch.randn(N, K, generator=g)).to(torch.bfloat16).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        frag = hip.gemm_fragment_b(Bs, N, K, b_kmajor=b_km)
+        kw = dict(b_kmajor=b_km, lda=K, ldb=N if b_km else K, ldc=N, bias=bias, pads_are_zero=True)
+        want = hip.gemm(A, Bs, torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), M, N, K, **kw)
+        got = hip.gemm(A, Bs, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"), M, N, K, b_fragments=frag, **kw)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (M, N, K, b_km)
+        ref = A.float() @ (Bs.float() if b_km else Bs.float().t()) + bias
+        assert float((got.float() - ref).norm() / ref.norm()) < 4e-3
+        took += hip.gemm_uses_fragments(M, N, K, b_kmajor=b_km, pads_are_zero=True)
+    assert took >= 6, took  # the six per-layer products of the train step do take the form
+    assert not hip.gemm_uses_fragments(15968, 3072, 768)  # feed-forward up: wide output, stays on the LDS form
+
+
 def test_gemm_dynamic_tile_order(hip):
     """The ticket-drawn tile order of the persistent kernels (what the data-parallel trainers switch on) gives exactly the
     static order's results: multi-round shapes, integer operands (bit-exact), repeated launches on one stream (every launch
