@@ -239,6 +239,9 @@ static_assert(sizeof(GemmParams) + sizeof(P8Group) <= 4096, "kernel arguments ar
 template <int MH, bool A_KM, bool B_KM, bool GROUPED = false, int EPI = -1>
 __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p, const P8GroupT<GROUPED ? P8_GROUP_CAP : 1> grp) {
   constexpr int BM = 64 * MH, SEGA = 16 * MH;
+  // (Balanced load phases for the 192-row form -- the right B fragments of K tile t+1 read in LB(t) into a second register set
+  // and BR staged from LA, so that both load phases carry 2 MH + 4 fragment reads and 4 LDS-DMA instructions instead of
+  // 2 MH + 8 / 2 and 2 MH / 6 -- were built in round 3, bit-identical, and are 3-10 % SLOWER: profiles/r03_gemm_balanced_probe.log.)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef P8_STAMPS
   int p8_round = 0;  // stamps: [workgroup][tile round < 4][8]
