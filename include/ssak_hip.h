@@ -357,9 +357,9 @@ int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begi
  * SSAK_W2V2_OPT_DYNAMIC_TILES  0 / 1: ssak_gemm_desc.dynamic_tiles of every product the engine launches -- the data-parallel
  *                              trainers set it, RCCL's kernels share the chip with the persistent GEMMs;
  * SSAK_W2V2_OPT_ATTENTION_BWD  SSAK_ATTN_BWD_*: the form of the fused attention backward;
- * SSAK_W2V2_OPT_POSCONV_DIRECT  1 (default) / 0: the grouped positional convolution as a direct convolution with its input
- *                              window resident in LDS (group widths 48 and 64) or as the Toeplitz GEMM of rounds 1-2 (kept for
- *                              other geometries and as the comparison path of the tests);
+ * SSAK_W2V2_OPT_POSCONV_DIRECT  1 (default) / 0: the grouped positional convolution (forward, input gradient and weight gradient)
+ *                              as direct convolutions with the input rows resident in LDS (group widths 48 and 64) or as the
+ *                              Toeplitz GEMMs of rounds 1-2 (kept for other geometries and as the comparison path of the tests);
  * SSAK_W2V2_OPT_FRAGMENT_WEIGHTS  0 (default) / 1: every TRAINING forward makes fragment-ordered copies of the kept encoder
  *                              layers' projection weights (one batched launch after the optimizer's event, ssak_gemm_fragment_b)
  *                              and the forward / input-gradient products the library would run in its B-direct form take

@@ -6,7 +6,7 @@
 // GEMM instantiation registers a slot under its own name (as rocprofv3 prints it) the first time it is launched.
 enum : int {
   PROF_ATTN_FWD = 0, PROF_ATTN_BWD, PROF_LN_FWD, PROF_LN_BWD, PROF_CONV0, PROF_ADAMW, PROF_SUMSQ, PROF_CTC, PROF_WAVE_NORM,
-  PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX, PROF_POSCONV_DIRECT,
+  PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX, PROF_POSCONV_DIRECT, PROF_POSCONV_WGRAD,
   PROF_CLASS_SLOTS
 };
 constexpr int PROF_MAX_SLOTS = 128;
@@ -150,6 +150,11 @@ bool k_posconv_direct_supported(int H, int G, int K);
 int k_posconv_frag_weights(const bf16* w, bf16* wfrag, int H, int G, int K, hipStream_t st);
 int k_posconv_direct(const bf16* x, long rows_per_group, int row0, const bf16* w, const float* bias, bf16* out, bf16* pre, int B, int F,
                      int H, int G, int K, int gelu, hipStream_t st);
+
+// ... and its weight gradient as a direct contraction over time (x, dy packed by k_posconv_pack_t; dwf [G][K * cg][cg] fp32)
+size_t k_posconv_wgrad_scratch_floats(int H, int G, int K);
+int k_posconv_wgrad_direct(const bf16* x, const bf16* dy, long rows_per_group, long rows, int lead, float* dwf, float* scratch, int H, int G,
+                           int K, hipStream_t st);
 
 // whisper_frontend.hip
 // (T_ = bf16, or float in the fp32-exact mode)

@@ -1460,12 +1460,21 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     // dW^T[g][tap*cg + c][n] = sum over packed rows of x[row + tap][c] * dy[row][n]: one long-K GEMM per group, with the
     // 48 output channels of a group on the N side (128x64 tiles, 75 % useful) -- on the M side they sat in 128-row tiles
     // (37 % useful) and this product was the slowest launch of the backward
-    TRY(GemmX<EXACT>(K * cg, cg, B * RS)
-            .a(BF(p.pgx), cg, true)
-            .b(BF(p.pgdy) + (long)lead * cg, cg, true)
-            .c(FP(p.dwf), cg, true)
-            .batch(1, G, 0, p.pg_rows * cg, 0, p.pg_rows * cg, 0, (long)cg * K * cg)
-            .run(st));
+    bool pcw_direct = false;
+    if constexpr (!EXACT)
+      pcw_direct = e->posconv_direct && e->pc_wf_frag != nullptr && k_posconv_wgrad_scratch_floats(H, G, K) * sizeof(float) <= p.slab_bytes;
+    if (pcw_direct) {
+      // direct contraction over time: a stage of x and dy rows is written to LDS once and serves every tap (posconv.hip)
+      if constexpr (!EXACT)
+        TRY(k_posconv_wgrad_direct(BF(p.pgx), BF(p.pgdy), p.pg_rows, (long)B * RS, lead, FP(p.dwf), reinterpret_cast<float*>(slab), H, G, K, st));
+    } else {
+      TRY(GemmX<EXACT>(K * cg, cg, B * RS)
+              .a(BF(p.pgx), cg, true)
+              .b(BF(p.pgdy) + (long)lead * cg, cg, true)
+              .c(FP(p.dwf), cg, true)
+              .batch(1, G, 0, p.pg_rows * cg, 0, p.pg_rows * cg, 0, (long)cg * K * cg)
+              .run(st));
+    }
     TRY(k_posconv_weight_bwd(FP(p.dwf), P + e->p_pc_g, P + e->p_pc_v, e->pc_norms, Gd + e->p_pc_g, Gd + e->p_pc_v, H, G, K, st));
     // input gradient: correlation of dy with the flipped, transposed taps
     const int shift = 2 * (K / 2) - K + 1;  // 1 for even K (SamePad drops the last frame), 0 for odd
