@@ -176,8 +176,8 @@ def main():
         model.set_option(hip.W2V2_OPT_DYNAMIC_TILES, 1)
     if os.environ.get("SSAK_BENCH_POSCONV_GEMM") == "1":  # A/B switch: the positional convolution as the Toeplitz GEMM of rounds 1-2
         model.set_option(hip.W2V2_OPT_POSCONV_DIRECT, 0)
-    if os.environ.get("SSAK_BENCH_NO_FRAGMENTS") == "1":  # A/B switch: every product stages its weight through LDS (rounds 1-2)
-        model.set_option(hip.W2V2_OPT_FRAGMENT_WEIGHTS, 0)
+    if os.environ.get("SSAK_BENCH_FRAGMENTS") == "1":  # A/B switch: the opt-in B-direct GEMM form with fragment-ordered weight copies
+        model.set_option(hip.W2V2_OPT_FRAGMENT_WEIGHTS, 1)
     trainer.broadcast_parameters()
 
     T = int(round(args.seconds * 16000))
