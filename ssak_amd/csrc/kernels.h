@@ -71,7 +71,10 @@ int k_layernorm_bwd_t(const T* g1, const T* g2, const T* r, const float* mean, c
                       float* partial /*[LN_BWD_BLOCKS*3*C] scratch*/, int M, int C, const DropSpec& pre, const DropSpec& post,
                       hipStream_t st, const DropSpec& mid = DropSpec(), float* dy_colsum = nullptr /*[C] += column sums of dy*/,
                       const float* post_gelu_beta = nullptr /*forward was gelu(LN(x)): beta of that LN*/);
-constexpr int LN_BWD_BLOCKS = 768;  // 3 waves per SIMD (the kernel takes 159 VGPRs): bytes in flight bound this kernel (one row + one prefetched row per wave)
+#ifndef SSAK_LN_BWD_BLOCKS
+#define SSAK_LN_BWD_BLOCKS 768
+#endif
+constexpr int LN_BWD_BLOCKS = SSAK_LN_BWD_BLOCKS;  // 3 waves per SIMD (the kernel takes 159 VGPRs): bytes in flight bound this kernel (one row + one prefetched row per wave)
 template <typename T>
 int k_softmax_fwd_t(const T* S, T* P, T* Pd, const int32_t* klens, int rows, int cols, int ld,
                     int rows_per_batch, const DropSpec& drop, hipStream_t st);
