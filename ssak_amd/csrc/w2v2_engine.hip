@@ -1462,7 +1462,8 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     // (37 % useful) and this product was the slowest launch of the backward
     bool pcw_direct = false;
     if constexpr (!EXACT)
-      pcw_direct = e->posconv_direct && e->pc_wf_frag != nullptr && k_posconv_wgrad_scratch_floats(H, G, K) * sizeof(float) <= p.slab_bytes;
+      pcw_direct = e->posconv_direct && e->pc_wf_frag != nullptr && k_posconv_wgrad_scratch_floats(H, G, K) * sizeof(float) <= p.slab_bytes &&
+                   !SSAK_DEV_ENV("SSAK_PCW_GEMM");  // (development builds: the weight gradient alone as the Toeplitz GEMM, tools/pcw_check.py)
     if (pcw_direct) {
       // direct contraction over time: a stage of x and dy rows is written to LDS once and serves every tap (posconv.hip)
       if constexpr (!EXACT)

@@ -276,7 +276,9 @@ def test_base_matched_loss_50_steps_vs_hf_curve(gold, which):
     * fast_ramp: a 100x faster ramp (5 warm-up steps to 1e-4): the loss collapses to the blank plateau (3.3) within 7 steps
       through gradient-norm spikes of 166.  Through the descent (steps 0-12) the curves must agree to 5e-3 per step (measured:
       1.3e-3); on the plateau the fp32 reference itself scatters by +-2 % from step to step (its gradient norm jumps between 2
-      and 12), so there the bars are 4e-2 per step and 1e-2 on the means of 10-step windows."""
+      and 12) and the trajectory is chaotic: replacing ONE weight-gradient kernel by another that agrees with it to 2e-7
+      relative (fp32 summation order; tests/dev_pcw_check.py) moves the largest per-step deviation from 1.8e-2 (step 26) to 5.4e-2
+      (step 17).  So there the per-step bar is 8e-2 and the bar that means something is 1e-2 on the means of 10-step windows."""
     from oracle import w2v2_ref as R
     from oracle.gen_golden_full import curve_inputs
     from ssak_amd.config import Wav2Vec2Config
@@ -314,6 +316,6 @@ def test_base_matched_loss_50_steps_vs_hf_curve(gold, which):
             t = sd[str(n)].double().reshape(-1)
             assert abs(float(t.norm()) - nr) < 2e-3 * nr + 1e-6, (str(n), float(t.norm()), nr)
     else:
-        assert rel[:13].max() < 5e-3 and rel.max() < 4e-2
+        assert rel[:13].max() < 5e-3 and rel.max() < 8e-2
         for w in range(20, 50, 10):
             assert abs(got[w:w + 10].mean() - ref[w:w + 10].mean()) < 1e-2 * ref[w:w + 10].mean(), w

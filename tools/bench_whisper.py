@@ -21,8 +21,10 @@ g = torch.Generator().manual_seed(0)
 sd = {}
 for n, (off, cnt, shape) in model.layout.items():
     if n.endswith("embed_positions.weight"):
-        from oracle.whisper_ref import sinusoids
-        sd[n] = sinusoids(*shape)
+        length, channels = shape  # Whisper's fixed sinusoidal table
+        inv = torch.exp(-(np.log(10000.0) / (channels // 2 - 1)) * torch.arange(channels // 2))
+        t = torch.arange(length).view(-1, 1) * inv.view(1, -1)
+        sd[n] = torch.cat([t.sin(), t.cos()], dim=1)
     elif "layer_norm.weight" in n:
         sd[n] = torch.ones(shape)
     elif n.endswith(".bias"):
