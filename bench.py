@@ -99,17 +99,22 @@ def build_stamp():
 
 def traffic_of(kernel_name: str, build: dict):
     """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 --pmc passes -- but only if they were taken on
-    THIS library (profiles/rNN_hbm_traffic.json carries the stamp of the build it measured): a number from another build is
-    refused, not reported."""
+    THIS build (profiles/rNN_hbm_traffic.json carries the stamp of the build it measured: library sha256 and the sha256 of the
+    kernel sources): a number from other sources is refused, not reported."""
     import glob
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
             tj = json.load(open(fn))
             rel = os.path.relpath(fn, ROOT)
-            if tj.get("stamp", {}).get("lib_sha256") != build["lib_sha256"]:
-                return None, f"refused: {rel} was measured on another build of the library (its stamp differs from the loaded libssak_hip.so)"
+            st = tj.get("stamp", {})
+            same_lib = st.get("lib_sha256") == build["lib_sha256"]
+            # (hipcc's output is not bit-reproducible across incremental builds: the identity that matters is the kernel SOURCES)
+            same_src = st.get("source_sha256") == build["source_sha256"] and not build.get("sources_modified_since_commit")
+            if not (same_lib or same_src):
+                return None, f"refused: {rel} was measured on another build of the library (neither its library nor its source stamp matches the loaded libssak_hip.so)"
             return (tj["kernels"][kernel_name]["hbm_bytes_per_launch"],
-                    f"{rel} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of: {tj['command']}; same library)")
+                    f"{rel} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of: {tj['command']}; "
+                    f"{'same library' if same_lib else 'same kernel sources, library rebuilt'})")
         except (OSError, KeyError, ValueError):
             return None, None
     return None, None
