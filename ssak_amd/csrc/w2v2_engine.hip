@@ -426,7 +426,7 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     // two sets (layer pairs) by default; SSAK_WGRAD_ALL=1: up to WGRAD_SETS layers per grouped launch on a single GPU -- measured
     // SLOWER (eleven layers as one 1 188-tile launch: 2 064 us per step against 2 014 us in pairs, the same 0.46 of the roof per
     // tile: the better fill of the rounds is lost again to the operand panels of many layers competing for the L2)
-    p.wgrad_sets = wgrad_all() ? std::max(2, std::min(WGRAD_SETS, c.num_layers)) : 2;
+    p.wgrad_sets = wgrad_all() ? std::max(2, std::min(WGRAD_SETS, c.num_layers)) : 3;  // (three: a layer's last product may wait for the launch after next)
     for (int s2 = 1; s2 < p.wgrad_sets; ++s2) {
       p.dYb[s2] = cv.take((size_t)M * H * b2);
       p.dY1b[s2] = cv.take((size_t)M * H * b2);
@@ -559,25 +559,37 @@ struct GemmX : Gemm {
 };
 
 // Weight-gradient products are not on the critical path of the backward: they are queued and launched together as ONE grouped
-// GEMM (ssak_gemm_bf16_grouped) instead of four launches per layer that each need split-K slabs and a reduction pass: two
-// layers at a time (216 tiles of 256 x 256: one round of workgroups; under data parallelism their gradient ranges are announced
-// early for the bucketed all-reduce).  All kept layers in one multi-round launch (SSAK_WGRAD_ALL=1; 1 188 tiles for eleven
-// layers = 4.6 rounds, 93 % of the CU-rounds busy where a pair fills 84 %) was measured slower on one GPU: see the plan.
+// GEMM (ssak_gemm_bf16_grouped) instead of four launches per layer that each need split-K slabs and a reduction pass.  The
+// queue is packed greedily into launches of at most one round of 256 x 256 tiles (see flush_gemms in the backward): ~2.4 base
+// layers per launch (rounds 1-2: pairs of layers, 216 tiles, with the odd layer LayerDrop leaves over as four split-K
+// launches); under data parallelism a layer's gradient range is announced for the bucketed all-reduce as soon as its last
+// product has been launched.  All kept layers in one multi-round launch (SSAK_WGRAD_ALL=1; 1 188 tiles for eleven layers = 4.6
+// rounds) was measured slower on one GPU: see the plan.
 struct WgradQueue {
   static constexpr int CAP = 4 * WGRAD_SETS;  // four products per encoder layer
   ssak_gemm_desc d[CAP];
   const void* A[CAP];
   const void* B[CAP];
   void* C[CAP];
+  int set[CAP];  // buffer set the product's operands live in
   int n = 0, layers = 0, tiles = 0;
+  long pushed = 0, launched = 0;  // products ever queued / launched
   bool f32 = false;
   // gradient ranges to announce once the queued products have been launched, in LAYER ORDER: a data-parallel caller
   // pairs the k-th announcement of every rank in one collective, and LayerDrop decisions differ between ranks, so a
   // dropped layer's (zero) range must not overtake the kept layers still waiting here
   long ann_off[64];
+  long ann_last[64];  // the layer's last product (sequence number), -1: nothing to wait for (a dropped layer)
   int n_ann = 0;
   static int tiles_of(const ssak_gemm_desc& g) { return ssak_cdiv(g.M, 256) * ssak_cdiv(g.N, 256); }
-  void push(const Gemm& g) {
+  bool uses_set(int s) const {
+    for (int i = 0; i < n; ++i)
+      if (set[i] == s) return true;
+    return false;
+  }
+  void push(const Gemm& g, int buffer_set) {
+    set[n] = buffer_set;
+    ++pushed;
     d[n] = g.d;
     A[n] = g.A;
     B[n] = g.B;
@@ -586,7 +598,8 @@ struct WgradQueue {
     tiles += tiles_of(g.d);
     ++n;
   }
-  // launch what is queued: grouped when it fills at least 5/8 of a round of 256 workgroups, else one by one (split-K)
+  // launch what is queued: grouped when it fills at least 5/8 of a round of 256 workgroups, else one by one (split-K: the last,
+  // partial launch of a backward and tiny test models)
   int flush(hipStream_t st, void* slab, size_t slab_bytes) {
     int rc = SSAK_OK;
     if (n > 0) {
@@ -601,6 +614,7 @@ struct WgradQueue {
         }
       }
     }
+    launched += n;
     n = 0;
     tiles = 0;
     return rc;
@@ -1288,19 +1302,34 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   };
   const size_t ln_part_floats = (size_t)LN_BWD_BLOCKS * 3 * H;
   int kept = 0;  // layers that ran so far: selects the buffer set their weight-gradient operands live in
-  const int layer_tiles = ssak_cdiv(3 * H, 256) * ssak_cdiv(H, 256) + ssak_cdiv(H, 256) * ssak_cdiv(H, 256) +
-                          2 * ssak_cdiv(I, 256) * ssak_cdiv(H, 256);
   auto flush_reductions = [&]() -> int {
     TRY(k_reduce_flush(sink, st));
     red_used = 0;
     return SSAK_OK;
   };
+  // Weight-gradient products are packed GREEDILY into launches of at most one round of 256 x 256 tiles (a base layer has 108:
+  // pairs of layers filled 216 of 256 workgroups and LayerDrop left an odd layer over in half of the steps, which then ran as
+  // four split-K launches): a product that does not fit any more starts the next launch, so launches hold ~2.4 layers and a
+  // layer's products may go out in two launches.  Its gradient range is announced when the last of them has been launched.
+  auto flush_gemms = [&]() -> int {
+    TRY(wq.flush(st, slab, p.slab_bytes));
+    int done = 0;
+    while (done < wq.n_ann && wq.ann_last[done] < wq.launched) announce(wq.ann_off[done++], layer_span);
+    for (int i = done; i < wq.n_ann; ++i) {
+      wq.ann_off[i - done] = wq.ann_off[i];
+      wq.ann_last[i - done] = wq.ann_last[i];
+    }
+    wq.n_ann -= done;
+    return SSAK_OK;
+  };
+  auto wq_push = [&](const Gemm& g, int buffer_set) -> int {
+    if (wq.n > 0 && (wq.tiles + WgradQueue::tiles_of(g.d) > 256 || wq.n == WgradQueue::CAP)) TRY(flush_gemms());
+    wq.push(g, buffer_set);
+    return SSAK_OK;
+  };
   auto flush_wgrads = [&]() -> int {
     TRY(flush_reductions());
-    TRY(wq.flush(st, slab, p.slab_bytes));
-    for (int i = 0; i < wq.n_ann; ++i) announce(wq.ann_off[i], layer_span);
-    wq.n_ann = 0;
-    wq.layers = 0;
+    TRY(flush_gemms());
     return SSAK_OK;
   };
   SinkGuard sink_guard(&sink);
@@ -1314,10 +1343,12 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     const long nxt_b = (l + 1 < c.num_layers) ? e->lp[l + 1].ln1b : e->p_eln_b;
     if (!e->keep[l]) {
       // zeros (memset above), still part of the all-reduce; behind any kept layer whose gradients are still queued
-      if (wq.n_ann > 0)
-        wq.ann_off[wq.n_ann++] = L.wqkv;
-      else
+      if (wq.n_ann > 0) {
+        wq.ann_off[wq.n_ann] = L.wqkv;
+        wq.ann_last[wq.n_ann++] = -1;
+      } else {
         announce(L.wqkv, layer_span);
+      }
       if (!stable) continue;  // identity layer: gradient passes through unchanged
       // x[l+1] = LN_next(r): its gradient joins the residual-stream gradient; nothing consumed x[l]
       AT* dr = free_buf(gA, gB, Gres);
@@ -1336,6 +1367,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     AT* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
     const int set = kept % p.wgrad_sets;
     ++kept;
+    if (wq.uses_set(set)) TRY(flush_gemms());  // a queued product still reads the buffers this layer is about to overwrite
     AT* dY = BF(p.dYb[set]);     // dy of the feed-forward branch (dropout mask applied): dX and dW operand
     AT* dY1 = BF(p.dY1b[set]);   // dy of the attention branch
     AT* dI = BF(p.dIb[set]);
@@ -1351,12 +1383,12 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     // (the dy output is written even without hidden dropout -- a plain copy then -- so that the queued weight-gradient
     // products always read buffers of this layer's set, never the rotating residual-stream buffers)
     const AT* dy2 = dY;
-    wq.push(GemmX<EXACT>(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true));  // (b2's gradient: summed by the LN backward)
+    TRY(wq_push(GemmX<EXACT>(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true), set));  // (b2's gradient: summed by the LN backward)
     TRY(GemmX<EXACT>(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
             .epi(SSAK_EPI_MUL_AUX, BF(lb.f1pre))  // the forward saved the whole factor (GELU' and the dropout mask) as 8-bit codes
             .drop(c.activation_dropout, ds_act(l), seed)  // (which 1 / (1 - p) the codes decode with; no mask is drawn here)
             .colsum(Gd + L.b1).run(st, ffn_part, ffn_part_floats * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
-    wq.push(GemmX<EXACT>(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true));
+    TRY(wq_push(GemmX<EXACT>(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true), set));
     AT* dX = BF(p.dB);
     TRY(GemmX<EXACT>(M, H, I).a(dI, I).b(W + L.w1, H, true).bfrag(e->frag(l, 5)).c(dX, H).run(st));
     AT* dR1;
@@ -1372,7 +1404,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
                           Gd + L.ln2b, ln_part2, M, H, DS(c.hidden_dropout, ds_hid1(l)), none, st, none, Gd + L.bo));
     }
     const AT* dy1 = dY1;
-    wq.push(GemmX<EXACT>(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true));  // (bo's gradient: summed by the LN backward)
+    TRY(wq_push(GemmX<EXACT>(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true), set));  // (bo's gradient: summed by the LN backward)
     AT* dctx = free_buf(dR1, dX, nullptr);
     TRY(GemmX<EXACT>(M, H, H).a(dy1, H).b(W + L.wo, H, true).bfrag(e->frag(l, 4)).c(dctx, H).run(st));
     // attention backward per (utterance, head)
@@ -1394,17 +1426,16 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       TRY(GemmX<EXACT>(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
     }
-    wq.push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true));
+    TRY(wq_push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true), set));
     TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
     TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).bfrag(e->frag(l, 3)).c(dX, H).run(st));
-    wq.ann_off[wq.n_ann++] = L.wqkv;
+    wq.ann_off[wq.n_ann] = L.wqkv;
+    wq.ann_last[wq.n_ann++] = wq.pushed - 1;  // announced once the qkv product -- the layer's last -- has been launched
     ++wq.layers;
-    // data parallelism (a gradient-ready callback is installed): launch when a second layer is queued, or when another layer
-    // would spill into a second round of workgroups; single GPU: when every buffer set is in use (then at the end of the loop)
-    if ((e->on_ready || p.wgrad_sets == 2) ? (wq.layers == 2 || wq.tiles + layer_tiles > 256) : (wq.layers == p.wgrad_sets))
-      TRY(flush_wgrads());
-    else if (wq.layers > 0 && (wq.layers & 1) == 0)
-      TRY(flush_reductions());  // the deferred second stages of the column reductions still go out every two layers
+    if (wgrad_all() ? (wq.layers % p.wgrad_sets == 0) : false)
+      TRY(flush_wgrads());  // (SSAK_WGRAD_ALL: one launch per p.wgrad_sets layers)
+    else if ((wq.layers & 1) == 0)
+      TRY(flush_reductions());  // the deferred second stages of the column reductions go out every two layers
     if (!stable) {
       // gradient w.r.t. this layer's input = dR1 (residual of r1) + dX
       gA = dR1;
