@@ -1323,7 +1323,8 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     return SSAK_OK;
   };
   auto wq_push = [&](const Gemm& g, int buffer_set) -> int {
-    if (wq.n > 0 && (wq.tiles + WgradQueue::tiles_of(g.d) > 256 || wq.n == WgradQueue::CAP)) TRY(flush_gemms());
+    const bool full = !wgrad_all() && wq.tiles + WgradQueue::tiles_of(g.d) > 256;  // (SSAK_WGRAD_ALL: multi-round launches on purpose)
+    if (wq.n > 0 && (full || wq.n == WgradQueue::CAP)) TRY(flush_gemms());
     wq.push(g, buffer_set);
     return SSAK_OK;
   };
