@@ -884,18 +884,22 @@ int launch_p8(const GemmParams& p, hipStream_t st) {
   q.tile_ctr = nullptr;
   if (ntiles > n_cu && n_cu % 8 == 0 && p.dynamic)
     if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
-#ifdef P8BD_SLOT_PER_SHAPE
-  char nms[112];
-  snprintf(nms, sizeof(nms), "gemm_p8_kernel<%d, %s, %s, false, %d> N=%d K=%d", MH, A_KM ? "true" : "false", B_KM ? "true" : "false", EPI, p.N, p.K);
-  const int slot = ssak_prof_register(nms, SSAK_BOUND_MFMA);
-#else
-  static int slot = -1;
-  if (slot < 0) {
-    char nm[112];
-    snprintf(nm, sizeof(nm), "gemm_p8_kernel<%d, %s, %s, false, %d>", MH, A_KM ? "true" : "false", B_KM ? "true" : "false", EPI);
-    slot = ssak_prof_register(nm, SSAK_BOUND_MFMA);
+  // one timing slot per (instantiation, N, K): an instantiation serves several products of the step (qkv, attention output and
+  // feed-forward-down projections share one), and "algorithmic FLOPs per launch" only means something per product
+  static std::mutex slot_mu;
+  static std::map<std::pair<int, int>, int> slots;
+  int slot;
+  {
+    std::lock_guard<std::mutex> lock(slot_mu);
+    auto it = slots.find({p.N, p.K});
+    if (it == slots.end()) {
+      char nm[112];
+      snprintf(nm, sizeof(nm), "gemm_p8_kernel<%d, %s, %s, false, %d> (N = %d, K = %d)", MH, A_KM ? "true" : "false", B_KM ? "true" : "false", EPI,
+               p.N, p.K);
+      it = slots.emplace(std::make_pair(p.N, p.K), ssak_prof_register(nm, SSAK_BOUND_MFMA)).first;
+    }
+    slot = it->second;
   }
-#endif
   ProfScope prof_scope(slot, 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q, none);  // one persistent workgroup per CU
   SSAK_LAUNCH_CHECK();
@@ -917,18 +921,19 @@ int launch_p8bd(const GemmParams& p, hipStream_t st) {
   q.tile_ctr = nullptr;
   if (ntiles > n_cu && n_cu % 8 == 0 && p.dynamic)
     if (int rc = p8_ticket_slot(st, &q.tile_ctr)) return rc;
-#ifdef P8BD_SLOT_PER_SHAPE  // development: one timing slot per (N, K)
-  char nms[112];
-  snprintf(nms, sizeof(nms), "gemm_p8bd_kernel<%d, %d> N=%d K=%d", MH, EPI, p.N, p.K);
-  const int slot = ssak_prof_register(nms, SSAK_BOUND_MFMA);
-#else
-  static int slot = -1;
-  if (slot < 0) {
-    char nm[112];
-    snprintf(nm, sizeof(nm), "gemm_p8bd_kernel<%d, %d>", MH, EPI);
-    slot = ssak_prof_register(nm, SSAK_BOUND_MFMA);
+  static std::mutex slot_mu;
+  static std::map<std::pair<int, int>, int> slots;  // one timing slot per (N, K), as launch_p8
+  int slot;
+  {
+    std::lock_guard<std::mutex> lock(slot_mu);
+    auto it = slots.find({p.N, p.K});
+    if (it == slots.end()) {
+      char nm[112];
+      snprintf(nm, sizeof(nm), "gemm_p8bd_kernel<%d, %d> (N = %d, K = %d)", MH, EPI, p.N, p.K);
+      it = slots.emplace(std::make_pair(p.N, p.K), ssak_prof_register(nm, SSAK_BOUND_MFMA)).first;
+    }
+    slot = it->second;
   }
-#endif
   ProfScope prof_scope(slot, 2.0 * p.M * p.N * (double)p.K * p.nz, st);
   kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P8_THREADS, P8_LDS, st>>>(q);
   SSAK_LAUNCH_CHECK();
