@@ -14,7 +14,7 @@ EXTRA ?=
 # `make DEV=1`: development switches read from the environment (SSAK_GEMM_P8, SSAK_ATTN_TILE, ...) are compiled in; the
 # release library has none (common.h: SSAK_DEV_ENV)
 DEVFLAGS := $(if $(DEV),-DSSAK_DEV,)
-HIPFLAGS := $(DEVFLAGS) $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-atomic-optimizer-strategy=None
+HIPFLAGS := $(DEVFLAGS) $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-lambda-capture -Iinclude -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-atomic-optimizer-strategy=None
 SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%,$(OBJ)/%.o,$(SRCS))
 

@@ -184,6 +184,9 @@ typedef struct {
                  loads its B fragments from this copy straight into registers and B never enters LDS (the LDS form is bound by
                  LDS read bandwidth; N = 768 products of the train step run 5-25 % faster); otherwise it is ignored and B is
                  read.  Both must describe the same matrix: results are bit-identical either way.  Not with B batch strides. */
+  int plan_tile; /* 0 (default): the library's cost model picks kernel, tile height and split.  256 / 192 / 128: run the product
+                 on the persistent 256-column-tile kernels with this tile height whenever it qualifies for them (M, N >= 256,
+                 whole 16-byte chunks) -- for tests and tuning; results do not depend on it beyond the summation order. */
 } ssak_gemm_desc;
 /* Fragment-ordered copy of a B operand ([N, K] K-contiguous, or [K, N] with b_kmajor; ldb as in the descriptor):
  * out[(cb * nkt + kt)][j][kk][lane][8] = B(n = 64 cb + 16 j + (lane & 15), k = 64 kt + 32 kk + 8 (lane >> 4) + e), zeros
@@ -368,11 +371,18 @@ int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begi
  *                              the bf16 size of the layers' matrices).  OFF by default: with the operands warm the B-direct
  *                              form is 5-25 % faster on the N = 768 products, but in the train step a layer's weights are read
  *                              once per step -- from HBM -- and the gain is gone (3 591 -> 3 664 us per step for the six
- *                              products, + 160 us for the copies: profiles/r03_ab_fragments.log). */
+ *                              products, + 160 us for the copies: profiles/r03_ab_fragments.log);
+ * SSAK_W2V2_OPT_TRANSPOSED_WEIGHTS  1 (default) / 0: every TRAINING forward makes TRANSPOSED bf16 copies of the kept encoder layers'
+ *                              four projection matrices (one batched launch after the optimizer's event, ~310 MB of traffic for
+ *                              wav2vec2-base) and the backward's input-gradient products dX = dY W read them as a K-contiguous
+ *                              B operand -- the layout of the four-wave GEMM (gemm_p4.hip) -- instead of the weight itself
+ *                              K-major.  Same products, summation order aside; engine-owned memory (the bf16 size of the
+ *                              layers' matrices).  Used when hidden and intermediate sizes are multiples of 256. */
 #define SSAK_W2V2_OPT_DYNAMIC_TILES 1
 #define SSAK_W2V2_OPT_ATTENTION_BWD 2
 #define SSAK_W2V2_OPT_POSCONV_DIRECT 3
 #define SSAK_W2V2_OPT_FRAGMENT_WEIGHTS 4
+#define SSAK_W2V2_OPT_TRANSPOSED_WEIGHTS 5
 int ssak_w2v2_set_option(ssak_w2v2* h, int option, int value);
 /* The gradient ranges ssak_w2v2_backward announces, in announcement order, from the configuration alone (host arithmetic, no
  * device): head matrix, one range per encoder layer from the last to the first (a layer's q|k|v|out|ffn matrices are

@@ -730,12 +730,15 @@ struct GemmPlan {
   double cost;
 };
 int g_env_p8 = -2, g_env_p8_bm = 0;
+bool g_no_p4 = false;  // development switch SSAK_GEMM_NO_P4: keep everything on the 8-wave kernel
 GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
   if (g_env_p8 == -2) {
     const char* v = SSAK_DEV_ENV("SSAK_GEMM_P8");  // development switches: 0 = never, 1 = whenever it applies
     g_env_p8 = v ? atoi(v) : -1;
     v = SSAK_DEV_ENV("SSAK_GEMM_P8_BM");
     g_env_p8_bm = v ? atoi(v) : 0;
+    v = SSAK_DEV_ENV("SSAK_GEMM_NO_P4");
+    g_no_p4 = v && v[0] == '1';
   }
   const int nkt = ssak_cdiv(d->K, BK);
   const long nz = (long)d->nb1 * d->nb2;
@@ -749,8 +752,9 @@ GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
   // (the feed-forward epilogue pair exists on the persistent kernel only for the layouts the encoder uses: other layouts take
   // the 128 x 128 kernels, whose LDS-staged epilogue handles every mode)
   const bool p8_layout_ok = (d->epilogue != SSAK_EPI_GELU_SAVE_GRAD || (!d->a_kmajor && !d->b_kmajor)) &&
-                            (d->epilogue != SSAK_EPI_MUL_AUX || (!d->a_kmajor && d->b_kmajor));
+                            (d->epilogue != SSAK_EPI_MUL_AUX || !d->a_kmajor);
   const bool p8_ok = dma && d->M >= 256 && d->N >= 256 && g_env_p8 != 0 && p8_layout_ok;
+  if (p8_ok && (d->plan_tile == 256 || d->plan_tile == 192 || d->plan_tile == 128)) return GemmPlan{true, d->plan_tile, s_lo, 0.0};  // caller's choice
   GemmPlan best_def{false, 0, s_lo, 1e30}, best_p8{true, 256, s_lo, 1e30};
   for (int s = s_lo; s <= s_hi; ++s) {
     if (d->split_k == 0 && s > 1 && (size_t)s * nz * (size_t)d->M * d->N * sizeof(float) > workspace_bytes) break;
@@ -935,6 +939,8 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
       p.B = (const bf16*)d->b_fragments;
       p.ext_b = (uint32_t)k_gemm_fragment_b_bytes(d->N, d->K);
       rc = ssak_gemm_p8bd_launch(&p, p8_bm, st);
+    } else if (!g_no_p4 && ssak_gemm_p4_supports(&p, p8_bm, d->a_kmajor, d->b_kmajor)) {
+      rc = ssak_gemm_p4_launch(&p, p8_bm, d->b_kmajor, st);
     } else {
       rc = ssak_gemm_p8_launch(&p, p8_bm, d->a_kmajor, d->b_kmajor, st);
     }

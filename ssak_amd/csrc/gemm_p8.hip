@@ -951,7 +951,8 @@ int dispatch_p8(const GemmParams& p, int a_km, int b_km, hipStream_t st) {
   }
   if (p.epilogue == SSAK_EPI_MUL_AUX) {
     if (!a_km && b_km) return launch_p8<MH, false, true, SSAK_EPI_MUL_AUX>(p, st);
-    ssak_set_error("gemm_p8: MUL_AUX is built for a K-contiguous A and a K-major B");
+    if (!a_km && !b_km) return launch_p8<MH, false, false, SSAK_EPI_MUL_AUX>(p, st);  // B = a transposed weight copy
+    ssak_set_error("gemm_p8: MUL_AUX is built for a K-contiguous A");
     return SSAK_ERR_INVALID;
   }
   // lean forms of the common modes (gemm_common.h): no dropout, no column sums, no split-K slabs

@@ -180,6 +180,12 @@ int k_adamw(float* p, const float* g, float* m, float* v, bf16* shadow, long n, 
 // gemm_p8.hip: (256|192|128)x256-tile phase-interleaved GEMM; `params` is gemm_common.h's GemmParams with
 // tiles_m / tiles_n counted for bm x 256 tiles
 int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st);
+// transpose.hip: dst[i] [C][R] = src[i] [R][C]^T, n matrices in one launch
+int k_transpose_bf16_batched(int n, const bf16* const* src, bf16* const* dst, const int* R, const int* C, hipStream_t st);
+
+// gemm_p4.hip: the same tiles with four waves and a hand-scheduled main loop (K-contiguous A, K % 128 == 0, N % 256 == 0, static tile order)
+bool ssak_gemm_p4_supports(const void* params, int bm, int a_km, int b_km);
+int ssak_gemm_p4_launch(const void* params, int bm, int b_km, hipStream_t st);
 // B-direct form: params->B = the fragment-ordered copy (k_gemm_fragment_b_batched), params->ext_b its bytes
 int ssak_gemm_p8bd_launch(const void* params, int bm, hipStream_t st);
 size_t k_gemm_fragment_b_bytes(int N, int K);

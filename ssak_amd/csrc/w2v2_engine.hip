@@ -139,6 +139,17 @@ struct ssak_w2v2 {
   const bf16* frag(int layer, int which) const {
     return (wfrag_valid && wfrag_use[which] && keep[layer]) ? wfrag + (size_t)layer * wfrag_layer + wfrag_off[which] : nullptr;
   }
+  // Transposed copies of the layers' projection matrices (qkv^T [H][3H] | out^T [H][H] | ffn-up^T [H][I] | ffn-down^T [I][H]):
+  // the B operand of the backward's input-gradient products, K-contiguous (SSAK_W2V2_OPT_TRANSPOSED_WEIGHTS).  Engine-owned,
+  // allocated by the first training forward, refreshed by every training forward for the layers it keeps.
+  int transposed_weights = 1;
+  bf16* wtr = nullptr;
+  size_t wtr_layer = 0;
+  size_t wtr_off[4] = {0};
+  bool wtr_valid = false;
+  const bf16* wt(int layer, int which) const {
+    return (wtr_valid && keep[layer]) ? wtr + (size_t)layer * wtr_layer + wtr_off[which] : nullptr;
+  }
 };
 
 namespace {
@@ -493,6 +504,8 @@ struct Gemm {
     d.b_kmajor = km;
     return *this;
   }
+  // B of an input-gradient product dX = dY W: the transposed copy of W (K-contiguous) when there is one, else W itself K-major
+  Gemm& b_wt(const void* wt, long ld_t, const void* w, long ld_w) { return wt ? b(wt, ld_t, false) : b(w, ld_w, true); }
   Gemm& c(void* p, long ld, bool f32 = false) {
     C = p;
     d.ldc = ld;
@@ -696,6 +709,38 @@ int refresh_weight_fragments(ssak_w2v2* e, int M, const uint8_t* layer_keep, hip
   return SSAK_OK;
 }
 
+// qkv | out | ffn-up | ffn-down, each [rows = out features][cols = in features] in the shadow -> [in][out]
+int refresh_weight_transposes(ssak_w2v2* e, const uint8_t* layer_keep, hipStream_t st) {
+  const ssak_w2v2_config& c = e->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size, L = c.num_layers;
+  const int rows[4] = {3 * H, H, I, H}, cols[4] = {H, H, H, I};
+  long LayerP::*const w[4] = {&LayerP::wqkv, &LayerP::wo, &LayerP::w1, &LayerP::w2};
+  if (!e->wtr) {
+    size_t off = 0;
+    for (int i = 0; i < 4; ++i) {
+      e->wtr_off[i] = off;
+      off += (size_t)rows[i] * cols[i];
+    }
+    e->wtr_layer = off;
+    SSAK_HIP(hipMalloc((void**)&e->wtr, (size_t)L * off * sizeof(bf16)));
+  }
+  std::vector<const bf16*> src;
+  std::vector<bf16*> dst;
+  std::vector<int> R, Cc;
+  for (int l = 0; l < L; ++l) {
+    if (layer_keep && !layer_keep[l]) continue;
+    for (int i = 0; i < 4; ++i) {
+      src.push_back(e->W + e->lp[l].*(w[i]));
+      dst.push_back(e->wtr + (size_t)l * e->wtr_layer + e->wtr_off[i]);
+      R.push_back(rows[i]);
+      Cc.push_back(cols[i]);
+    }
+  }
+  if (!src.empty()) TRY(k_transpose_bf16_batched((int)src.size(), src.data(), dst.data(), R.data(), Cc.data(), st));
+  e->wtr_valid = true;
+  return SSAK_OK;
+}
+
 }  // namespace
 
 // =================================================================================================== C ABI
@@ -740,6 +785,7 @@ extern "C" void ssak_w2v2_destroy(ssak_w2v2* e) {
   if (e->pc_wb) (void)hipFree(e->pc_wb);
   if (e->pc_wf_frag) (void)hipFree(e->pc_wf_frag);
   if (e->wfrag) (void)hipFree(e->wfrag);
+  if (e->wtr) (void)hipFree(e->wtr);
   if (e->pc_wb_frag) (void)hipFree(e->pc_wb_frag);
   if (e->pc_norms) (void)hipFree(e->pc_norms);
   delete e;
@@ -772,6 +818,7 @@ extern "C" int ssak_w2v2_bind(ssak_w2v2* e, float* params, float* grads, void* s
   e->G = grads;
   e->W = (bf16*)shadow_bf16;
   e->wfrag_valid = false;
+  e->wtr_valid = false;
   return SSAK_OK;
 }
 
@@ -786,6 +833,8 @@ extern "C" int ssak_w2v2_set_option(ssak_w2v2* e, int option, int value) {
     e->posconv_direct = value ? 1 : 0;
   } else if (option == SSAK_W2V2_OPT_FRAGMENT_WEIGHTS) {
     e->fragment_weights = value ? 1 : 0;
+  } else if (option == SSAK_W2V2_OPT_TRANSPOSED_WEIGHTS) {
+    e->transposed_weights = value ? 1 : 0;
   } else {
     ssak_set_error("w2v2_set_option: unknown option %d", option);
     return SSAK_ERR_INVALID;
@@ -1074,6 +1123,11 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
     // fragment-ordered weights of the layers that will run, for the products that take the B-direct GEMM form (the optimizer's
     // event has been waited for above: the shadow is final)
     if (tr && e->fragment_weights) TRY(refresh_weight_fragments(e, M, layer_keep, st));
+  }
+  e->wtr_valid = false;
+  if constexpr (!EXACT) {
+    // transposed weights for the backward's input-gradient products (the four-wave GEMM wants both operands K-contiguous)
+    if (tr && e->transposed_weights && c.hidden_size % 256 == 0 && c.intermediate_size % 256 == 0) TRY(refresh_weight_transposes(e, layer_keep, st));
   }
   e->hres.assign(c.num_layers + 1, p.h1);
   const float scale = 1.f / sqrtf((float)hd);
@@ -1385,13 +1439,13 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     // products always read buffers of this layer's set, never the rotating residual-stream buffers)
     const AT* dy2 = dY;
     TRY(wq_push(GemmX<EXACT>(H, I, M).a(dy2, H, true).b(BF(lb.f1), I, true).c(Gd + L.w2, I, true), set));  // (b2's gradient: summed by the LN backward)
-    TRY(GemmX<EXACT>(M, I, H).a(dy2, H).b(W + L.w2, I, true).c(dI, I)
+    TRY(GemmX<EXACT>(M, I, H).a(dy2, H).b_wt(EXACT ? nullptr : e->wt(l, 3), H, W + L.w2, I).c(dI, I)
             .epi(SSAK_EPI_MUL_AUX, BF(lb.f1pre))  // the forward saved the whole factor (GELU' and the dropout mask) as 8-bit codes
             .drop(c.activation_dropout, ds_act(l), seed)  // (which 1 / (1 - p) the codes decode with; no mask is drawn here)
             .colsum(Gd + L.b1).run(st, ffn_part, ffn_part_floats * sizeof(float)));  // b1's gradient = column sums of dI, taken in the epilogue
     TRY(wq_push(GemmX<EXACT>(I, H, M).a(dI, I, true).b(BF(lb.x1), H, true).c(Gd + L.w1, H, true), set));
     AT* dX = BF(p.dB);
-    TRY(GemmX<EXACT>(M, H, I).a(dI, I).b(W + L.w1, H, true).bfrag(e->frag(l, 5)).c(dX, H).run(st));
+    TRY(GemmX<EXACT>(M, H, I).a(dI, I).b_wt(EXACT ? nullptr : e->wt(l, 2), I, W + L.w1, H).bfrag(e->wt(l, 2) ? nullptr : e->frag(l, 5)).c(dX, H).run(st));
     AT* dR1;
     if (!stable) {
       // layer_norm backward: r1 = x + drop(attn_out); incoming = dR (residual of r2) + dX
@@ -1407,7 +1461,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     const AT* dy1 = dY1;
     TRY(wq_push(GemmX<EXACT>(H, H, M).a(dy1, H, true).b(BF(lb.ctx), H, true).c(Gd + L.wo, H, true), set));  // (bo's gradient: summed by the LN backward)
     AT* dctx = free_buf(dR1, dX, nullptr);
-    TRY(GemmX<EXACT>(M, H, H).a(dy1, H).b(W + L.wo, H, true).bfrag(e->frag(l, 4)).c(dctx, H).run(st));
+    TRY(GemmX<EXACT>(M, H, H).a(dy1, H).b_wt(EXACT ? nullptr : e->wt(l, 1), H, W + L.wo, H).bfrag(e->wt(l, 1) ? nullptr : e->frag(l, 4)).c(dctx, H).run(st));
     // attention backward per (utterance, head)
     AT* qkv = BF(lb.qkv);
     AT* dqkv = BF(p.dqkvb[set]);
@@ -1429,7 +1483,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     }
     TRY(wq_push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true), set));
     TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
-    TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b(W + L.wqkv, H, true).bfrag(e->frag(l, 3)).c(dX, H).run(st));
+    TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b_wt(EXACT ? nullptr : e->wt(l, 0), 3 * H, W + L.wqkv, H).bfrag(e->wt(l, 0) ? nullptr : e->frag(l, 3)).c(dX, H).run(st));
     wq.ann_off[wq.n_ann] = L.wqkv;
     wq.ann_last[wq.n_ann++] = wq.pushed - 1;  // announced once the qkv product -- the layer's last -- has been launched
     ++wq.layers;

@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
                 ("sc2", C.c_long), ("alpha", C.c_float), ("epilogue", C.c_int), ("out_f32", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
                 ("drop_seed", C.c_uint64), ("bias_s2", C.c_long), ("pads_are_zero", C.c_int), ("colsum", C.c_int),
-                ("dynamic_tiles", C.c_int), ("b_fragments", C.c_void_p)]
+                ("dynamic_tiles", C.c_int), ("b_fragments", C.c_void_p), ("plan_tile", C.c_int)]
 
 
 class W2V2Config(C.Structure):
@@ -260,13 +260,13 @@ def ctc_wer(hyp_ids: torch.Tensor, hyp_lens: torch.Tensor, labels: torch.Tensor,
 def gemm(A, B, C_out, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, nb1=1, nb2=1,
          sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha=1.0, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
          accumulate=False, split_k=1, drop_p=0.0, drop_stream=0, drop_seed=0, pads_are_zero=False, colsum_out=None,
-         dynamic_tiles=False, b_fragments=None):
+         dynamic_tiles=False, b_fragments=None, plan_tile=0):
     """Raw descriptor-level GEMM on device tensors (see ``ssak_gemm_desc`` in include/ssak_hip.h).  ``b_fragments``: the
     copy of B made by :func:`gemm_fragment_b` (used when the library picks the B-direct kernel, ignored otherwise)."""
     d = GemmDesc(M, N, K, int(a_kmajor), int(b_kmajor), lda, ldb, ldc, nb1, nb2, sa[0], sa[1], sb[0], sb[1], sc[0],
                  sc[1], float(alpha), epilogue, int(C_out.dtype == torch.float32), int(accumulate), split_k, float(drop_p),
                  drop_stream, drop_seed, 0, int(pads_are_zero), int(colsum_out is not None), int(dynamic_tiles),
-                 ptr(b_fragments))
+                 ptr(b_fragments), int(plan_tile))
     n_slabs = split_k if split_k > 0 else max(1, min(32, ((K + 63) // 64) // 4))  # 0 = library-sized split
     ws = _ws(n_slabs * nb1 * nb2 * M * N * 4, A.device) if n_slabs > 1 else None
     if colsum_out is not None:
@@ -361,7 +361,7 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
 
 
 ATTN_BWD_DEFAULT, ATTN_BWD_TWO_KERNEL, ATTN_BWD_FUSED = 0, 1, 2
-W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD, W2V2_OPT_POSCONV_DIRECT, W2V2_OPT_FRAGMENT_WEIGHTS = 1, 2, 3, 4
+W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD, W2V2_OPT_POSCONV_DIRECT, W2V2_OPT_FRAGMENT_WEIGHTS, W2V2_OPT_TRANSPOSED_WEIGHTS = 1, 2, 3, 4, 5
 
 
 def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0,

@@ -1,0 +1,108 @@
+"""The four-wave hand-scheduled GEMM (ssak_amd/csrc/gemm_p4.hip) against an fp32 matmul: bit-exact on integer-valued operands
+(every partial sum is exact in fp32, so ANY summation order must give the same bits -- a fragment map, a swizzle, a stale LDS
+slot or a mis-counted wait cannot).  Every case also checks that the product really ran on gemm_p4_kernel (the dispatcher
+falls back to the eight-wave kernel silently otherwise).  Math replaced: the Linear layers of Wav2Vec2FeedForward /
+Wav2Vec2Attention reached from ssak/train/transformers/wav2vec_train.py:415."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ssak_amd.hip as h
+    return h
+
+
+def _ran_on_p4(hip, fn):
+    hip.prof_enable(1)
+    hip.prof_collect()
+    fn()
+    torch.cuda.synchronize()
+    hip.prof_enable(0)
+    names = [e[0] for e in hip.prof_collect() if e[1] > 0]
+    assert any(n.startswith("gemm_p4_kernel") for n in names), names
+    return names
+
+
+def _operands(M, N, K, seed, lo=-2, hi=3, nb=1):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randint(lo, hi, (nb * M, K), generator=g).to(torch.bfloat16)
+    W = torch.randint(lo, hi, (N, K), generator=g).to(torch.bfloat16)
+    return A, W
+
+
+# (M, N, K, tile height; 0 = the library's choice): one tile with a row tail; the train step's products as the library plans them --
+# the 192-row form in one round, three rounds of 256-row tiles with every workgroup re-priming (756 tiles on 256 CUs) and a last
+# tile row of 96 valid rows --; deep K; K = 256 (the shortest pipeline: no steady-state K tile at all); every tile height with
+# row tails that leave whole waves without rows
+SHAPES = [(300, 256, 256, 256), (15968, 768, 768, 0), (15968, 3072, 768, 0), (4000, 768, 3072, 192), (8193, 512, 256, 128),
+          (3077, 1024, 1024, 256), (15968, 2304, 768, 0), (70000, 256, 256, 128), (33000, 512, 384, 192), (257, 256, 512, 128)]
+
+
+@pytest.mark.parametrize("M,N,K,tile", SHAPES)
+def test_p4_plain_bf16_bit_exact(hip, M, N, K, tile):
+    A, W = _operands(M, N, K, M + N + K)
+    bias = torch.randint(-4, 5, (N,), generator=torch.Generator().manual_seed(1)).float()
+    ref = (A.float() @ W.float().T + bias).to(torch.bfloat16)
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16).cuda()
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    _ran_on_p4(hip, lambda: hip.gemm(Ad, Wd, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, plan_tile=tile))
+    assert torch.equal(C.cpu(), ref), (C.cpu().float() - ref.float()).abs().max()
+    # the same launch again and again: a persistent workgroup's hand-off between output tiles must not depend on what the
+    # previous launch left in LDS / in flight
+    for _ in range(3):
+        C.fill_(float("nan"))
+        hip.gemm(Ad, Wd, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, plan_tile=tile)
+        assert torch.equal(C.cpu(), ref)
+
+
+def test_p4_fp32_out_alpha_batches(hip):
+    """General epilogue form: fp32 output, alpha, accumulate, a batch of 3 operand slices (one weight)."""
+    M, N, K, nb = 1100, 512, 384, 3
+    A, W = _operands(M, N, K, 7, nb=nb)
+    ref = (A.float().view(nb, M, K) @ W.float().T) * 0.5
+    C = torch.ones(nb, M, N, dtype=torch.float32).cuda()
+    Ad, Wd = A.cuda(), W.cuda()
+    _ran_on_p4(hip, lambda: hip.gemm(Ad, Wd, C, M, N, K, lda=K, ldb=K, ldc=N, nb1=nb, sa=(M * K, 0), sc=(M * N, 0), alpha=0.5,
+                                     accumulate=True, plan_tile=192))
+    assert torch.equal(C.cpu(), ref + 1.0)
+
+
+def test_p4_toeplitz_rows(hip):
+    """Overlapping A rows (channels-last Conv1d as a GEMM: lda < K) with K = 2 * 512 (the k = 2 layers of the conv stack)."""
+    g = torch.Generator().manual_seed(3)
+    Bn, Tin, Cc, Co, k, s = 2, 2001, 512, 512, 2, 2
+    Tout = (Tin - k) // s + 1
+    x = torch.randint(-2, 3, (Bn, Tin, Cc), generator=g).to(torch.bfloat16)
+    w = torch.randint(-1, 2, (Co, Cc, k), generator=g).to(torch.bfloat16)
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), stride=s).transpose(1, 2)
+    wk = w.permute(0, 2, 1).contiguous().view(Co, k * Cc)
+    y = torch.empty(Bn, Tout, Co, dtype=torch.float32).cuda()
+    xd, wd = x.cuda(), wk.cuda()
+    _ran_on_p4(hip, lambda: hip.gemm(xd, wd, y, Tout, Co, k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Co, nb1=Bn, sa=(Tin * Cc, 0), sc=(Tout * Co, 0), plan_tile=256))
+    assert torch.equal(y.cpu(), ref)
+
+
+def test_p4_gelu_save_grad_matches_the_eight_wave_contract(hip):
+    """Feed-forward up-projection form (bias + GELU + dropout, 8-bit gelu' factor side output) on random data against an fp32
+    reference of the same arithmetic: the epilogue code is shared with the eight-wave kernel, this checks that the four-wave
+    kernel hands it the right accumulators, bias slices and coordinates (two 64-column halves per wave)."""
+    M, N, K = 15968, 3072, 768
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16).cuda()
+    fac = torch.zeros(M, N, dtype=torch.uint8).cuda()
+    _ran_on_p4(hip, lambda: hip.gemm(A, W, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, epilogue=hip.EPI_GELU_SAVE_GRAD, aux_out=fac))
+    pre = A.float() @ W.float().T + bias
+    ref = torch.nn.functional.gelu(pre)
+    err = (C.float() - ref).abs().max().item()
+    assert err < 3e-2, err
+    x = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    f = (fac.float() - 26.0) * (1.26 / 254.0)
+    ferr = (f - x.grad).abs().max().item()
+    assert ferr < 1.2e-2, ferr
