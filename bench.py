@@ -55,10 +55,11 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("SSAK_CPU_THREADS", "64"))))
 
 
-def cpu_baseline(budget_s: float = 30.0):
+def cpu_baseline(budget_s: float = 75.0, min_timed: int = 5):
     """The CPU restatement (oracle: eager torch fp32 on all host cores as ssak/utils/env.py:86-90 does, gradient checkpointing
     on as wav2vec_train.py:329 enables it) timed on a bounded sample of the same workload, SURVEY.md section 8d's protocol
-    scaled to ~30 s: B=8, one warm-up step, then timed full train steps (median) within the budget."""
+    scaled to about a minute: B=8, one warm-up step, then at least `min_timed` timed full train steps (more while the budget
+    lasts, at most 10); min / median / max are reported."""
     from oracle import w2v2_ref as R
     from ssak_amd.synth import synth_batch
     cores = host_cores()
@@ -73,7 +74,7 @@ def cpu_baseline(budget_s: float = 30.0):
     rs = np.random.RandomState(0)
     times = []
     t_all = time.time()
-    while len(times) < 11 and (len(times) < 2 or (time.time() - t_all) + times[-1] < budget_s):
+    while len(times) < 11 and (len(times) < 1 + min_timed or (time.time() - t_all) + times[-1] < budget_s):
         t0 = time.time()
         mask = torch.tensor(R.compute_mask_indices((B, 499), cfg.mask_time_prob, cfg.mask_time_length, None, 2, rng=rs))
         keep = rs.rand(cfg.num_hidden_layers) >= cfg.layerdrop
@@ -86,8 +87,10 @@ def cpu_baseline(budget_s: float = 30.0):
     timed = sorted(times[1:])
     med = timed[len(timed) // 2]
     return {"value": round(B / med, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
+            "min": round(B / timed[-1], 4), "median": round(B / med, 4), "max": round(B / timed[0], 4), "timed_steps": len(timed),
             "sample": f"1 warm-up + {len(timed)} timed full train steps (fwd + bwd with per-layer gradient checkpointing + clip + AdamW) "
-                      f"of oracle/w2v2_ref.py, eager torch fp32, B={B} x 10 s, median step {med:.2f} s"}
+                      f"of oracle/w2v2_ref.py, eager torch fp32, B={B} x 10 s, median step {med:.2f} s "
+                      f"(fastest {timed[0]:.2f} s, slowest {timed[-1]:.2f} s)"}
 
 
 def build_stamp():
@@ -128,7 +131,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (Whisper-small, XLSR-large bucketed, ingest)")
+    ap.add_argument("--long-steps", type=int, default=100, help="extra untimed-by-the-driver run after the timed region (0 = skip)")
     args = ap.parse_args()
+    build = build_stamp()  # before anything touches the GPU: it spawns git (no child processes under a profiler's preload later)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -198,9 +204,14 @@ def main():
 
     # Roofline leg: HIP events around GEMM launches, recorded by the library on the launch stream.  Bracketing EVERY GEMM of
     # a step costs ~3 % of it (an event pair keeps consecutive kernels from overlapping head to tail), so the survey of all
-    # GEMM instantiations runs inside the last warm-up steps and the timed region brackets only the dominant instantiation.
-    n_survey = min(2, args.warmup)
-    for _ in range(args.warmup - n_survey):
+    # kernel classes runs inside two of the warm-up steps and the timed region brackets only the dominant slot.
+    # Order of the W warm-up steps: [one cold step when W >= 4] -> the survey steps -> the remaining plain steps.  The plain steps
+    # come LAST, right before the timed region: reading the survey's events back takes the host a while, the GPU idles
+    # meanwhile and drops its clocks, and a timed region that starts from that state pays 20-50 ms of ramp-up (measured: 20
+    # timed steps read 16.9-17.9 ms per step right after the read-back, 14.9-15.0 ms with two plain steps in between).
+    n_cold = 1 if args.warmup >= 4 else 0
+    n_survey = min(2, args.warmup - n_cold)
+    for _ in range(n_cold):
         trainer.train_step(waves, None, labels)
     sync()
     survey, dom = None, -1
@@ -222,13 +233,34 @@ def main():
     hip.prof_enable(2 + dom if dom >= 0 else 1)
     if os.environ.get("SSAK_BENCH_NO_PROF") == "1":  # development switch: cost of the events
         hip.prof_enable(0)
-    hip.prof_collect()
+    for _ in range(args.warmup - n_cold - n_survey):
+        trainer.train_step(waves, None, labels)
+    sync()
+    hip.prof_collect()  # (drops what the plain warm-up steps recorded for the dominant slot)
+    # no Python garbage collection inside the timed region: a generation-2 pass over the survey's objects stopped the host for
+    # ~40 ms in the first timed step of every other run (SSAK_BENCH_STEP_TRACE=1: host issue 41.9 ms, device 57.1 ms for that step)
+    import gc
+    gc.collect()
+    gc.disable()
+    sync()
     fw0, kl0 = model.train_forwards, model.kept_layers
+    trace = [] if os.environ.get("SSAK_BENCH_STEP_TRACE") == "1" else None  # development switch: per-step device times on stderr
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if trace is not None:
+            trace.append((torch.cuda.Event(enable_timing=True), time.perf_counter()))
+            trace[-1][0].record()
         loss = trainer.train_step(waves, None, labels)
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if trace:
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        torch.cuda.synchronize()
+        evs = [e for e, _ in trace] + [end]
+        print("per-step device ms:", " ".join(f"{evs[i].elapsed_time(evs[i + 1]):.1f}" for i in range(len(trace))), file=sys.stderr)
+        print("host issue ms:", " ".join(f"{(trace[i + 1][1] - trace[i][1]) * 1e3:.1f}" for i in range(len(trace) - 1)), file=sys.stderr)
     hip.prof_enable(0)
     prof = hip.prof_collect()
     kept_avg = (model.kept_layers - kl0) / max(1, model.train_forwards - fw0)
@@ -245,11 +277,26 @@ def main():
         trainer.train_step(waves, None, labels)
         stalls.append(trainer.stall_ms())
     sync()
+    # a longer run of the same step after the driver's timed region (profiler markers off): box noise and LayerDrop's
+    # step-to-step work differences average out over it
+    long_run = None
+    if args.long_steps > 0:
+        hip.prof_enable(0)
+        t1 = time.perf_counter()
+        for _ in range(args.long_steps):
+            trainer.train_step(waves, None, labels)
+        sync()
+        dl = time.perf_counter() - t1
+        if world > 1:
+            tl = torch.tensor([dl], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tl, op=torch.distributed.ReduceOp.MAX)
+            dl = float(tl.item())
+        long_run = {"steps": args.long_steps, "value": round(B * world * args.long_steps / dl, 2), "ms_per_step": round(dl / args.long_steps * 1e3, 3),
+                    "note": "same step, run after the timed region, no event markers"}
 
     if rank == 0:
         utts = B * world * args.steps
         value = utts / dt
-        build = build_stamp()
 
         def entry(p, steps):
             name, launches, ms, work, bound = p
@@ -297,7 +344,8 @@ def main():
         out = {"metric": "utterances/sec (16 kHz, 10 s) Wav2Vec2-base CTC train step", "value": round(value, 2),
                "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic, HBM-resident batch (the timed loop re-feeds one device batch; the "
+               "file -> device path is measured beside it: ingest)",
                "config": {"workload": "Wav2Vec2-base CTC fine-tune step, bf16, synthetic 10 s @16 kHz utterances "
                                       "(BASELINE.json configs[1]; DP over xGMI for n_gpus>1 = configs[2])",
                           "per_gpu_batch": B, "global_batch": B * world, "samples_per_utt": T, "frames": model.num_frames(T),
@@ -318,6 +366,26 @@ def main():
                                "grad_dtype": trainer.grad_exchange_dtype,
                                "bucket_bytes": [c * (2 if trainer.grad_exchange_dtype == "bf16" else 4) for _, c in trainer.bucket_log],
                                "payload_bytes_per_step": sum(c for _, c in trainer.bucket_log) * (2 if trainer.grad_exchange_dtype == "bf16" else 4)}
+        out["long_run"] = long_run
+        if world == 1 and not args.no_secondary:
+            # BASELINE.json configs[3] / configs[4] and the ingest path on the same clock as the headline (their models are built after
+            # the headline's timed region; its buffers are released first)
+            del trainer, opt, model
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import side_benches
+            sec = []
+            for fn, kw in ((side_benches.whisper_step, dict(B=8, steps=10)), (side_benches.xlsr_bucketed, dict(B=16, N=320))):
+                try:
+                    sec.append(fn(**kw))
+                except Exception as e:  # a secondary line must not take the headline down with it
+                    sec.append({"workload": fn.__name__, "error": repr(e)})
+                torch.cuda.empty_cache()
+            out["secondary"] = sec
+            try:
+                out["ingest"] = side_benches.ingest_rate(N=256)
+            except Exception as e:
+                out["ingest"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

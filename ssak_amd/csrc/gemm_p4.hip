@@ -39,11 +39,8 @@
 namespace {
 
 constexpr int P4_THREADS = 256;
-constexpr int P4_OP = 32768;        // one operand of one K tile
-constexpr int P4_BUF = 2 * P4_OP;   // A | B
-constexpr int P4_PIPE = 2 * P4_BUF;
-constexpr int P4_BIAS = 4 * 1024;   // per output-tile parity: 1 KiB per wave (128 fp32 from lanes 0-31; the other lanes' LDS-DMA writes zeros)
-constexpr int P4_LDS = P4_PIPE + 2 * P4_BIAS;
+// LDS: SA stages of A (32 NI rows x 128 B) | two stages of B (256 rows x 128 B) | two bias slots of 1 KiB per wave (128 fp32 from
+// lanes 0-31; the other lanes' LDS-DMA writes zeros)
 
 template <int I>
 using IC = std::integral_constant<int, I>;
@@ -60,30 +57,35 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define P4_MFMA(ACC, FB, FA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(FB), "v"(FA))
 #define P4_MFMA_Z(ACC, FB, FA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(FB), "v"(FA))
 #define P4_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
-// K-major operand: the 16 x 32 fragment is two transposing reads, k-rows +0..3 and +4..7 (2 KiB further down), into the two
-// halves of ONE four-register operand -- which an asm operand cannot name; see the K-major instantiation below
-#define P4_READ_TR(DST, ADDR, OFF) static_assert(!B_KM, "K-major B: fragment reads not built yet")
 
 struct P4Tile {
   int bm0, bn0, z, z1, z2;
+  int k0;  // K tile this output tile's loop starts at (it wraps around): see decode()
 };
 typedef u32x4 Frag;  // 8 bf16 = one MFMA operand
 
-// NI: 16-row groups per wave (tile = 32 NI x 256).  EPI: as gemm_p8_kernel.
-template <int NI, bool B_KM, int EPI>
+// NI: 16-row groups per wave (tile = 32 NI x 256).  SA: LDS stages of the A operand (3 where they fit: the activations are read
+// once, from HBM, and want two K tiles in flight; B -- a weight every row panel re-reads, from L2 / the Infinity Cache -- has 2).
+// EPI: as gemm_p8_kernel.
+template <int NI, int SA, int EPI>
 __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 32 * NI;
-  constexpr int NA = NI, NQ = NA + 8;  // LDS-DMA instructions per wave and K tile: A (32 rows each), then B
+  constexpr int NA = NI, NB = 8;           // LDS-DMA instructions per wave and K tile: A (32 rows each), B
+  constexpr int A_SZ = BM * 128, B_SZ = 32768;
+  constexpr int LDS_B = SA * A_SZ, LDS_BIAS = LDS_B + 2 * B_SZ;
   // epilogues that only store a fixed number of 16-byte rows per 16-row group may leave their stores in flight
   constexpr bool EPI_EARLY = EPI == P8_EPI_PLAIN_BF16 || EPI == P8_EPI_GELU_ONLY || EPI == SSAK_EPI_GELU_SAVE_GRAD;
   constexpr int EPI_STORES = (EPI == SSAK_EPI_GELU_SAVE_GRAD ? 6 : 4) * NI;
+  constexpr int MID_KEEP = SA == 3 ? NA : 0;  // LDS-DMA younger than what a K tile's barrier needs: the A tile staged last
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int per_z = p.tiles_m * p.tiles_n;
   const int ntiles = per_z * p.nz;
-  const int nkt = p.K / BK;  // even, >= 4 (launcher)
+  const int nkt = p.K / BK;  // >= 3 (launcher)
+  // byte offset of the K tile visited at step k (gemm_common.h: kperm_*; identity without a Toeplitz A)
+  const int kpp = p.kperm_p, kpn = p.kperm_n2;
   auto decode = [&](int t) __attribute__((always_inline)) {
     P4Tile c;
     const int id = xcd_remap(t, ntiles);
@@ -93,76 +95,62 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
     c.z2 = zs % p.nb2;
     c.bm0 = rem / p.tiles_n * BM;
     c.bn0 = rem % p.tiles_n * 256;
+    // K ROTATION: row panel r starts its K loop at K tile (7 r) mod nkt and wraps around.  B is a weight that every row panel
+    // streams, from HBM the first time in a train step; with every workgroup on the same K tile at the same moment each K tile
+    // of it is a fresh miss for ALL of them at once, 2 us of latency against the ~1 us a B stage is staged ahead (cold
+    // operands: +10 % on the K >= 2304 products, tools/bench_gemm_cold.py).  Rotated, one workgroup takes the miss and the
+    // others find the lines in L2 / the Infinity Cache.  (The column tiles of a row panel keep one start: they share A.)
+    // fp32 summation order differs per row panel; every panel's own order is fixed, results are deterministic.
+    c.k0 = kpn ? 0 : (rem / p.tiles_n * 7 + zs * 3) % nkt;
     return c;
+  };
+  auto koff_of = [kpp, kpn](int k) __attribute__((always_inline)) {
+    const int kt = k < 2 * kpn ? (k >> 1) + ((k & 1) ? kpp : 0) : k - kpn;
+    return (uint32_t)kt * 128u;
   };
   typedef __attribute__((address_space(3))) char lds_char;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
-  const uint32_t wbase = lds0 + wave * 1024;  // LDS-DMA destination of this wave: + buffer + instruction * 4 KiB
-  // ---- LDS-DMA source offsets.  K-contiguous operand: instruction j of this wave fills rows 32 j + 8 wave + (lane >> 3) (128 B
-  // each); K-major B: k-rows 8 j + 2 wave + (lane >> 5) (512 B each).  One VGPR offset per instruction, constant for the output
-  // tile (the descriptor's range check zero-fills rows beyond the matrix from it); the K tile's offset is scalar.
+  const uint32_t wbase = lds0 + wave * 1024;  // LDS-DMA destination of this wave: + stage + instruction * 4 KiB
+  // ---- LDS-DMA source offsets: instruction j of this wave fills rows 32 j + 8 wave + (lane >> 3) (128 B each, chunk swizzle on
+  // the source side).  One VGPR offset per instruction, constant for the output tile (the descriptor's range check zero-fills
+  // rows beyond the matrix from it); the K tile's offset is scalar (soffset).
   const int drow = 8 * wave + (lane >> 3);
   const int dchunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-  const int bkrow = 2 * wave + (lane >> 5);  // (+ 8 j: bits 0, 1, 3 of the k-row -- the swizzle's inputs -- do not depend on j... bit 3 does)
-  uint32_t vo[NQ];
-  u32x4 ra_v, rb_v;  // descriptors as computed; uni4() right before a K loop hands them to the asm statements in SGPRs
+  uint32_t voa[NA], vob[NB];
+  u32x4 ra_v, rb_v;  // descriptors as computed; uni4() right before use hands them to the asm statements in SGPRs
   uint32_t bias_vo = 0x80000000u;
-  auto uni4 = [](u32x4 v) __attribute__((always_inline)) {
-    return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]), (uint32_t)__builtin_amdgcn_readfirstlane((int)v[1]),
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)v[2]), (uint32_t)__builtin_amdgcn_readfirstlane((int)v[3])};
-  };
   auto make_rsrc = [](const void* ptr, uint32_t bytes) __attribute__((always_inline)) {
     const uint64_t a = (uint64_t)(uintptr_t)ptr;
     return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xffffu,
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
   };
+  auto uni4 = [](u32x4 v) __attribute__((always_inline)) {
+    return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]), (uint32_t)__builtin_amdgcn_readfirstlane((int)v[1]),
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)v[2]), (uint32_t)__builtin_amdgcn_readfirstlane((int)v[3])};
+  };
   const u32x4 rbias = uni4(make_rsrc(p.bias, p.bias ? (uint32_t)((((long)p.nb2 - 1) * p.bias_s2 + p.N) * 4) : 0u));
-  auto setup = [&](const P4Tile& c, bool real) __attribute__((always_inline)) {
+  // (`real` false: no tile to stage -- out of range = zeros into slots nobody reads, no memory traffic)
+  auto setup_a = [&](const P4Tile& c, bool real) __attribute__((always_inline)) {
     ra_v = make_rsrc(p.A + c.z1 * p.sa1 + c.z2 * p.sa2, p.ext_a);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) voa[q] = real ? (uint32_t)(((long)(c.bm0 + 32 * q + drow) * p.lda + dchunk * 8) * 2) : 0x80000000u;
+  };
+  auto setup_b = [&](const P4Tile& c, bool real) __attribute__((always_inline)) {
     rb_v = make_rsrc(p.B + c.z1 * p.sb1 + c.z2 * p.sb2, p.ext_b);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      uint32_t o;
-      if (q < NA) {
-        o = (uint32_t)(((long)(c.bm0 + 32 * q + drow) * p.lda + dchunk * 8) * 2);
-      } else if (!B_KM) {
-        o = (uint32_t)(((long)(c.bn0 + 32 * (q - NA) + drow) * p.ldb + dchunk * 8) * 2);
-      } else {
-        const int kr = 8 * (q - NA) + bkrow;
-        const int ch = (lane & 31) ^ (((kr & 3) | (((kr >> 3) & 1) << 2)) << 1);
-        o = (uint32_t)(((long)kr * p.ldb + c.bn0 + ch * 8) * 2);
-      }
-      vo[q] = real ? o : 0x80000000u;  // no next tile: out of range = zeros into slots nobody reads, no memory traffic
-    }
+    for (int q = 0; q < NB; ++q) vob[q] = real ? (uint32_t)(((long)(c.bn0 + 32 * q + drow) * p.ldb + dchunk * 8) * 2) : 0x80000000u;
     // bias of the wave's 128 columns: lanes 0-31, 16 B each
     bias_vo = (real && lane < 32) ? (uint32_t)((c.z2 * p.bias_s2 + c.bn0 + wc * 128 + 4 * lane) * 4) : 0x80000000u;
   };
-  const uint32_t kstep_b = B_KM ? (uint32_t)(64 * p.ldb * 2) : 128u;  // byte advance of B per K tile
-  // ---- fragment read addresses [buffer][slice]
+  // ---- fragment read addresses inside stage 0 [slice]: row 16 i + lm of this wave's panel, 16-byte chunk 4 slice + lq
   const int lm = lane & 15, lq = lane >> 4;
-  uint32_t fo_a[2][2];
-  uint32_t fo_b[2][B_KM ? 8 : 2];  // K-contiguous: [buffer][slice]; K-major: [buffer][column group j] (slice = + 16 KiB)
+  uint32_t fo_a[2], fo_b[2];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fo_a[b][kk] = lds0 + b * P4_BUF + (wr * 16 * NI + lm) * 128 + (((4 * kk + lq) ^ ((lm >> 1) & 7)) << 4);
-    if (!B_KM) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        fo_b[b][kk] = lds0 + b * P4_BUF + P4_OP + (wc * 128 + lm) * 128 + (((4 * kk + lq) ^ ((lm >> 1) & 7)) << 4);
-    } else {
-      // lane = 16 g + 4 q4 + pp supplies k-row 8 g + q4 (+ 4: second read, + 32: slice 1), columns 16 j + 4 pp .. of the wave's 128
-      const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
-      const int kr = 8 * g + q4;
-      const int sw = ((kr & 3) | (((kr >> 3) & 1) << 2)) << 1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ch = wc * 16 + 2 * j + (pp >> 1);
-        fo_b[b][j] = lds0 + b * P4_BUF + P4_OP + kr * 512 + ((ch ^ sw) << 4) + (pp & 1) * 8;
-      }
-    }
+  for (int kk = 0; kk < 2; ++kk) {
+    fo_a[kk] = lds0 + (wr * 16 * NI + lm) * 128 + (((4 * kk + lq) ^ ((lm >> 1) & 7)) << 4);
+    fo_b[kk] = lds0 + LDS_B + (wc * 128 + lm) * 128 + (((4 * kk + lq) ^ ((lm >> 1) & 7)) << 4);
   }
-  const uint32_t bias_lds0 = lds0 + P4_PIPE + wave * 1024;
+  const uint32_t bias_lds0 = lds0 + LDS_BIAS + wave * 1024;
 
   // one LDS-DMA with its M0 write: the form outside the MFMA stream (prologue)
   auto dma_plain = [](uint32_t dst, uint32_t voff, u32x4 rsrc, uint32_t soff) __attribute__((always_inline)) {
@@ -171,154 +159,183 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
 
   f32x4 acc[2][NI][4];  // [column half][16-row group][16-column group]: a half is what gemm_epilogue_direct takes
   Frag fa0[NI], fb0[8], fa1[NI], fb1[8];
-  uint32_t koff_a = 0, koff_b = 0;  // scalar byte offsets of the K tile being staged
 
-  // ---- one K tile in buffer P.
-  //   ZERO: first K tile of an output tile (slice 0 multiplies into 0).  STAGE: issue the NQ LDS-DMA of the tile two ahead (or of
-  //   the next output tile: the caller has re-pointed vo / koff) into this buffer, BIAS: and the bias slice first.
-  //   READ_NEXT: read set 0 of the following K tile from the other buffer.  mid_keep: vector-memory operations younger than
-  //   the tile that must have landed (the previous epilogue's stores).
-  auto ktile = [&acc, &fa0, &fb0, &fa1, &fb1, &vo, &bias_vo, &koff_a, &koff_b, &fo_a, &fo_b, wbase, kstep_b](
-                   auto par_c, auto zero_c, auto stage_c, auto rn_c, auto bias_c, bool keep_stores, uint32_t bias_dst, const u32x4 ra,
-                   const u32x4 rb, const u32x4 rbias) __attribute__((always_inline)) {
-    constexpr int P = decltype(par_c)::value;
-    constexpr bool ZERO = decltype(zero_c)::value, STAGE = decltype(stage_c)::value, READ_NEXT = decltype(rn_c)::value,
-                   BIAS = decltype(bias_c)::value;
-    const uint32_t wb = wbase + P * P4_BUF;
+  // ---- one K tile.  s_sa / s_sb: byte offsets of the LDS stages holding its A / B (in: this tile's; out: the next tile's);
+  //   a_cur / b_cur: this lane's slice-1 fragment addresses in them (in / out likewise) -- the few scalar and vector
+  //   instructions that advance them sit in free gaps of slice 0, not in a block between two K tiles.
+  //   ZERO: first K tile of an output tile (slice 0 multiplies into 0).  READ_NEXT: read set 0 of the following K tile.
+  //   BIAS: stage the next output tile's bias slice too.  Slice 1 always stages B of the K tile two ahead into this tile's B
+  //   stage and A of the K tile SA ahead into its A stage (the caller has pointed vob / voa / the descriptors / koff at them:
+  //   this or the next output tile).  keep_stores: the previous epilogue's stores are still in flight behind this tile's operands.
+  auto ktile = [&acc, &fa0, &fb0, &fa1, &fb1, &voa, &vob, &bias_vo, &fo_a, &fo_b, wbase](
+                   auto zero_c, auto rn_c, auto bias_c, uint32_t& s_sa, uint32_t& s_sb, uint32_t& a_cur, uint32_t& b_cur, uint32_t koff_a,
+                   uint32_t koff_b, bool keep_stores, uint32_t bias_dst, const u32x4 ra, const u32x4 rb, const u32x4 rbias) __attribute__((always_inline)) {
+    constexpr bool ZERO = decltype(zero_c)::value, READ_NEXT = decltype(rn_c)::value, BIAS = decltype(bias_c)::value;
+    uint32_t n_sa = 0, n_sb = 0, a_nxt = 0, b_nxt = 0, a_cur_n = 0, b_cur_n = 0, wb_a = 0, wb_b = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // set 0 is in registers
     // ---- slice 0
-    static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &fo_a, &fo_b, keep_stores](auto mc) __attribute__((always_inline)) {
+    static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &fo_a, &fo_b, &a_cur, &b_cur, &s_sa, &s_sb, &n_sa, &n_sb, &a_nxt, &b_nxt, &a_cur_n, &b_cur_n,
+                        &wb_a, &wb_b, wbase, keep_stores](auto mc) __attribute__((always_inline)) {
       constexpr int m = decltype(mc)::value, i = m / 8, j = m % 8;
       if constexpr (ZERO) P4_MFMA_Z(acc[j / 4][i][j % 4], fb0[j], fa0[i]);
       else P4_MFMA(acc[j / 4][i][j % 4], fb0[j], fa0[i]);
       if constexpr (m % 2 == 0 && m / 2 < 8 + NI) {
         constexpr int r = m / 2;
-        if constexpr (r == 0) P4_READ(fa1[0], fo_a[P][1], 0);
-        else if constexpr (r <= 8) {
-          if constexpr (B_KM) P4_READ_TR(fb1[r - 1], fo_b[P][r - 1], 16384);
-          else P4_READ(fb1[r - 1], fo_b[P][1], (r - 1) * 2048);
-        } else P4_READ(fa1[r - 8], fo_a[P][1], (r - 8) * 2048);
+        if constexpr (r == 0) P4_READ(fa1[0], a_cur, 0);
+        else if constexpr (r <= 8) P4_READ(fb1[r - 1], b_cur, (r - 1) * 2048);
+        else P4_READ(fa1[r - 8], a_cur, (r - 8) * 2048);
       }
+      // bookkeeping for slice 1 and for the next K tile, one instruction or two per free gap
+      if constexpr (m == 1) n_sa = s_sa + A_SZ == SA * A_SZ ? 0u : s_sa + A_SZ;
+      if constexpr (m == 3) n_sb = s_sb ^ B_SZ;
+      if constexpr (m == 5) a_nxt = fo_a[0] + n_sa;
+      if constexpr (m == 7) b_nxt = fo_b[0] + n_sb;
+      if constexpr (m == 9) a_cur_n = fo_a[1] + n_sa;
+      if constexpr (m == 11) b_cur_n = fo_b[1] + n_sb;
+      if constexpr (m == 13) wb_a = wbase + s_sa;
+      if constexpr (m == 15) wb_b = wbase + LDS_B + s_sb;
       if constexpr (m == 8 * NI - 4) {
-        // my reads of this buffer are done; my share of the next K tile has landed (everything but the previous epilogue's stores)
-        if (keep_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(EPI_STORES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // my reads of these stages are done; my share of the next K tile has landed (everything but the youngest A tile and,
+        // right after an early-staged start, the previous epilogue's stores)
+        if (keep_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(MID_KEEP + EPI_STORES < 63 ? MID_KEEP + EPI_STORES : 63) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(MID_KEEP) : "memory");
       }
       if constexpr (m == 8 * NI - 3) asm volatile("s_barrier" ::: "memory");
     });
-    // ---- slice 1: groups of DS MFMAs: [fragment read | M0 write | LDS-DMA | ...]
-    static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &vo, ra, rb, rbias, &bias_vo, &koff_a, &koff_b, &fo_a, &fo_b, wb, bias_dst](auto mc) __attribute__((always_inline)) {
+    // ---- slice 1: groups of DS MFMAs: [fragment read | M0 write | LDS-DMA | ...]; DMA order: (bias,) B, then A
+    static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &voa, &vob, ra, rb, rbias, &bias_vo, a_nxt, b_nxt, wb_a, wb_b, koff_a, koff_b, bias_dst](
+                           auto mc) __attribute__((always_inline)) {
       constexpr int m = decltype(mc)::value, i = m / 8, j = m % 8;
-      constexpr int DS = (8 * NI / (NQ + (BIAS ? 1 : 0)) < 4) ? 8 * NI / (NQ + (BIAS ? 1 : 0)) : 4;
+      constexpr int NG = NA + NB + (BIAS ? 1 : 0);
+      constexpr int DS = (8 * NI / NG < 4) ? 8 * NI / NG : 4;
       constexpr int g = m / DS, ph = m % DS;
-      constexpr int q = BIAS ? g - 1 : g;  // LDS-DMA of this group (-1: the bias slice)
-      if constexpr (STAGE && ph == 1 && q >= (BIAS ? -1 : 0) && q < NQ) {
+      constexpr int q = BIAS ? g - 1 : g;  // LDS-DMA of this group: -1 the bias slice, 0 .. NB - 1 B, NB .. A
+      if constexpr (ph == 1 && g < NG) {
         if constexpr (q < 0) {
           asm volatile("s_mov_b32 m0, %3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tbuffer_load_dwordx4 %4, %5, 0 offen lds"
                        : "+a"(acc[j / 4][i][j % 4])
                        : "v"(fb1[j]), "v"(fa1[i]), "s"(bias_dst), "v"(bias_vo), "s"(rbias)
                        : "memory");
-        } else {
-          constexpr int imm = q < NA ? q * 4096 : P4_OP + (q - NA) * 4096;
+        } else if constexpr (q < NB) {
           asm volatile("s_add_u32 m0, %3, %4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tbuffer_load_dwordx4 %5, %6, %7 offen lds"
                        : "+a"(acc[j / 4][i][j % 4])
-                       : "v"(fb1[j]), "v"(fa1[i]), "s"(wb), "i"(imm), "v"(vo[q]), "s"(q < NA ? ra : rb), "s"(q < NA ? koff_a : koff_b)
+                       : "v"(fb1[j]), "v"(fa1[i]), "s"(wb_b), "i"(q * 4096), "v"(vob[q]), "s"(rb), "s"(koff_b)
+                       : "memory", "scc");
+        } else {
+          asm volatile("s_add_u32 m0, %3, %4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tbuffer_load_dwordx4 %5, %6, %7 offen lds"
+                       : "+a"(acc[j / 4][i][j % 4])
+                       : "v"(fb1[j]), "v"(fa1[i]), "s"(wb_a), "i"((q - NB) * 4096), "v"(voa[q - NB]), "s"(ra), "s"(koff_a)
                        : "memory", "scc");
         }
       } else {
         P4_MFMA(acc[j / 4][i][j % 4], fb1[j], fa1[i]);
       }
       if constexpr (READ_NEXT) {
-        // fragment reads of the next K tile: one per DS MFMAs in the DMA's free gaps, the rest after the last DMA
-        constexpr int r_dense = m / DS;                       // reads placed so far if one per group
-        constexpr int tail0 = DS * (NQ + (BIAS ? 1 : 0));     // first MFMA after the DMA groups
-        constexpr bool in_groups = m < tail0 && ph == 0 && r_dense < 8 + NI;
-        constexpr int r_tail = (NQ + (BIAS ? 1 : 0)) + (m - tail0);
+        // fragment reads of the next K tile: one per group in the DMA's free gaps, the rest after the last DMA
+        constexpr int tail0 = DS * NG;  // first MFMA after the DMA groups
+        constexpr bool in_groups = m < tail0 && ph == 0 && g < 8 + NI;
+        constexpr int r_tail = NG + (m - tail0);
         constexpr bool in_tail = m >= tail0 && r_tail < 8 + NI;
         if constexpr (in_groups || in_tail) {
-          constexpr int r = in_groups ? r_dense : r_tail;
-          if constexpr (r == 0) P4_READ(fa0[0], fo_a[P ^ 1][0], 0);
-          else if constexpr (r <= 8) {
-            if constexpr (B_KM) P4_READ_TR(fb0[r - 1], fo_b[P ^ 1][r - 1], 0);
-            else P4_READ(fb0[r - 1], fo_b[P ^ 1][0], (r - 1) * 2048);
-          } else P4_READ(fa0[r - 8], fo_a[P ^ 1][0], (r - 8) * 2048);
+          constexpr int r = in_groups ? g : r_tail;
+          if constexpr (r == 0) P4_READ(fa0[0], a_nxt, 0);
+          else if constexpr (r <= 8) P4_READ(fb0[r - 1], b_nxt, (r - 1) * 2048);
+          else P4_READ(fa0[r - 8], a_nxt, (r - 8) * 2048);
         }
       }
     });
-    koff_a += 128;
-    koff_b += kstep_b;
+    s_sa = n_sa;
+    s_sb = n_sb;
+    a_cur = a_cur_n;
+    b_cur = b_cur_n;
   };
   using T = std::true_type;
   using F = std::false_type;
 
   bool primed = false;
-  int par = 0;  // output-tile parity: which bias slot
+  int par = 0;                  // output-tile parity: which bias slot
+  uint32_t s_sa = 0, s_sb = 0;  // byte offsets of the LDS stages of the current K tile's A (cycles through SA stages, across output tiles) / B
   P4Tile cur = decode(min((int)blockIdx.x, ntiles - 1));
   for (int t = blockIdx.x; t < ntiles;) {
     const P4Tile c = cur;
-    const uint32_t bias_lds = bias_lds0 + par * P4_BIAS;
+    const uint32_t bias_lds = bias_lds0 + par * 4096;
     const bool was_primed = primed;
     if (!primed) {
-      setup(c, true);
+      setup_a(c, true);
+      setup_b(c, true);
       const u32x4 ra = uni4(ra_v), rb = uni4(rb_v);
       dma_plain(bias_lds, bias_vo, rbias, 0);
-      static_for<2 * NQ>([&vo, ra, rb, &dma_plain, wbase, kstep_b](auto qq) __attribute__((always_inline)) {
-        constexpr int b = decltype(qq)::value / NQ, q = decltype(qq)::value % NQ;
-        dma_plain(wbase + b * P4_BUF + (q < NA ? q * 4096 : P4_OP + (q - NA) * 4096), vo[q], q < NA ? ra : rb, q < NA ? b * 128u : b * kstep_b);
-      });
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NQ) : "memory");  // bias + K tile 0 (this wave's share)
+      // A0 B0 A1 B1 (A2): the same order and counts the tail of a previous tile leaves in flight
+      uint32_t sa = s_sa, sb = s_sb;
+      for (int k = 0; k < 2; ++k) {
+        static_for<NA>([&voa, ra, &dma_plain, wbase, sa, &koff_of, k, &c, nkt](auto q) __attribute__((always_inline)) { dma_plain(wbase + sa + q * 4096, voa[q], ra, koff_of((k + c.k0) % nkt)); });
+        static_for<NB>([&vob, rb, &dma_plain, wbase, sb, &koff_of, k, &c, nkt](auto q) __attribute__((always_inline)) { dma_plain(wbase + LDS_B + sb + q * 4096, vob[q], rb, koff_of((k + c.k0) % nkt)); });
+        sa = sa + A_SZ == SA * A_SZ ? 0 : sa + A_SZ;
+        sb ^= B_SZ;
+      }
+      if (SA == 3) static_for<NA>([&voa, ra, &dma_plain, wbase, sa, &koff_of, &c, nkt](auto q) __attribute__((always_inline)) { dma_plain(wbase + sa + q * 4096, voa[q], ra, koff_of((2 + c.k0) % nkt)); });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA + NB + (SA == 3 ? NA : 0)) : "memory");  // bias, A0, B0 (this wave's share)
     } else {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NQ + EPI_STORES < 63 ? NQ + EPI_STORES : 63) : "memory");  // everything older than K tile 1 and the stores
+      // everything older than B1, the youngest A tile and the stores: bias, A0, B0 (and A1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NB + NA + EPI_STORES < 63 ? NB + NA + EPI_STORES : 63) : "memory");
     }
     asm volatile("s_barrier" ::: "memory");
-    static_for<8>([&fb0, &fo_b](auto j) __attribute__((always_inline)) {
-      if constexpr (B_KM) P4_READ_TR(fb0[j], fo_b[0][j], 0);
-      else P4_READ(fb0[j], fo_b[0][0], j * 2048);
-    });
-    static_for<NI>([&fa0, &fo_a](auto i) __attribute__((always_inline)) { P4_READ(fa0[i], fo_a[0][0], i * 2048); });
-    koff_a = 256;
-    koff_b = 2 * kstep_b;
     {
-      const u32x4 ra = uni4(ra_v), rb = uni4(rb_v);
-      ktile(IC<0>{}, T{}, T{}, T{}, F{}, was_primed, 0u, ra, rb, rbias);
-      ktile(IC<1>{}, F{}, T{}, T{}, F{}, false, 0u, ra, rb, rbias);
-      for (int kt = 4; kt < nkt; kt += 2) {
-        ktile(IC<0>{}, F{}, T{}, T{}, F{}, false, 0u, ra, rb, rbias);
-        ktile(IC<1>{}, F{}, T{}, T{}, F{}, false, 0u, ra, rb, rbias);
-      }
+      const uint32_t a0 = fo_a[0] + s_sa, b0 = fo_b[0] + s_sb;
+      static_for<8>([&fb0, b0](auto j) __attribute__((always_inline)) { P4_READ(fb0[j], b0, j * 2048); });
+      static_for<NI>([&fa0, a0](auto i) __attribute__((always_inline)) { P4_READ(fa0[i], a0, i * 2048); });
     }
-    // bias of this tile into registers (the next tile's slice lands in the other slot)
-    BiasRegs<4> bias_regs[2];
-    {
-      const char* bl = smem + P4_PIPE + par * P4_BIAS + wave * 1024;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + (64 * h + 16 * j + 4 * lq) * 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bias_regs[h].v[j][r] = b4[r];
-        }
-    }
-    // the next output tile: its first two K tiles are staged by the last two K tiles of this one
+    uint32_t a_cur = fo_a[1] + s_sa, b_cur = fo_b[1] + s_sb;
+    // the next output tile: the tail of this one stages its first K tiles
     const int t_next = t + (int)gridDim.x;
     const bool full_rows = c.bm0 + BM <= p.M;  // (a tile with rows beyond M skips some epilogue stores: their count is not fixed)
     const bool stage_next = EPI_EARLY && t_next < ntiles && full_rows;
     if (t_next < ntiles) cur = decode(t_next);
-    setup(cur, stage_next);
-    koff_a = 0;
-    koff_b = 0;
-    const uint32_t bias_lds_next = bias_lds0 + (par ^ 1) * P4_BIAS;
-    {
-      const u32x4 ra = uni4(ra_v), rb = uni4(rb_v);
-      ktile(IC<0>{}, F{}, T{}, T{}, T{}, false, bias_lds_next, ra, rb, rbias);
-      ktile(IC<1>{}, F{}, T{}, F{}, F{}, false, 0u, ra, rb, rbias);
+    const uint32_t bias_lds_next = bias_lds0 + (par ^ 1) * 4096;
+    u32x4 ra = uni4(ra_v), rb = uni4(rb_v);
+    BiasRegs<4> bias_regs[2];
+    // per K tile, before its MFMAs: which K tiles its slice 1 stages -- B of K tile k + 2 and A of K tile k + SA, of this output
+    // tile or of the next one (then the offsets / descriptors are re-pointed first)
+    int ka = SA - 1, kb = 1;  // (+ 1 in pre(): K tiles SA and 2 for k = 0)
+    int k0a = c.k0, k0b = c.k0;  // K rotation of the output tile whose A / B is being staged
+    uint32_t koff_a = 0, koff_b = 0;
+    auto pre = [&]() __attribute__((always_inline)) {
+      if (++ka == nkt) {
+        ka = 0;
+        k0a = cur.k0;
+        setup_a(cur, stage_next);
+        ra = uni4(ra_v);
+      }
+      if (++kb == nkt) {
+        kb = 0;
+        k0b = cur.k0;
+        // (this tile's bias slice into registers first: the next tile's lands in the other slot)
+        const char* bl = smem + LDS_BIAS + par * 4096 + wave * 1024;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + (64 * h + 16 * j + 4 * lq) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias_regs[h].v[j][r] = b4[r];
+          }
+        setup_b(cur, stage_next);
+        rb = uni4(rb_v);
+      }
+      const int pa = ka + k0a >= nkt ? ka + k0a - nkt : ka + k0a, pb = kb + k0b >= nkt ? kb + k0b - nkt : kb + k0b;
+      koff_a = kpn ? koff_of(pa) : (uint32_t)pa * 128u;
+      koff_b = kpn ? koff_of(pb) : (uint32_t)pb * 128u;
+    };
+    pre();
+    ktile(T{}, T{}, F{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, was_primed, 0u, ra, rb, rbias);
+    for (int k = 1; k + 1 < nkt; ++k) {
+      pre();
+      ktile(F{}, T{}, F{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, 0u, ra, rb, rbias);
     }
+    pre();
+    ktile(F{}, F{}, T{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, bias_lds_next, ra, rb, rbias);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are read by compiler-generated code
     primed = stage_next;
-
-    const long coff = c.z1 * p.sc1 + c.z2 * p.sc2;
-    (void)coff;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
       gemm_epilogue_direct<NI, EPI>(p, acc[h], bias_regs[h], c.bm0, c.bn0, wr * 16 * NI, wc * 128 + 64 * h, lane, c.z, c.z1, c.z2, 0);
@@ -340,9 +357,12 @@ int p4_num_cu(int* out) {
   return SSAK_OK;
 }
 
-template <int NI, bool B_KM, int EPI>
+template <int NI, int EPI>
 int launch_p4(const GemmParams& p, hipStream_t st) {
-  auto kern = gemm_p4_kernel<NI, B_KM, EPI>;
+  constexpr int SA = NI <= 6 ? 3 : 2;  // three A stages where 160 KB of LDS hold them next to two B stages and the bias slots
+  constexpr int P4_LDS = SA * NI * 32 * 128 + 2 * 32768 + 2 * 4096;
+  static_assert(P4_LDS <= 160 * 1024, "LDS");
+  auto kern = gemm_p4_kernel<NI, SA, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     SSAK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS));
@@ -360,7 +380,7 @@ int launch_p4(const GemmParams& p, hipStream_t st) {
     auto it = slots.find({p.N, p.K});
     if (it == slots.end()) {
       char nm[112];
-      snprintf(nm, sizeof(nm), "gemm_p4_kernel<%d, %s, %d> (N = %d, K = %d)", NI, B_KM ? "true" : "false", EPI, p.N, p.K);
+      snprintf(nm, sizeof(nm), "gemm_p4_kernel<%d, %d, %d> (N = %d, K = %d)", NI, SA, EPI, p.N, p.K);
       it = slots.emplace(std::make_pair(p.N, p.K), ssak_prof_register(nm, SSAK_BOUND_MFMA)).first;
     }
     slot = it->second;
@@ -373,20 +393,16 @@ int launch_p4(const GemmParams& p, hipStream_t st) {
 
 template <int NI>
 int dispatch_p4(const GemmParams& p, int b_km, hipStream_t st) {
-  if (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) {
-    if (!b_km) return launch_p4<NI, false, SSAK_EPI_GELU_SAVE_GRAD>(p, st);
-    ssak_set_error("gemm_p4: GELU_SAVE_GRAD is built for K-contiguous operands");
-    return SSAK_ERR_INVALID;
-  }
   if (b_km) {
-    ssak_set_error("gemm_p4: the K-major B form is not built");
+    ssak_set_error("gemm_p4: built for K-contiguous operands");
     return SSAK_ERR_INVALID;
   }
-  if (p.epilogue == SSAK_EPI_MUL_AUX) return launch_p4<NI, false, SSAK_EPI_MUL_AUX>(p, st);
+  if (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) return launch_p4<NI, SSAK_EPI_GELU_SAVE_GRAD>(p, st);
+  if (p.epilogue == SSAK_EPI_MUL_AUX) return launch_p4<NI, SSAK_EPI_MUL_AUX>(p, st);
   const bool no_extras = !p.drop_thresh && !p.colsum;
-  if (no_extras && p.epilogue == SSAK_EPI_NONE && !p.out_f32 && !p.accumulate) return launch_p4<NI, false, P8_EPI_PLAIN_BF16>(p, st);
-  if (no_extras && p.epilogue == SSAK_EPI_GELU && !p.aux_out && !p.out_f32) return launch_p4<NI, false, P8_EPI_GELU_ONLY>(p, st);
-  return launch_p4<NI, false, -1>(p, st);
+  if (no_extras && p.epilogue == SSAK_EPI_NONE && !p.out_f32 && !p.accumulate) return launch_p4<NI, P8_EPI_PLAIN_BF16>(p, st);
+  if (no_extras && p.epilogue == SSAK_EPI_GELU && !p.aux_out && !p.out_f32) return launch_p4<NI, P8_EPI_GELU_ONLY>(p, st);
+  return launch_p4<NI, -1>(p, st);
 }
 
 }  // namespace
@@ -395,10 +411,9 @@ int dispatch_p4(const GemmParams& p, int b_km, hipStream_t st) {
 // stays on gemm_p8.hip
 bool ssak_gemm_p4_supports(const void* params, int bm, int a_km, int b_km) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
-  if (b_km) return false;  // (K-major B: not built yet)
-  if (a_km || p.split_k != 1 || p.dynamic || p.kperm_n2) return false;
+  if (a_km || b_km || p.split_k != 1 || p.dynamic) return false;
   if (bm != 256 && bm != 192 && bm != 128) return false;
-  if (p.K % 128 != 0 || p.K < 256 || p.N % 256 != 0) return false;
+  if (p.K % 64 != 0 || p.K < 192 || p.N % 256 != 0) return false;
   if ((p.ldc & 7) || ((p.sc1 | p.sc2) & 7)) return false;
   const bool fq = p.epilogue == SSAK_EPI_GELU_SAVE_GRAD || p.epilogue == SSAK_EPI_MUL_AUX;
   if (fq && ((p.ldc | p.sc1 | p.sc2) & 15)) return false;

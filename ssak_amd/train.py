@@ -124,29 +124,43 @@ def prepare(utts, tok):
     return waves, labels
 
 
-def evaluate(model, tok, waves, labels, batch_size):
+def evaluate(model, tok, waves, labels, batch_size, rank: int = 0, world: int = 1):
     """eval_loss and eval_wer over the validation set.  Logits never leave the device: greedy decode and the word-level
     edit counts are kernels (ssak_amd.metrics), the loss is summed on the device, and there is ONE host read at the end
-    (the reference's compute_metrics argmaxes the full logits on the host at every eval step, wav2vec_train.py:110-125)."""
+    (the reference's compute_metrics argmaxes the full logits on the host at every eval step, wav2vec_train.py:110-125).
+
+    With a process group every rank evaluates ITS contiguous shard of each validation batch -- the reference's
+    per_device_eval_batch_size = batch_size // num_devices (wav2vec_train.py:357) -- and ONE all-reduce of four sums
+    (word edits, reference words, summed per-utterance loss, utterances) gives every rank the same metrics: no rank idles
+    at a barrier while rank 0 walks the whole set."""
     from .metrics import WerAccumulator
     model.eval()
     acc = WerAccumulator(tok.vocab, tok.pad_token_id, model.device, tok.delim)
-    tot = torch.zeros(1, dtype=torch.float32, device=model.device)
+    tot = torch.zeros(1, dtype=torch.float64, device=model.device)
     n = 0
     for i in range(0, len(waves), batch_size):
-        x, lens = pad_waves(waves[i:i + batch_size])
-        lab = torch.from_numpy(pad_labels(labels[i:i + batch_size])).to(model.device)
+        mine = list(range(i, min(i + batch_size, len(waves))))
+        if world > 1:
+            mine = shard_batch(mine, rank, world)
+            if not mine:
+                continue
+        x, lens = pad_waves([waves[k] for k in mine])
+        lab = torch.from_numpy(pad_labels([labels[k] for k in mine])).to(model.device)
         xd, ld = torch.from_numpy(x).to(model.device), torch.from_numpy(lens).to(model.device)
         use_mask = model.config.feat_extract_norm == "layer"
         fl = torch.tensor([model.num_frames(int(l)) for l in lens], dtype=torch.int32, device=model.device)
         with torch.cuda.device(model.device):
             xn = hip.wave_normalize(xd, ld)
             out = model(xn, lengths=ld if use_mask else None, labels=lab)
-            tot += out.loss * len(x)
+            tot += out.loss.double() * len(x)
             acc.add(out.logits, lab, fl)
         n += len(x)
     model.train()
-    return {"eval_loss": float(tot.item()) / max(n, 1), "eval_wer": acc.compute()["wer"]}
+    sums = torch.cat([acc.sums.double(), tot, torch.tensor([float(n)], dtype=torch.float64, device=model.device)])
+    if world > 1:
+        torch.distributed.all_reduce(sums)  # (exact: integer counts far below 2^53)
+    edits, words, loss_sum, count = (float(v) for v in sums.cpu())
+    return {"eval_loss": loss_sum / max(count, 1.0), "eval_wer": edits / max(1.0, words)}
 
 
 def main(argv=None):
@@ -214,16 +228,22 @@ def main(argv=None):
             print(datetime.datetime.now(), file=readme)
             print(" ".join(sys.argv), file=readme)
             print(f"{len(train_u)} training / {len(valid_u)} validation utterances\n", file=readme)
-        # initial evaluation: computed once per (data, base model) in the "untrained" folder, copied into every run's folder,
-        # never redone on resume (wav2vec_train.py:397-410)
-        init_results = os.path.join(out_dir, "init_eval.json")
-        if not args.disable_first_eval and not os.path.isfile(init_results):
-            cached = os.path.join(untrained_dir, "init_eval.json")
-            if not os.path.exists(cached):
-                os.makedirs(untrained_dir, exist_ok=True)
-                with open(cached, "w") as f:
-                    json.dump(evaluate(model, tok, vw, vl, args.batch_size), f, indent=1)
-            shutil.copy(cached, init_results)
+    # initial evaluation: computed once per (data, base model) in the "untrained" folder, copied into every run's folder,
+    # never redone on resume (wav2vec_train.py:397-410).  Rank 0 decides from the files, every rank evaluates its shard.
+    init_results = os.path.join(out_dir, "init_eval.json")
+    cached = os.path.join(untrained_dir, "init_eval.json")
+    need = torch.tensor([int(rank == 0 and not args.disable_first_eval and not os.path.isfile(init_results) and not os.path.exists(cached))],
+                        device=dev)
+    if world > 1:
+        torch.distributed.broadcast(need, src=0)
+    if bool(need.item()):
+        first = evaluate(model, tok, vw, vl, args.batch_size, rank, world)
+        if rank == 0:
+            os.makedirs(untrained_dir, exist_ok=True)
+            with open(cached, "w") as f:
+                json.dump(first, f, indent=1)
+    if rank == 0 and not args.disable_first_eval and not os.path.isfile(init_results):
+        shutil.copy(cached, init_results)
     rng = np.random.RandomState(args.seed)
     use_mask = model.config.feat_extract_norm == "layer"
     step, t0, run_loss = 0, time.time(), []
@@ -239,16 +259,19 @@ def main(argv=None):
         with open(os.path.join(last, "trainer_state.json")) as f:
             state = json.load(f)
         tracker = BestModelTracker(state)
-        # every rank restores ITS OWN regulariser streams (the trainer seeds ranks differently: seed + rank); a checkpoint of
-        # an older build or of a run with fewer ranks only has rank 0's file
-        rng_file = os.path.join(last, f"rng-rank{rank}.json")
-        if not os.path.exists(rng_file):
-            rng_file = os.path.join(last, "rng.json")
-        with open(rng_file) as f:  # plain JSON, no pickle
-            extra = json.load(f)
-        model._step_seed = int(extra["step_seed"])
-        kind, keys, pos, has_gauss, cached = extra["host_rng"]
-        model._host_rng.set_state((kind, np.asarray(keys, dtype=np.uint32), int(pos), int(has_gauss), float(cached)))
+        # every rank restores ITS OWN regulariser streams (the trainer seeds ranks differently: seed + rank).  A checkpoint written
+        # by fewer ranks has no file for the extra ones: they take rank 0's, then an older build's rng.json; with neither the
+        # freshly seeded (seed + rank) streams stay (a warning, not an error: the other ranks would hang at the next collective)
+        rng_file = next((f for f in (os.path.join(last, f"rng-rank{rank}.json"), os.path.join(last, "rng-rank0.json"),
+                                     os.path.join(last, "rng.json")) if os.path.exists(f)), None)
+        if rng_file is None:
+            print(f"warning: {last} holds no regulariser stream state for rank {rank}: keeping the freshly seeded streams")
+        else:
+            with open(rng_file) as f:  # plain JSON, no pickle
+                extra = json.load(f)
+            model._step_seed = int(extra["step_seed"])
+            kind, keys, pos, has_gauss, cached_g = extra["host_rng"]
+            model._host_rng.set_state((kind, np.asarray(keys, dtype=np.uint32), int(pos), int(has_gauss), float(cached_g)))
         best = state.get("best_model_checkpoint")
         if best is not None and not os.path.isdir(best):  # the output folder was moved: checkpoints are found by name
             state["best_model_checkpoint"] = os.path.join(out_dir, os.path.basename(best))
@@ -292,9 +315,9 @@ def main(argv=None):
                          "loss": float(torch.stack(run_loss).mean().item())}
                 run_loss = []
                 ck = os.path.join(out_dir, f"checkpoint-{step}")
+                metrics = evaluate(model, tok, vw, vl, args.batch_size, rank, world)  # every rank: its shard of each batch
                 if rank == 0:
                     state["log_history"].append(entry)
-                    metrics = evaluate(model, tok, vw, vl, args.batch_size)
                     state["log_history"].append({"epoch": entry["epoch"], "step": step, **metrics})
                     state["global_step"] = step
                     # on_evaluate (early stopping) first, then save + best-metric bookkeeping, then rotation: HF's order

@@ -328,6 +328,10 @@ def test_fragment_ordered_weights_change_no_bit(mods):
     for frag in (1, 0):
         model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc)).train()
         model.set_option(hip.W2V2_OPT_FRAGMENT_WEIGHTS, frag)
+        # the comparison form is the eight-wave LDS kernel with the weight read K-major in the input-gradient products (round 4:
+        # by default those read transposed copies on the four-wave kernel, whose K order is rotated per row panel)
+        model.set_option(hip.W2V2_OPT_DYNAMIC_TILES, 1)
+        model.set_option(hip.W2V2_OPT_TRANSPOSED_WEIGHTS, 0)
         model.load_state_dict(p)
         steps = []
         for step in range(2):

@@ -553,7 +553,9 @@ def test_gemm_b_direct_form_is_bit_identical(hip):
     """The B-direct form of the persistent GEMM (fragment-ordered weights loaded straight into registers, B never in LDS;
     ssak_gemm_desc.b_fragments) against the LDS form on the shapes that take it in the train step (M = 32 x 499 frames; qkv,
     output and feed-forward-down projections and the three input-gradient products), plus a ragged M / a K tail and a bias:
-    same accumulation order -> the same bits.  Also: shapes the library keeps on the LDS form ignore the copy."""
+    same accumulation order -> the same bits.  (The LDS form compared with is the eight-wave kernel's: `dynamic_tiles` keeps a
+    product on it -- the four-wave kernel that serves the K-contiguous products by default sums in a different, per-row-panel
+    rotated K order.)  Also: shapes the library keeps on the LDS form ignore the copy."""
     g = torch.Generator().manual_seed(11)
     took = 0
     cases = [(15968, 2304, 768, False), (15968, 768, 768, False), (15968, 768, 3072, False), (15968, 768, 2304, True),
@@ -564,7 +566,7 @@ def test_gemm_b_direct_form_is_bit_identical(hip):
         bias = torch.randn(N, generator=g).cuda()
         frag = hip.gemm_fragment_b(Bs, N, K, b_kmajor=b_km)
         kw = dict(b_kmajor=b_km, lda=K, ldb=N if b_km else K, ldc=N, bias=bias, pads_are_zero=True)
-        want = hip.gemm(A, Bs, torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), M, N, K, **kw)
+        want = hip.gemm(A, Bs, torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), M, N, K, dynamic_tiles=True, **kw)
         got = hip.gemm(A, Bs, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"), M, N, K, b_fragments=frag, **kw)
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (M, N, K, b_km)
         ref = A.float() @ (Bs.float() if b_km else Bs.float().t()) + bias

@@ -472,6 +472,60 @@ def test_train_cli_two_rank_resume_restores_each_ranks_regulariser_streams(tmp_p
 
 
 @pytest.mark.timeout(900)
+def test_train_cli_sharded_evaluation_equals_single_process(tmp_path):
+    """Every rank evaluates its contiguous shard of each validation batch (the reference's per_device_eval_batch_size =
+    batch_size // num_devices, ssak/train/transformers/wav2vec_train.py:357) and one all-reduce of (edits, words, loss sum,
+    utterances) gives the metrics: the initial evaluation of two ranks (gloo, one card) equals the single-process one -- word
+    error counts exactly, the loss to fp32 summation order -- on 11 utterances in batches of 4 (shards 2+2, 2+2, 2+1)."""
+    import socket
+    from oracle import w2v2_ref as R
+    from ssak_amd import data as D
+    from ssak_amd.checkpoint import save_pretrained
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.synth import VOCAB, synth_text, synth_wave
+    rng = np.random.default_rng(5)
+    kd = tmp_path / "kaldi"
+    (kd / "audio").mkdir(parents=True)
+    with open(kd / "wav.scp", "w") as fw, open(kd / "text", "w") as ft, open(kd / "utt2dur", "w") as fd:
+        for i in range(11):
+            n = int(rng.integers(16000, 30000))
+            D.write_wav(str(kd / "audio" / f"u{i}.wav"), synth_wave(rng, n))
+            fw.write(f"utt{i}\t{kd}/audio/u{i}.wav\n")
+            ft.write(f"utt{i} {synth_text(rng, 3, 8)}\n")
+            fd.write(f"utt{i} {n / 16000:.3f}\n")
+    oc = R.W2V2Config.tiny().deterministic()
+    base = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc))
+    base.load_state_dict(R.init_params(oc, 3))
+    save_pretrained(base, D.CharTokenizer(VOCAB), str(tmp_path / "base"))
+    del base
+    torch.cuda.synchronize()
+
+    def run(out, nproc):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, PYTHONPATH=ROOT, SSAK_DIST_BACKEND="gloo")
+        launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "-m"] if nproc > 1 else [sys.executable, "-m"]
+        r = subprocess.run(launcher + ["ssak_amd.train", str(kd), str(kd), "--base_model", str(tmp_path / "base"), "--batch_size", "4",
+                                       "--num_epochs", "1", "--eval_steps", "100", "--learning_rate", "1e-4", "--min_duration", "0",
+                                       "--output_dir", str(out)], env=env, capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        name = [d for d in os.listdir(out) if "_adamwt" in d][0]
+        run_dir = os.path.join(out, name)
+        st = json.load(open(os.path.join(run_dir, "checkpoint-3", "trainer_state.json")))
+        return json.load(open(os.path.join(run_dir, "init_eval.json"))), [e for e in st["log_history"] if "eval_wer" in e][-1]
+
+    one_init, one_last = run(tmp_path / "one", 1)
+    two_init, two_last = run(tmp_path / "two", 2)
+    assert one_init["eval_wer"] == two_init["eval_wer"] and one_init["eval_wer"] > 0
+    assert abs(one_init["eval_loss"] - two_init["eval_loss"]) <= 1e-5 * abs(one_init["eval_loss"])
+    # after three data-parallel steps both runs hold (nearly) the same weights: the metrics of the final evaluation agree too
+    assert abs(one_last["eval_loss"] - two_last["eval_loss"]) <= 2e-2 * abs(one_last["eval_loss"])
+
+
+@pytest.mark.timeout(900)
 def test_bench_two_rank_rehearsal_reports_the_exchange(tmp_path):
     """bench.py under torch.distributed.run with two ranks (both on the one card, gloo standing in for RCCL -- the driver's
     N > 1 runs use one GPU per rank over RCCL): the JSON line carries what the N > 1 readings need -- the exposed optimizer /

@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256) void gemm_p4c_probe(const bf16* A, const bf16*
     const int row = (q < NA ? bm0 + 32 * q : bn0 + 32 * (q - NA)) + drow;
     vo[q] = (uint32_t)(((long)row * K + dchunk * 8) * 2);
   }
+#ifdef P4C_PF
+  // L2 prefetch, P4C_PF K tiles ahead: one dword per 128-byte line (lane = row), A rows 64 w .. and B rows 64 w .. of the tile
+  const uint32_t pf_a = (wave * 64 + lane < BM) ? (uint32_t)(((long)(bm0 + wave * 64 + lane) * K) * 2) : 0x80000000u;
+  const uint32_t pf_b = (uint32_t)(((long)(bn0 + wave * 64 + lane) * K) * 2);
+  uint32_t pf_sink = 0;
+#endif
   typedef __attribute__((address_space(3))) char lds_char;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
   const uint32_t wbase = lds0 + wave * 1024;  // + buffer + q * 4096 (B: + 32768 - NA * 4096 more)
@@ -141,15 +147,24 @@ __global__ __launch_bounds__(256) void gemm_p4c_probe(const bf16* A, const bf16*
   // one K tile in buffer P.  DMA: stage tile t + 2 into this buffer; READ_NEXT: read set 0 of tile t + 1 from the other one.
   // Every gap between two MFMAs carries at most ONE other instruction: a fragment read, the M0 write of an LDS-DMA or the
   // LDS-DMA itself (one statement = M0 write, MFMA, LDS-DMA: the compiler does not preserve M0 between statements).
-  auto ktile = [&acc, &fa0, &fb0, &fa1, &fb1, &vo, &ra, &rb, &koff, &fo_a, &fo_b, wbase](auto par_c, auto dma_c, auto rn_c) {
+#ifdef P4C_PF
+#define PF_CAP , pf_a, pf_b, &pf_sink
+#else
+#define PF_CAP
+#endif
+  auto ktile = [&acc, &fa0, &fb0, &fa1, &fb1, &vo, &ra, &rb, &koff, &fo_a, &fo_b, wbase PF_CAP](auto par_c, auto dma_c, auto rn_c) {
     constexpr int P = decltype(par_c)::value;
     constexpr bool DMA = decltype(dma_c)::value && !(P4C_ABL & 1), READ_NEXT = decltype(rn_c)::value;
     const uint32_t wb = wbase + P * P4_BUF;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // set 0 is in registers
     // ---- slice 0: 8 NI MFMAs on set 0; set 1 <- slice 1 of this tile
-    static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &fo_a, &fo_b](auto mc) {
+    static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &fo_a, &fo_b, &ra, &rb, &koff PF_CAP](auto mc) {
       constexpr int m = decltype(mc)::value, i = m / 8, j = m % 8;
       MFMA(acc[i][j], fb0[j], fa0[i]);
+#ifdef P4C_PF
+      if constexpr (DMA && m == 8 * NI - 12) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pf_sink) : "v"(pf_a), "s"(ra), "s"(koff + (P4C_PF - 2) * 128) : "memory");
+      if constexpr (DMA && m == 8 * NI - 10) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(pf_sink) : "v"(pf_b), "s"(rb), "s"(koff + (P4C_PF - 2) * 128) : "memory");
+#endif
       if constexpr (m % P4C_R0STEP == 0 && m / P4C_R0STEP < 8 + NI) {
         constexpr int r = m / P4C_R0STEP;
         if constexpr (r == 0) DSREAD(fa1[0], fo_a[P][1], 0);
@@ -158,6 +173,9 @@ __global__ __launch_bounds__(256) void gemm_p4c_probe(const bf16* A, const bf16*
       }
       if constexpr (m == 8 * NI - 4) {
         if constexpr (P4C_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef P4C_PF
+        else if constexpr (DMA) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");  // (the two prefetch loads just issued stay in flight)
+#endif
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my reads of this buffer are done, my share of tile t + 1 has landed
       }
       if constexpr (m == 8 * NI - 3 && !(P4C_ABL & 4)) asm volatile("s_barrier" ::: "memory");
@@ -240,18 +258,21 @@ static float tof(unsigned short h) {
   return c.f;
 }
 
+static int g_sets = 1, g_iters = 200, g_rot = 3;  // g_rot: bit 0 rotate A, bit 1 rotate B
 template <int NI>
 static void run(int M, int N, int K) {
   bf16 *A, *B, *C;
-  hipMalloc(&A, (size_t)M * K * 2);
-  hipMalloc(&B, (size_t)N * K * 2);
+  hipMalloc(&A, (size_t)M * K * 2 * g_sets);
+  hipMalloc(&B, (size_t)N * K * 2 * g_sets);
   hipMalloc(&C, (size_t)M * N * 2);
   std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
   srand(1);
   for (auto& v : ha) v = tobf((float)rand() / RAND_MAX * 2.f - 1.f);  // uniform [-1, 1): the chip clocks lower on random data
   for (auto& v : hb) v = tobf((float)rand() / RAND_MAX * 2.f - 1.f);
-  hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
-  hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+  for (int s = 0; s < g_sets; ++s) {
+    hipMemcpy(A + (size_t)s * M * K, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(B + (size_t)s * N * K, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+  }
   hipMemset(C, 0xff, (size_t)M * N * 2);
   hipFuncSetAttribute((const void*)gemm_p4c_probe<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P4_BUF);
   const int grid = ((M + 32 * NI - 1) / (32 * NI)) * (N / 256);
@@ -262,9 +283,10 @@ static void run(int M, int N, int K) {
   hipMalloc(&stamps, (size_t)grid * 64);
   for (int it = 0; it < 5; ++it) gemm_p4c_probe<NI><<<grid, 256, 2 * P4_BUF>>>(A, B, C, M, N, K, stamps);
   hipDeviceSynchronize();
-  const int iters = 200;
+  const int iters = g_iters;
   hipEventRecord(e0);
-  for (int it = 0; it < iters; ++it) gemm_p4c_probe<NI><<<grid, 256, 2 * P4_BUF>>>(A, B, C, M, N, K, stamps);
+  for (int it = 0; it < iters; ++it)
+    gemm_p4c_probe<NI><<<grid, 256, 2 * P4_BUF>>>(A + (size_t)((g_rot & 1) ? it % g_sets : 0) * M * K, B + (size_t)((g_rot & 2) ? it % g_sets : 0) * N * K, C, M, N, K, stamps);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms;
@@ -307,6 +329,9 @@ static void run(int M, int N, int K) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 2) g_sets = atoi(argv[2]);
+  if (argc > 3) g_iters = atoi(argv[3]);
+  if (argc > 4) g_rot = atoi(argv[4]);
   if (argc > 1) {  // short list for A/B runs of variants
     run<8>(4096, 4096, 4096);
     run<8>(15968, 3072, 768);

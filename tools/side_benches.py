@@ -1,0 +1,207 @@
+"""Secondary workloads of BASELINE.json (configs[3], configs[4]) and the audio-ingest path, as functions: bench.py puts their
+lines into `secondary[]` of its one JSON line; tools/bench_whisper.py / bench_xlsr.py / bench_ingest.py print them alone.
+Synthetic data and seeded random-init weights of the named architectures (no network for datasets or checkpoints)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def _w2v2_state(model, seed=69):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, (off, n, shape) in model.layout.items():
+        if name.endswith("layer_norm.weight"):
+            t = torch.ones(shape)
+        elif name.endswith(".bias"):
+            t = torch.zeros(shape)
+        elif name.endswith("masked_spec_embed"):
+            t = torch.rand(shape, generator=g)
+        elif ".conv.weight" in name or name.endswith("original1"):
+            t = torch.randn(shape, generator=g) * (2.0 / (shape[1] * shape[2])) ** 0.5
+        else:
+            t = torch.randn(shape, generator=g) * 0.02
+        sd[name] = t
+    v = sd["wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
+    sd["wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    return sd
+
+
+def whisper_step(B=8, steps=10, warmup=2, device="cuda:0"):
+    """BASELINE configs[3]: Whisper-small encoder + CTC head train step on 30 s windows.  Step = log-mel (a13, HIP kernel) ->
+    encoder forward -> CTC -> backward -> clip + AdamW.  Also times the log-mel front end alone (HIP events)."""
+    from ssak_amd import hip
+    from ssak_amd.synth import synth_wave
+    from ssak_amd.trainer import AdamW
+    from ssak_amd.whisper import WhisperCTCConfig, WhisperEncoderForCTC
+    cfg = WhisperCTCConfig()
+    model = WhisperEncoderForCTC(cfg, device=device).train()
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for n, (off, cnt, shape) in model.layout.items():
+        if n.endswith("embed_positions.weight"):
+            length, channels = shape  # Whisper's fixed sinusoidal table
+            inv = torch.exp(-(np.log(10000.0) / (channels // 2 - 1)) * torch.arange(channels // 2))
+            t = torch.arange(length).view(-1, 1) * inv.view(1, -1)
+            sd[n] = torch.cat([t.sin(), t.cos()], dim=1)
+        elif "layer_norm.weight" in n:
+            sd[n] = torch.ones(shape)
+        elif n.endswith(".bias"):
+            sd[n] = torch.zeros(shape)
+        else:
+            sd[n] = torch.randn(shape, generator=g) * 0.02
+    model.load_state_dict(sd)
+    opt = AdamW(model, lr=1e-4, warmup_steps=500)
+    rng = np.random.default_rng(0)
+    wav = torch.tensor(np.stack([synth_wave(rng, 480000) for _ in range(B)])).to(device)
+    labels = torch.randint(1, cfg.vocab_size, (B, 200)).to(device)
+
+    def step():
+        mel = hip.logmel_whisper(wav)
+        out = model(mel, labels=labels)
+        model.backward()
+        opt.step()
+        return out.loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # the log-mel front end alone: 1.92 MB of waveform in, 0.96 MB of features out per window
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    hip.logmel_whisper(wav)
+    e0.record()
+    for _ in range(10):
+        hip.logmel_whisper(wav)
+    e1.record()
+    torch.cuda.synchronize()
+    lm_us = e0.elapsed_time(e1) / 10 * 1e3
+    gf = 1032.0  # ~3 x 344.16 GF per 30 s window, nothing frozen
+    tf = gf * B / dt / 1e3
+    del model, opt
+    return {"workload": "Whisper-small encoder + CTC head train step incl. the log-mel kernel, bf16, synthetic 30 s windows "
+                        "(BASELINE.json configs[3], 1 GPU)",
+            "value": round(B / dt, 2), "unit": "windows/sec", "audio_sec_per_sec": round(30 * B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+            "batch": B, "steps": steps, "whole_step_tflops": round(tf, 1), "whole_step_frac": round(tf / PEAK_BF16_TFLOPS, 4),
+            "logmel": {"kernel": "ssak_logmel_whisper (reflect pad + DFT + |.|^2 + mel + log10 + clamp/scale)", "us_per_window": round(lm_us / B, 2),
+                       "us_per_call": round(lm_us, 1), "algorithmic_mb_per_window": 2.88,
+                       "achieved_gbs": round(2.88e6 * B / (lm_us * 1e-6) / 1e9, 1), "peak_gbs": 8000.0,
+                       "frac": round(2.88e6 * B / (lm_us * 1e-6) / 1e9 / 8000.0, 4), "share_of_step": round(lm_us * 1e-6 / dt, 4)},
+            "loss": round(float(loss.item()), 4)}
+
+
+def xlsr_bucketed(B=16, N=320, device="cuda:0"):
+    """BASELINE configs[4] on one GPU: Wav2Vec2-large-XLSR CTC train step over mixed-length utterances (durations log-uniform in
+    [1 s, 15 s], wav2vec_train.py:149-150), batched like HF's LengthGroupedSampler (docker/transformers_modified/trainer.py:758-775),
+    right-padded with lengths.  One pass over all batches; algorithmic FLOPs counted on the real (unpadded) lengths."""
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.data import length_grouped_batches
+    from ssak_amd.model import Wav2Vec2ForCTC, conv_out_lengths
+    from ssak_amd.synth import synth_text, synth_wave, text_to_ids
+    from ssak_amd.trainer import AdamW, Trainer
+    cfg = Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                         feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
+
+    def train_gflop(T: int) -> float:
+        L, cin, fe = T, 1, 0.0
+        for c, k, s in zip(cfg.conv_dim, cfg.conv_kernel, cfg.conv_stride):
+            L = (L - k) // s + 1
+            fe += 2.0 * L * c * cin * k
+            cin = c
+        H, I, F = cfg.hidden_size, cfg.intermediate_size, L
+        rest = 2.0 * F * cin * H + 2.0 * F * H * (H // cfg.num_conv_pos_embedding_groups) * cfg.num_conv_pos_embeddings
+        rest += cfg.num_hidden_layers * (2.0 * F * (4 * H * H + 2 * H * I) + 4.0 * F * F * H) + 2.0 * F * H * cfg.vocab_size
+        return (fe + 3.0 * rest) / 1e9
+
+    assert abs(train_gflop(160000) - 1053.50) < 1.0, train_gflop(160000)  # XLSR-large @10 s
+    model = Wav2Vec2ForCTC(cfg, device=device, freeze_feature_encoder=True, seed=69).train()
+    model.load_state_dict(_w2v2_state(model))
+    opt = AdamW(model, lr=1e-4, warmup_steps=500)
+    trainer = Trainer(model, opt)
+    rng = np.random.default_rng(1234)
+    durs = np.exp(rng.uniform(np.log(1.0), np.log(15.0), N))
+    nsamp = (durs * 16000).astype(np.int64)
+    batches = [b for b in length_grouped_batches(nsamp.tolist(), B, np.random.RandomState(0)) if len(b) == B]
+    dev_batches = []
+    for idx in batches:
+        T = (int(max(nsamp[i] for i in idx)) + 7) // 8 * 8
+        wav = np.zeros((B, T), np.float32)
+        ids = []
+        for r, i in enumerate(idx):
+            wav[r, :nsamp[i]] = synth_wave(rng, int(nsamp[i]))
+            fl = int(conv_out_lengths(cfg, np.array([nsamp[i]]))[0])
+            n = max(1, min(int(durs[i] * 8), (fl - 1) // 2))  # ~8 characters per second, always feasible for CTC
+            ids.append(text_to_ids(synth_text(rng, n, n)))
+        Lm = max(len(x) for x in ids)
+        lab = np.full((B, Lm), -100, np.int64)
+        for r, x in enumerate(ids):
+            lab[r, :len(x)] = x
+        dev_batches.append((torch.tensor(wav).to(device), torch.tensor(nsamp[idx].astype(np.int32)).to(device), torch.tensor(lab).to(device)))
+    order = sorted(range(len(dev_batches)), key=lambda j: -dev_batches[j][0].shape[1])
+    for j in (order[0], order[-1]):  # warm-up on the longest batch (sizes the workspace once) and one short one
+        trainer.train_step(*dev_batches[j])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for w, l, y in dev_batches:
+        loss = trainer.train_step(w, l, y)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    utts = B * len(dev_batches)
+    used = [i for b in batches for i in b]
+    audio = float(sum(durs[i] for i in used))
+    padded = float(sum(dev_batches[j][0].shape[1] * B for j in range(len(dev_batches)))) / 16000.0
+    tf = sum(train_gflop(int(nsamp[i])) for i in used) / dt / 1e3
+    del model, opt, trainer
+    return {"workload": "Wav2Vec2-large-XLSR CTC train step, bf16, durations log-uniform 1-15 s, length-grouped batches, attention "
+                        "mask (BASELINE.json configs[4] on 1 GPU)",
+            "value": round(utts / dt, 2), "unit": "utterances/sec", "audio_sec_per_sec": round(audio / dt, 1), "batch": B,
+            "steps": len(dev_batches), "ms_per_step": round(dt / len(dev_batches) * 1e3, 3), "padding_overhead": round(padded / audio - 1.0, 4),
+            "whole_step_tflops": round(tf, 1), "whole_step_frac": round(tf / PEAK_BF16_TFLOPS, 4), "loss": round(float(loss.item()), 4)}
+
+
+def ingest_rate(N=256, sr=16000, nch=1, B=32):
+    """10 s PCM16 WAV files -> normalised device batches of B through the prefetching device ingest
+    (ssak_amd/ingest.py: file read, PCM decode + mono mix + resample on the device, waveform normalisation)."""
+    import tempfile
+    import wave as wavmod
+    from ssak_amd.ingest import BatchPrefetcher, DeviceIngest
+    d = tempfile.mkdtemp()
+    rng = np.random.default_rng(0)
+    items = []
+    for i in range(N):
+        p = os.path.join(d, f"u{i}.wav")
+        pcm = (rng.standard_normal(10 * sr * nch) * 3000).astype("<i2")
+        with wavmod.open(p, "wb") as f:
+            f.setnchannels(nch)
+            f.setsampwidth(2)
+            f.setframerate(sr)
+            f.writeframes(pcm.tobytes())
+        items.append((p, None, None))
+    batches = [items[i:i + B] for i in range(0, N, B)]
+    ing = DeviceIngest(16000)
+    for w, l in BatchPrefetcher(ing, batches[:2]):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for w, l in BatchPrefetcher(ing, batches, depth=3):
+        pass
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for p, _, _ in items:
+        os.unlink(p)
+    os.rmdir(d)
+    return {"path": "Kaldi-style wav.scp entries -> PCM16 WAV read -> device decode / mono / resample -> ssak_wave_normalize -> batches of "
+                    f"{B} (ssak_amd/ingest.py, prefetch depth 3)", "utterances_per_sec": round(N / dt, 1), "files": N,
+            "source": f"{sr} Hz x {nch} ch, 10 s"}
