@@ -287,6 +287,23 @@ int ssak_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
                     const float* gnorm_sq, float max_norm, float grad_scale, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, void* stream);
 
+/* ---- e: data-parallel gradient exchange ------------------------------------------------------
+ * One process per GPU, utterance shards per rank, ONE sum all-reduce of the flat gradient buffer per step (in buckets, as the
+ * backward announces them: ssak_w2v2_set_grad_ready_callback) -- what torch.nn.DataParallel's gather + loss.mean() does inside
+ * HF Trainer for the reference (docker/transformers_modified/trainer.py:2532-2533; per_device_train_batch_size = batch_size //
+ * num_devices, ssak/train/transformers/wav2vec_train.py:349,356).  RCCL over xGMI; librccl.so is dlopen'ed on the first call
+ * (libssak_hip.so does not link it: a single-GPU host never loads it).  Rank 0 calls ssak_comm_unique_id and hands the 128
+ * bytes to the other ranks by its own means (file, socket, MPI, torch.distributed); every rank then calls ssak_comm_create
+ * (collective).  ssak_allreduce: buf[offset, offset + count) of `dtype` elements := the sum over ranks, in place, asynchronous
+ * on `stream`; 1 / world is folded into ssak_adamw_step's grad_scale.  One communicator per process and device. */
+typedef struct ssak_comm ssak_comm;
+#define SSAK_DTYPE_F32 0
+#define SSAK_DTYPE_BF16 1
+int ssak_comm_unique_id(void* id128 /*host, 128 bytes out*/);
+int ssak_comm_create(ssak_comm** out, int world, int rank, const void* id128 /*host*/);
+int ssak_allreduce(ssak_comm* comm, void* buf, long offset, long count, int dtype, void* stream);
+int ssak_comm_destroy(ssak_comm* comm);
+
 /* ---- a3-a10: the Wav2Vec2-CTC acoustic model ------------------------------------------------
  * Replaces `model(input_values, attention_mask, labels)` / `loss.backward()` of transformers.Wav2Vec2ForCTC as
  * called at ssak/train/transformers/wav2vec_train.py:387-415 (through HF Trainer.training_step) and
@@ -456,7 +473,8 @@ int ssak_cast_bf16_f32(const void* src_bf16, float* dst, long n, void* stream);
 size_t ssak_colsum_workspace_bytes(int N);
 int ssak_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- debug: dropout bits of one site --------------------------------------------------------------------------------
+/* ---- TEST-ONLY entries (not part of the product path; kept in the release library so that the parity tests run against the
+ * library that ships): dropout bits of one site ------------------------------------------------------------------------
  * The engine stores no dropout mask: each site recomputes keep(seed, site, element) in its forward and backward kernels
  * (transformers draws torch's global generator at modeling_wav2vec2.py:433,458,568,571,596,692,1698; the reference passes the
  * probabilities at ssak/train/transformers/wav2vec_train.py:313-318).  These two entries write the bits out so that the CPU

@@ -13,7 +13,7 @@ import torch
 
 _DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")
 _LIB_PATH = os.environ.get("SSAK_HIP_LIB") or _DEFAULT_LIB  # (the override names another build OF THE SAME ABI: A/B runs, instrumented builds)
-ABI_VERSION = 301  # ssak_version() of the library this binding's struct layouts and signatures were written for
+ABI_VERSION = 400  # ssak_version() of the library this binding's struct layouts and signatures were written for
 
 
 class GemmDesc(C.Structure):
@@ -124,6 +124,10 @@ def _load():
         "ssak_cast_bf16_f32": (i32, [vp, vp, C.c_long, vp]),
         "ssak_colsum_workspace_bytes": (sz, [i32]),
         "ssak_colsum_bf16": (i32, [vp, C.c_long, i32, i32, vp, vp, sz, vp]),
+        "ssak_comm_unique_id": (i32, [vp]),
+        "ssak_comm_create": (i32, [C.POINTER(vp), i32, i32, vp]),
+        "ssak_allreduce": (i32, [vp, vp, C.c_long, C.c_long, i32, vp]),
+        "ssak_comm_destroy": (i32, [vp]),
         "ssak_debug_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, C.c_long, vp, C.POINTER(f32), vp]),
         "ssak_debug_attention_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, i32, i32, i32, vp, vp]),
     }
@@ -316,6 +320,38 @@ def gemm_grouped(problems, stream_=None, dynamic_tiles=False):
                             int(Cout.dtype == torch.float32), 0, 1, 0.0, 0, 0, 0, 1, 0, int(dynamic_tiles))
         pa[i], pb[i], pc[i] = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
     check(lib.ssak_gemm_bf16_grouped(descs, n, pa, pb, pc, stream()))
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (``ssak_comm_*`` / ``ssak_allreduce``): what a host without torch.distributed uses for
+    the data-parallel exchange.  ``unique_id()`` on rank 0, the 128 bytes carried to the other ranks by the host's own means,
+    then ``Comm(world, rank, id)`` on every rank (collective)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(lib.ssak_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, world: int, rank: int, uid: bytes):
+        assert len(uid) == 128
+        self._h = C.c_void_p()
+        check(lib.ssak_comm_create(C.byref(self._h), int(world), int(rank), C.create_string_buffer(uid, 128)))
+        self.world, self.rank = world, rank
+
+    def all_reduce(self, t: torch.Tensor, offset: int = 0, count: int | None = None, stream_=None):
+        """In-place sum over ranks of ``t.view(-1)[offset : offset + count]`` (fp32 or bf16), asynchronous on the current stream."""
+        dt = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[t.dtype]
+        n = t.numel() - offset if count is None else count
+        check(lib.ssak_allreduce(self._h, ptr(t), int(offset), int(n), dt, stream() if stream_ is None else stream_))
+
+    def close(self):
+        if self._h:
+            check(lib.ssak_comm_destroy(self._h))
+            self._h = C.c_void_p()
 
 
 def prof_enable(mode: int):

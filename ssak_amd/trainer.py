@@ -121,6 +121,21 @@ class AdamW:
         self.step_count = int(sd["step"])
 
 
+class _EventWork:
+    """``wait()`` of an exchange launched through the C ABI: the current stream waits for the collective's event."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+def C_stream(s: torch.cuda.Stream):
+    import ctypes
+    return ctypes.c_void_p(s.cuda_stream)
+
+
 class Trainer:
     """One optimizer step per call; data-parallel when a process group is initialised.
 
@@ -133,11 +148,18 @@ class Trainer:
 
     def __init__(self, model: Wav2Vec2ForCTC, optimizer: AdamW, normalize_on_device: bool = True,
                  grad_exchange_dtype: str | None = None, optimizer_stream: bool | None = None, measure_stall: bool = False,
-                 per_rank_seed: bool = True):
+                 per_rank_seed: bool = True, exchange: str | None = None):
         """``grad_exchange_dtype``: "fp32" (default; or environment SSAK_DP_GRAD_DTYPE) or "bf16" -- the gradient buckets are
         rounded to bf16 for the all-reduce and widened again before the clip + update: half the bytes over xGMI (180 MB
-        instead of 361 MB per step for the base model) at bf16 rounding of the exchanged sums."""
+        instead of 361 MB per step for the base model) at bf16 rounding of the exchanged sums.
+        ``exchange``: "torch" (default; or environment SSAK_DP_EXCHANGE) = torch.distributed.all_reduce (backend nccl = RCCL), or
+        "c" = the library's own ``ssak_allreduce`` (include/ssak_hip.h: RCCL through the C ABI, the path a host without
+        torch.distributed takes; torch.distributed then only carries the 128-byte communicator id)."""
         self.model, self.opt = model, optimizer
+        self.exchange = exchange or os.environ.get("SSAK_DP_EXCHANGE", "torch")
+        if self.exchange not in ("torch", "c"):
+            raise ValueError("exchange must be 'torch' or 'c'")
+        self._comm = None
         self.grad_exchange_dtype = grad_exchange_dtype or os.environ.get("SSAK_DP_GRAD_DTYPE", "fp32")
         if self.grad_exchange_dtype not in ("fp32", "bf16"):
             raise ValueError("grad_exchange_dtype must be 'fp32' or 'bf16'")
@@ -181,6 +203,12 @@ class Trainer:
             # bucketed exchange: one async sum all-reduce per announced gradient range (a layer's matrices = 28 MB
             # for base), issued while the rest of the backward is still running; RCCL runs them on its own stream
             model.set_grad_ready_callback(self._on_grads_ready)
+            if self.exchange == "c":
+                uid = [hip.Comm.unique_id() if torch.distributed.get_rank() == 0 else None]
+                torch.distributed.broadcast_object_list(uid, src=0)
+                with torch.cuda.device(model.device):
+                    self._comm = hip.Comm(self.world, torch.distributed.get_rank(), uid[0])
+                    self._xstream = torch.cuda.Stream()  # the collectives' own stream: they overlap the rest of the backward
 
     def _on_grads_ready(self, offset: int, count: int):
         m = self.model
@@ -190,9 +218,22 @@ class Trainer:
             # ranges start at multiples of 8 elements for every supported topology; the cast runs on the compute stream,
             # behind the kernels that produced the range
             hip.check(hip.lib.ssak_cast_f32_bf16(hip.ptr(m.grads[offset:]), hip.ptr(self._g16[offset:]), count, hip.stream()))
-            work = torch.distributed.all_reduce(self._g16[offset:offset + count], async_op=True)
+            buf = self._g16
         else:
-            work = torch.distributed.all_reduce(m.grads[offset:offset + count], async_op=True)
+            buf = m.grads
+        if self._comm is not None:
+            # ssak_allreduce on the exchange stream, behind the kernels that produced the range; `work.wait()` = the waiting
+            # stream waits for the collective's event (what torch's async work object does)
+            with torch.cuda.device(m.device):
+                ready = torch.cuda.Event()
+                ready.record()
+                self._xstream.wait_event(ready)
+                self._comm.all_reduce(buf, offset, count, stream_=C_stream(self._xstream))
+                done = torch.cuda.Event()
+                done.record(self._xstream)
+            work = _EventWork(done)
+        else:
+            work = torch.distributed.all_reduce(buf[offset:offset + count], async_op=True)
         self._works.append((work, offset, count))
 
     def broadcast_parameters(self):

@@ -190,7 +190,7 @@ def test_trainer_bucketed_allreduce_single_rank(mods):
     x = torch.tensor(R.zero_mean_unit_var_norm([rng.standard_normal(8000).astype(np.float32) for _ in range(2)])).cuda()
     labels = torch.tensor(R.pad_labels([[3, 4, 5], [6, 7]])).cuda()
 
-    def run(distributed):
+    def run(distributed, exchange="torch"):
         model = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc), seed=11).train()
         model.load_state_dict(p)
         seen = []
@@ -198,7 +198,7 @@ def test_trainer_bucketed_allreduce_single_rank(mods):
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
         try:
-            tr = Trainer(model, AdamW(model, warmup_steps=0, lr=1e-3))
+            tr = Trainer(model, AdamW(model, warmup_steps=0, lr=1e-3), exchange=exchange)
             if distributed:
                 orig = tr._on_grads_ready
                 model.set_grad_ready_callback(lambda o, c: (seen.append((o, c)), orig(o, c)))
@@ -212,6 +212,10 @@ def test_trainer_bucketed_allreduce_single_rank(mods):
 
     p0, l0, _ = run(False)
     p1, l1, seen = run(True)
+    # the same buckets through the library's own ssak_allreduce (librccl.so dlopen'ed behind the C ABI, a communicator of one
+    # rank): the exchange a host without torch.distributed would run
+    p2, l2, seen2 = run(True, exchange="c")
+    assert abs(l0 - l2) <= 1e-5 * abs(l0) and (p0 - p2).abs().max().item() < 0.5e-3 and seen2 == seen
     # not bitwise: under a process group the clip norm is summed bucket by bucket as the all-reduces complete (a different fp32
     # summation order: 23.555115 vs 23.555113), the first update differs in the last bit of a few parameters, and one flipped
     # bf16 rounding of a shadow weight moves the SECOND step's gradients by bf16 noise (Adam turns that into fractions of lr)

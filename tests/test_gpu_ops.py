@@ -567,7 +567,7 @@ def test_gemm_b_direct_form_is_bit_identical(hip):
         frag = hip.gemm_fragment_b(Bs, N, K, b_kmajor=b_km)
         kw = dict(b_kmajor=b_km, lda=K, ldb=N if b_km else K, ldc=N, bias=bias, pads_are_zero=True)
         want = hip.gemm(A, Bs, torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), M, N, K, dynamic_tiles=True, **kw)
-        got = hip.gemm(A, Bs, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"), M, N, K, b_fragments=frag, **kw)
+        got = hip.gemm(A, Bs, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"), M, N, K, b_fragments=frag, dynamic_tiles=True, **kw)
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (M, N, K, b_km)
         ref = A.float() @ (Bs.float() if b_km else Bs.float().t()) + bias
         assert float((got.float() - ref).norm() / ref.norm()) < 4e-3

@@ -386,8 +386,8 @@ def test_train_cli_best_model_early_stopping_and_rotation(tmp_path, monkeypatch)
     script = iter([0.5, 0.4, 0.6, 0.7, 0.1, 0.1, 0.1, 0.1])
     real_eval = T.evaluate
 
-    def scripted(model, tok, waves, labels, batch_size):
-        m = real_eval(model, tok, waves, labels, batch_size)
+    def scripted(model, tok, waves, labels, batch_size, rank=0, world=1):
+        m = real_eval(model, tok, waves, labels, batch_size, rank, world)
         m["eval_wer"] = next(script)
         return m
 
@@ -476,7 +476,9 @@ def test_train_cli_sharded_evaluation_equals_single_process(tmp_path):
     """Every rank evaluates its contiguous shard of each validation batch (the reference's per_device_eval_batch_size =
     batch_size // num_devices, ssak/train/transformers/wav2vec_train.py:357) and one all-reduce of (edits, words, loss sum,
     utterances) gives the metrics: the initial evaluation of two ranks (gloo, one card) equals the single-process one -- word
-    error counts exactly, the loss to fp32 summation order -- on 11 utterances in batches of 4 (shards 2+2, 2+2, 2+1)."""
+    error counts exactly, the loss to fp32 summation order -- on 11 utterances in batches of 4 (shards 2+2, 2+2, 2+1).  The
+    layer-norm (XLSR) topology is used: it runs with the attention mask, so an utterance's logits do not depend on how far
+    its batch was padded (a group-norm model sees the padding -- there the reference's per-device batches differ too)."""
     import socket
     from oracle import w2v2_ref as R
     from ssak_amd import data as D
@@ -494,7 +496,7 @@ def test_train_cli_sharded_evaluation_equals_single_process(tmp_path):
             fw.write(f"utt{i}\t{kd}/audio/u{i}.wav\n")
             ft.write(f"utt{i} {synth_text(rng, 3, 8)}\n")
             fd.write(f"utt{i} {n / 16000:.3f}\n")
-    oc = R.W2V2Config.tiny().deterministic()
+    oc = R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True).deterministic()
     base = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc))
     base.load_state_dict(R.init_params(oc, 3))
     save_pretrained(base, D.CharTokenizer(VOCAB), str(tmp_path / "base"))
@@ -520,7 +522,7 @@ def test_train_cli_sharded_evaluation_equals_single_process(tmp_path):
     one_init, one_last = run(tmp_path / "one", 1)
     two_init, two_last = run(tmp_path / "two", 2)
     assert one_init["eval_wer"] == two_init["eval_wer"] and one_init["eval_wer"] > 0
-    assert abs(one_init["eval_loss"] - two_init["eval_loss"]) <= 1e-5 * abs(one_init["eval_loss"])
+    assert abs(one_init["eval_loss"] - two_init["eval_loss"]) <= 1e-4 * abs(one_init["eval_loss"])
     # after three data-parallel steps both runs hold (nearly) the same weights: the metrics of the final evaluation agree too
     assert abs(one_last["eval_loss"] - two_last["eval_loss"]) <= 2e-2 * abs(one_last["eval_loss"])
 
