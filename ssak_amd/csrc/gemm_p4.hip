@@ -169,13 +169,14 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
   //   this or the next output tile).  keep_stores: the previous epilogue's stores are still in flight behind this tile's operands.
   auto ktile = [&acc, &fa0, &fb0, &fa1, &fb1, &voa, &vob, &bias_vo, &fo_a, &fo_b, wbase](
                    auto zero_c, auto rn_c, auto bias_c, uint32_t& s_sa, uint32_t& s_sb, uint32_t& a_cur, uint32_t& b_cur, uint32_t koff_a,
-                   uint32_t koff_b, bool keep_stores, uint32_t bias_dst, const u32x4 ra, const u32x4 rb, const u32x4 rbias) __attribute__((always_inline)) {
+                   uint32_t koff_b, bool keep_stores, uint32_t bias_dst, const u32x4 ra, const u32x4 rb, const u32x4 rbias, int* ticket_ctr,
+                   uint32_t& ticket) __attribute__((always_inline)) {
     constexpr bool ZERO = decltype(zero_c)::value, READ_NEXT = decltype(rn_c)::value, BIAS = decltype(bias_c)::value;
     uint32_t n_sa = 0, n_sb = 0, a_nxt = 0, b_nxt = 0, a_cur_n = 0, b_cur_n = 0, wb_a = 0, wb_b = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // set 0 is in registers
     // ---- slice 0
     static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &fo_a, &fo_b, &a_cur, &b_cur, &s_sa, &s_sb, &n_sa, &n_sb, &a_nxt, &b_nxt, &a_cur_n, &b_cur_n,
-                        &wb_a, &wb_b, wbase, keep_stores](auto mc) __attribute__((always_inline)) {
+                        &wb_a, &wb_b, wbase, keep_stores, ticket_ctr, &ticket](auto mc) __attribute__((always_inline)) {
       constexpr int m = decltype(mc)::value, i = m / 8, j = m % 8;
       if constexpr (ZERO) P4_MFMA_Z(acc[j / 4][i][j % 4], fb0[j], fa0[i]);
       else P4_MFMA(acc[j / 4][i][j % 4], fb0[j], fa0[i]);
@@ -201,6 +202,15 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(MID_KEEP) : "memory");
       }
       if constexpr (m == 8 * NI - 3) asm volatile("s_barrier" ::: "memory");
+      if constexpr (ZERO && m == 8 * NI - 2) {
+        // ticket tile order: one lane requests the NEXT tile's ticket here, behind the wait and ahead of this K tile's LDS-DMA --
+        // the next K tile's counted wait (everything older than its youngest A tile) then covers the returning atomic, so no
+        // wait count anywhere has to know about it; the value is read two K tiles later (pre())
+        if (ticket_ctr != nullptr && threadIdx.x == 0) {
+          const uint32_t one = 1;
+          asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ticket_ctr), "v"(one) : "memory");
+        }
+      }
     });
     // ---- slice 1: groups of DS MFMAs: [fragment read | M0 write | LDS-DMA | ...]; DMA order: (bias,) B, then A
     static_for<8 * NI>([&acc, &fa0, &fb0, &fa1, &fb1, &voa, &vob, ra, rb, rbias, &bias_vo, a_nxt, b_nxt, wb_a, wb_b, koff_a, koff_b, bias_dst](
@@ -255,8 +265,24 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
   bool primed = false;
   int par = 0;                  // output-tile parity: which bias slot
   uint32_t s_sa = 0, s_sb = 0;  // byte offsets of the LDS stages of the current K tile's A (cycles through SA stages, across output tiles) / B
-  P4Tile cur = decode(min((int)blockIdx.x, ntiles - 1));
-  for (int t = blockIdx.x; t < ntiles;) {
+  // Tile order.  Static (tile_ctr == null, the single-GPU default): workgroup b takes logical ids b, b + grid, ...  Dynamic
+  // (ssak_gemm_desc.dynamic_tiles; data-parallel runs, as gemm_p8.hip): every tile is drawn from a per-XCD ticket counter
+  // (x = blockIdx.x & 7, ticket k -> logical id 8 k + x), so that a workgroup whose CU is held by another stream's kernel --
+  // the RCCL all-reduce of the previous layer's gradients -- takes fewer tiles instead of finishing last.  The ticket of the
+  // next tile is requested inside K tile 0 (ktile), published through LDS by pre() at K tile 2 and read at K tile 3 (one
+  // barrier in between); only the first ticket of a launch is waited for on the spot.
+  int* const tile_ctr = p.tile_ctr ? p.tile_ctr + (blockIdx.x & 7) : nullptr;
+  uint32_t ticket = 0;
+  volatile int* const ticket_lds = reinterpret_cast<volatile int*>(smem + LDS_BIAS + 2 * 4096);
+  int t_first = blockIdx.x;
+  if (tile_ctr) {
+    if (threadIdx.x == 0) *ticket_lds = atomicAdd(tile_ctr, 1);
+    __syncthreads();
+    t_first = 8 * __builtin_amdgcn_readfirstlane(*ticket_lds) + (int)(blockIdx.x & 7);
+    __syncthreads();
+  }
+  P4Tile cur = decode(min(t_first, ntiles - 1));
+  for (int t = t_first; t < ntiles;) {
     const P4Tile c = cur;
     const uint32_t bias_lds = bias_lds0 + par * 4096;
     const bool was_primed = primed;
@@ -287,10 +313,10 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
     }
     uint32_t a_cur = fo_a[1] + s_sa, b_cur = fo_b[1] + s_sb;
     // the next output tile: the tail of this one stages its first K tiles
-    const int t_next = t + (int)gridDim.x;
+    int t_next = t + (int)gridDim.x;  // (ticket order: known from K tile 3 on, pre())
     const bool full_rows = c.bm0 + BM <= p.M;  // (a tile with rows beyond M skips some epilogue stores: their count is not fixed)
-    const bool stage_next = EPI_EARLY && t_next < ntiles && full_rows;
-    if (t_next < ntiles) cur = decode(t_next);
+    bool stage_next = EPI_EARLY && t_next < ntiles && full_rows;
+    if (!tile_ctr && t_next < ntiles) cur = decode(t_next);
     const uint32_t bias_lds_next = bias_lds0 + (par ^ 1) * 4096;
     u32x4 ra = uni4(ra_v), rb = uni4(rb_v);
     BiasRegs<4> bias_regs[2];
@@ -299,7 +325,23 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
     int ka = SA - 1, kb = 1;  // (+ 1 in pre(): K tiles SA and 2 for k = 0)
     int k0a = c.k0, k0b = c.k0;  // K rotation of the output tile whose A / B is being staged
     uint32_t koff_a = 0, koff_b = 0;
+    int kcount = 0;
     auto pre = [&]() __attribute__((always_inline)) {
+      if (tile_ctr) {
+        if (kcount == 2) {
+          // (wave 0 passed K tile 1's counted wait: its ticket has returned)
+          if (threadIdx.x == 0) {
+            typedef __attribute__((address_space(3))) int lds_int;
+            const uint32_t a = (uint32_t)(uintptr_t)(lds_int*)ticket_lds;
+            asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(ticket) : "memory");
+          }
+        } else if (kcount == 3) {
+          t_next = 8 * __builtin_amdgcn_readfirstlane(*ticket_lds) + (int)(blockIdx.x & 7);
+          stage_next = EPI_EARLY && t_next < ntiles && full_rows;
+          if (t_next < ntiles) cur = decode(t_next);
+        }
+      }
+      ++kcount;
       if (++ka == nkt) {
         ka = 0;
         k0a = cur.k0;
@@ -327,13 +369,13 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
       koff_b = kpn ? koff_of(pb) : (uint32_t)pb * 128u;
     };
     pre();
-    ktile(T{}, T{}, F{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, was_primed, 0u, ra, rb, rbias);
+    ktile(T{}, T{}, F{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, was_primed, 0u, ra, rb, rbias, tile_ctr, ticket);
     for (int k = 1; k + 1 < nkt; ++k) {
       pre();
-      ktile(F{}, T{}, F{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, 0u, ra, rb, rbias);
+      ktile(F{}, T{}, F{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, 0u, ra, rb, rbias, nullptr, ticket);
     }
     pre();
-    ktile(F{}, F{}, T{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, bias_lds_next, ra, rb, rbias);
+    ktile(F{}, F{}, T{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, bias_lds_next, ra, rb, rbias, nullptr, ticket);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are read by compiler-generated code
     primed = stage_next;
 #pragma unroll
@@ -344,6 +386,13 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
     par ^= 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the last workgroup out leaves the counters at zero for the next launch on this stream (agent-scope atomics only, as gemm_p8.hip)
+  if (p.tile_ctr && threadIdx.x == 0) {
+    if (atomicAdd(p.tile_ctr + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicExch(p.tile_ctr + i, 0);
+    }
+  }
 }
 
 int p4_num_cu(int* out) {
@@ -360,7 +409,7 @@ int p4_num_cu(int* out) {
 template <int NI, int EPI>
 int launch_p4(const GemmParams& p, hipStream_t st) {
   constexpr int SA = NI <= 6 ? 3 : 2;  // three A stages where 160 KB of LDS hold them next to two B stages and the bias slots
-  constexpr int P4_LDS = SA * NI * 32 * 128 + 2 * 32768 + 2 * 4096;
+  constexpr int P4_LDS = SA * NI * 32 * 128 + 2 * 32768 + 2 * 4096 + 64;  // (+ the ticket word)
   static_assert(P4_LDS <= 160 * 1024, "LDS");
   auto kern = gemm_p4_kernel<NI, SA, EPI>;
   static bool attr_done = false;
@@ -385,8 +434,12 @@ int launch_p4(const GemmParams& p, hipStream_t st) {
     }
     slot = it->second;
   }
+  GemmParams q = p;
+  q.tile_ctr = nullptr;
+  if (ntiles > n_cu && n_cu % 8 == 0 && p.dynamic)
+    if (int rc = ssak_gemm_ticket_slot(st, &q.tile_ctr)) return rc;
   ProfScope prof_scope(slot, 2.0 * p.M * p.N * (double)p.K * p.nz, st);
-  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P4_THREADS, P4_LDS, st>>>(p);  // one persistent workgroup per CU
+  kern<<<dim3((unsigned)std::min<long>(ntiles, n_cu)), P4_THREADS, P4_LDS, st>>>(q);  // one persistent workgroup per CU
   SSAK_LAUNCH_CHECK();
   return SSAK_OK;
 }
@@ -411,7 +464,8 @@ int dispatch_p4(const GemmParams& p, int b_km, hipStream_t st) {
 // stays on gemm_p8.hip
 bool ssak_gemm_p4_supports(const void* params, int bm, int a_km, int b_km) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
-  if (a_km || b_km || p.split_k != 1 || p.dynamic) return false;
+  if (a_km || b_km || p.split_k != 1) return false;
+  if (p.dynamic && p.K < 6 * 64) return false;  // (the ticket of the next tile travels through K tiles 0 .. 3 ahead of the tail's staging)
   if (bm != 256 && bm != 192 && bm != 128) return false;
   if (p.K % 64 != 0 || p.K < 192 || p.N % 256 != 0) return false;
   if ((p.ldc & 7) || ((p.sc1 | p.sc2) & 7)) return false;

@@ -998,6 +998,8 @@ int launch_p8_grouped(const GemmParams& p, const P8Group& grp, hipStream_t st) {
 
 }  // namespace
 
+int ssak_gemm_ticket_slot(hipStream_t st, int** out) { return p8_ticket_slot(st, out); }
+
 int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStream_t st) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
   if (bm == 256) return dispatch_p8<4>(p, a_km, b_km, st);

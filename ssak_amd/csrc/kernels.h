@@ -183,7 +183,9 @@ int ssak_gemm_p8_launch(const void* params, int bm, int a_km, int b_km, hipStrea
 // transpose.hip: dst[i] [C][R] = src[i] [R][C]^T, n matrices in one launch
 int k_transpose_bf16_batched(int n, const bf16* const* src, bf16* const* dst, const int* R, const int* C, hipStream_t st);
 
-// gemm_p4.hip: the same tiles with four waves and a hand-scheduled main loop (K-contiguous A, K % 128 == 0, N % 256 == 0, static tile order)
+// ticket counters of the persistent GEMMs (eight per-XCD counters + the count of finished workgroups), one slot per (device, stream)
+int ssak_gemm_ticket_slot(hipStream_t st, int** out);
+// gemm_p4.hip: the same tiles with four waves and a hand-scheduled main loop (K-contiguous operands, K % 64 == 0, N % 256 == 0)
 bool ssak_gemm_p4_supports(const void* params, int bm, int a_km, int b_km);
 int ssak_gemm_p4_launch(const void* params, int bm, int b_km, hipStream_t st);
 // B-direct form: params->B = the fragment-ordered copy (k_gemm_fragment_b_batched), params->ext_b its bytes

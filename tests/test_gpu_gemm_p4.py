@@ -106,3 +106,32 @@ def test_p4_gelu_save_grad_matches_the_eight_wave_contract(hip):
     f = (fac.float() - 26.0) * (1.26 / 254.0)
     ferr = (f - x.grad).abs().max().item()
     assert ferr < 1.2e-2, ferr
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(15968, 3072, 768, 0), (15968, 2304, 768, 0), (40000, 768, 384, 192), (15968, 768, 3072, 0)])
+def test_p4_ticket_tile_order_bit_exact(hip, M, N, K, tile):
+    """ssak_gemm_desc.dynamic_tiles on the four-wave kernel (what the data-parallel trainers switch on): every tile drawn from
+    the per-XCD ticket counters, the next tile's ticket requested inside K tile 0 and read three K tiles later.  Multi-round
+    shapes, integer operands (bit-exact whatever the order), repeated launches on one stream (every launch leaves its counters
+    at zero) and two streams at once (separate counter slots)."""
+    A, W = _operands(M, N, K, M + 3 * N + K)
+    bias = torch.randint(-4, 5, (N,), generator=torch.Generator().manual_seed(2)).float()
+    ref = (A.float() @ W.float().T + bias).to(torch.bfloat16)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16).cuda()
+    _ran_on_p4(hip, lambda: hip.gemm(Ad, Wd, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, plan_tile=tile, dynamic_tiles=True))
+    assert torch.equal(C.cpu(), ref)
+    for _ in range(3):
+        C.fill_(float("nan"))
+        hip.gemm(Ad, Wd, C, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, plan_tile=tile, dynamic_tiles=True)
+        assert torch.equal(C.cpu(), ref)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    C1, C2 = torch.full_like(C, float("nan")), torch.full_like(C, float("nan"))
+    torch.cuda.synchronize()
+    for _ in range(2):
+        with torch.cuda.stream(s1):
+            hip.gemm(Ad, Wd, C1, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, plan_tile=tile, dynamic_tiles=True)
+        with torch.cuda.stream(s2):
+            hip.gemm(Ad, Wd, C2, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, plan_tile=tile, dynamic_tiles=True)
+    torch.cuda.synchronize()
+    assert torch.equal(C1.cpu(), ref) and torch.equal(C2.cpu(), ref)
