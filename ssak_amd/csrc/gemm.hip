@@ -1044,6 +1044,11 @@ extern "C" int ssak_gemm_bf16_grouped(const ssak_gemm_desc* descs, int n, const 
   p.drop_scale = 1.f;
   p.kt_per_split = ssak_cdiv(d0.K, BK);
   hipStream_t st = (hipStream_t)stream;
+  // (the four-wave loop with both operands K-major -- transposing reads into pinned fragment registers, a padded two-rows-per-
+  // block image -- was built and is bit-exact, but no faster than the eight-wave kernel here: 1 170 vs 1 206 TFLOP/s in situ.
+  // These launches stream ~1 GB of activations per 250-tile round and both kernels sit at ~1.7 us per K tile on the bytes
+  // a CU can keep in flight with two 64 KB stages, not on the matrix pipe: tools/probes/gemm_p4w_kmajor.hip.txt,
+  // profiles/r04_gemm_p4w_kmajor_not_adopted.log)
   const int rc = ssak_gemm_p8_launch_grouped(&p, n, A, B, C, Ms, Ns, lda, ldb, ldc, ea, eb, d0.a_kmajor, d0.b_kmajor, st);
   return rc;
 }

@@ -437,9 +437,25 @@ __device__ __forceinline__ bool epilogue_direct_ok(const GemmParams& p, int bm0,
 // (bias / alpha only -- the qkv, output and feed-forward-down projections and every plain dX product), the plain fp32 store
 // (weight gradients, optionally accumulating) and GELU without a saved pre-activation (the frozen conv stack).
 constexpr int P8_EPI_PLAIN_BF16 = 100, P8_EPI_PLAIN_F32 = 101, P8_EPI_GELU_ONLY = 102;
+// SSAK_EPI_MUL_AUX: the 16 bytes of factor codes of every 16-row group of a wave tile, loaded ahead of the arithmetic (one load per
+// group, all in flight together).  Inside the per-group loop each load's round trip (L2 / HBM: ~1-2 us) was exposed -- the groups
+// are kept apart by scheduling fences -- and made the feed-forward dX product's epilogue ~9 us per tile.
+template <int MI>
+struct FqCodes {
+  u32x4 w[MI];
+};
+template <int MI>
+__device__ __forceinline__ void load_fq_codes(const GemmParams& p, FqCodes<MI>& c, int bm0, int bn0, int wm0, int wn0, int lane, int z1, int z2) {
+  const int lm = lane & 15, lq = lane >> 4;
+  const int rows_valid = p.M - (bm0 + wm0 + lm);
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(p.aux_in) + z1 * p.sc1 + z2 * p.sc2 + (long)(bm0 + wm0 + lm) * p.ldc + bn0 + wn0 + 16 * lq;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) c.w[i] = 16 * i < rows_valid ? *reinterpret_cast<const u32x4*>(src + (long)16 * i * p.ldc) : (u32x4){0u, 0u, 0u, 0u};
+}
 template <int MI, int EPI = -1>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 (&acc)[MI][4], const BiasRegs<4>& br, int bm0,
-                                                     int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split) {
+                                                     int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split,
+                                                     const FqCodes<MI>* codes = nullptr) {
   constexpr bool GENERAL = EPI < 0;
   const int lm = lane & 15, lq = lane >> 4;
   const int rows_valid = p.M - (bm0 + wm0 + lm);  // this lane's row 16 * i + lm exists iff 16 * i < rows_valid
@@ -525,7 +541,14 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
         }
     } else if (EPI == SSAK_EPI_MUL_AUX) {
       float f[4][4];  // one 16-byte load of this lane's row segment of codes, transposed back to the accumulator layout
-      load_fq_rows(reinterpret_cast<const uint8_t*>(p.aux_in) + orow + 16 * lq, rowok, p.fq_a, p.fq_b, f);
+      if (codes) {
+        uint32_t q[4] = {codes->w[i][0], codes->w[i][1], codes->w[i][2], codes->w[i][3]};
+        xpose4(q[0], q[1], q[2], q[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fq_unpack4(q[j], p.fq_a, p.fq_b, f[j]);
+      } else {
+        load_fq_rows(reinterpret_cast<const uint8_t*>(p.aux_in) + orow + 16 * lq, rowok, p.fq_a, p.fq_b, f);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll

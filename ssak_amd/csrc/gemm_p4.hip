@@ -378,9 +378,19 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
     ktile(F{}, F{}, T{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, bias_lds_next, ra, rb, rbias, nullptr, ticket);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are read by compiler-generated code
     primed = stage_next;
+    if constexpr (EPI == SSAK_EPI_MUL_AUX) {
+      // the factor codes of both halves in flight before any arithmetic (the fragment registers are free now)
+      FqCodes<NI> codes[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      gemm_epilogue_direct<NI, EPI>(p, acc[h], bias_regs[h], c.bm0, c.bn0, wr * 16 * NI, wc * 128 + 64 * h, lane, c.z, c.z1, c.z2, 0);
+      for (int h = 0; h < 2; ++h) load_fq_codes<NI>(p, codes[h], c.bm0, c.bn0, wr * 16 * NI, wc * 128 + 64 * h, lane, c.z1, c.z2);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        gemm_epilogue_direct<NI, EPI>(p, acc[h], bias_regs[h], c.bm0, c.bn0, wr * 16 * NI, wc * 128 + 64 * h, lane, c.z, c.z1, c.z2, 0, &codes[h]);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        gemm_epilogue_direct<NI, EPI>(p, acc[h], bias_regs[h], c.bm0, c.bn0, wr * 16 * NI, wc * 128 + 64 * h, lane, c.z, c.z1, c.z2, 0);
+    }
     if (!primed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dummies (and whatever the epilogue left) before LDS is re-staged
     t = t_next;
     par ^= 1;
@@ -465,6 +475,15 @@ int dispatch_p4(const GemmParams& p, int b_km, hipStream_t st) {
 bool ssak_gemm_p4_supports(const void* params, int bm, int a_km, int b_km) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
   if (a_km || b_km || p.split_k != 1) return false;
+  // the feed-forward up-projection's epilogue (GELU + GELU' + dropout hash + 8-bit codes: ~22 VALU instructions per element) is
+  // VALU-issue-bound, and a lone wave per SIMD issues a VALU instruction every ~4.3 cycles where two waves share 2: the
+  // eight-wave kernel runs it ~100 us per step faster (same-box A/B, profiles/r04_ab_ffn_up_kernel.log)
+  if (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) return false;
+  // ... and the general epilogue form (dropout / column sums / GELU with a saved pre-activation / fp32 out: every mode compiled into
+  // one body) does not fit next to 256 accumulators without scratch on 256-row tiles: those stay on the eight-wave kernel too
+  const bool lean = p.epilogue == SSAK_EPI_MUL_AUX ||
+                    (!p.drop_thresh && !p.colsum && !p.out_f32 && !p.accumulate && (p.epilogue == SSAK_EPI_NONE || (p.epilogue == SSAK_EPI_GELU && !p.aux_out)));
+  if (!lean && bm == 256) return false;
   if (p.dynamic && p.K < 6 * 64) return false;  // (the ticket of the next tile travels through K tiles 0 .. 3 ahead of the tail's staging)
   if (bm != 256 && bm != 192 && bm != 128) return false;
   if (p.K % 64 != 0 || p.K < 192 || p.N % 256 != 0) return false;

@@ -81,7 +81,7 @@ def test_p4_toeplitz_rows(hip):
     wk = w.permute(0, 2, 1).contiguous().view(Co, k * Cc)
     y = torch.empty(Bn, Tout, Co, dtype=torch.float32).cuda()
     xd, wd = x.cuda(), wk.cuda()
-    _ran_on_p4(hip, lambda: hip.gemm(xd, wd, y, Tout, Co, k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Co, nb1=Bn, sa=(Tin * Cc, 0), sc=(Tout * Co, 0), plan_tile=256))
+    _ran_on_p4(hip, lambda: hip.gemm(xd, wd, y, Tout, Co, k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Co, nb1=Bn, sa=(Tin * Cc, 0), sc=(Tout * Co, 0), plan_tile=192))
     assert torch.equal(y.cpu(), ref)
 
 
