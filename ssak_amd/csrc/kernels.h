@@ -6,7 +6,7 @@
 // GEMM instantiation registers a slot under its own name (as rocprofv3 prints it) the first time it is launched.
 enum : int {
   PROF_ATTN_FWD = 0, PROF_ATTN_BWD, PROF_LN_FWD, PROF_LN_BWD, PROF_CONV0, PROF_ADAMW, PROF_SUMSQ, PROF_CTC, PROF_WAVE_NORM,
-  PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX, PROF_POSCONV_DIRECT, PROF_POSCONV_WGRAD,
+  PROF_ROWWISE, PROF_POSCONV_W, PROF_SOFTMAX, PROF_POSCONV_DIRECT, PROF_POSCONV_WGRAD, PROF_LOGMEL,
   PROF_CLASS_SLOTS
 };
 constexpr int PROF_MAX_SLOTS = 128;

@@ -314,11 +314,14 @@ def test_no_freeze_layer_norm_feature_encoder_gradients(mods):
 
 
 def test_fragment_ordered_weights_change_no_bit(mods):
-    """SSAK_W2V2_OPT_FRAGMENT_WEIGHTS (default on): a training forward copies the kept layers' projection weights into the
-    B-direct GEMM's fragment order and six products per layer read them instead of staging the weight through LDS.  Same
-    accumulation order, so logits and every gradient must be BIT-identical to the option switched off -- with LayerDrop
-    (a dropped layer's copies are not refreshed and not read), dropout, and across an optimizer-style weight change between
-    two steps (the copies are refreshed by every training forward)."""
+    """SSAK_W2V2_OPT_FRAGMENT_WEIGHTS (opt-in): a training forward copies the kept layers' projection weights into the
+    B-direct GEMM's fragment order and the forward products that pay read them instead of staging the weight through LDS.
+    Since round 4 the option's off state runs those products on the four-wave kernel, whose K order is rotated per row
+    panel, so the two states differ by bf16 summation-order noise, not by a bit pattern: logits and every gradient must agree
+    to that noise (a wrong fragment map, a stale copy or a copy of a dropped layer gives O(1) errors) -- with LayerDrop (a
+    dropped layer's copies are not refreshed and not read), dropout, and across an optimizer-style weight change between two
+    steps (the copies are refreshed by every training forward).  The fragment form itself is bit-exact against fp32 on
+    integer operands in tests/test_gpu_ops.py."""
     import ssak_amd.hip as hip
     Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
     oc = R.W2V2Config.base(num_hidden_layers=3)
@@ -350,8 +353,9 @@ def test_fragment_ordered_weights_change_no_bit(mods):
     assert hip.gemm_uses_fragments(B * 499, 768, 3072, pads_are_zero=True)
     for (lg1, g1), (lg0, g0) in zip(*outs):
         assert torch.isfinite(g1).all()
-        assert torch.equal(lg1, lg0)
-        assert torch.equal(g1, g0)
+        e_l = float((lg1.float() - lg0.float()).norm() / lg0.float().norm())
+        e_g = float((g1.float() - g0.float()).norm() / g0.float().norm())
+        assert e_l < 5e-3 and e_g < 3e-2, (e_l, e_g)
 
 
 @pytest.mark.parametrize("geometry", ["base_cg48", "xlsr_cg64"])
