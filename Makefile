@@ -7,7 +7,8 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := ssak_amd/csrc
-OBJ ?= build/obj
+# (DEV objects in their own directory: a release build after a DEV build must not link objects that read the environment)
+OBJ ?= build/obj$(if $(DEV),_dev,)
 LIB ?= ssak_amd/lib/libssak_hip.so
 # experiment builds next to the product: make OBJ=build/obj_x LIB=tools/ab_x.so EXTRA=-DSOME_VARIANT
 EXTRA ?=

@@ -261,15 +261,18 @@ int ssak_attention_fwd(const void* qkv, void* ctx, float* lse, const int32_t* kl
 int ssak_attention_bwd(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx, float* delta,
                        void* dqkv, int B, int F, int nh, int H, float drop_p, uint64_t seed, uint32_t stream_id, int mode,
                        void* stream);
-/* `mode` of the backward (per call; the engine takes it from its handle, ssak_w2v2_set_option): SSAK_ATTN_BWD_DEFAULT /
- * SSAK_ATTN_BWD_TWO_KERNEL = two kernels (dQ; dK + dV), each recomputing P; SSAK_ATTN_BWD_FUSED = one fused pass that evaluates
- * P, the dropout words and dS once (40 % fewer VALU instructions, five matrix products instead of seven): a workgroup per head
- * walks the keys in blocks and adds each block's dQ tiles onto what it stored for the previous blocks (fixed order, no atomics,
- * bit-reproducible).  Parity-tested against the two-kernel form; slower at the train-step shape B = 32 today, 9-11 % ahead at
- * B = 64. */
+/* `mode` of the backward: SSAK_ATTN_BWD_DEFAULT = SSAK_ATTN_BWD_TWO_KERNEL = two kernels (dQ; dK + dV), each recomputing P from the
+ * saved log-sum-exp.  (Value 2, a fused single-pass form that lost to this one at the train step's shape, was removed in ABI 400:
+ * SSAK_ERR_ARG.) */
 #define SSAK_ATTN_BWD_DEFAULT 0
 #define SSAK_ATTN_BWD_TWO_KERNEL 1
-#define SSAK_ATTN_BWD_FUSED 2
+/* As ssak_attention_bwd, and bias_grad[3H] += the column sums of dqkv -- the gradient of the q|k|v projection bias (the Linear layers
+ * of Wav2Vec2Attention, modeling_wav2vec2.py:500-548) -- summed inside the two kernels from the rows they hold (deterministic: one
+ * partial row per workgroup in `workspace`, one fixed-order second stage), instead of a pass that reads dqkv again. */
+size_t ssak_attention_bwd_bias_workspace_bytes(int B, int F, int H);
+int ssak_attention_bwd_bias(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx, float* delta,
+                            void* dqkv, float* bias_grad, int B, int F, int nh, int H, float drop_p, uint64_t seed,
+                            uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- a11: optimizer tail (clip_grad_norm_ -> AdamW), flat fp32 buffers ----------------------
  * Replaces torch.nn.utils.clip_grad_norm_(max 1.0) + torch.optim.AdamW.step as driven by HF Trainer
@@ -376,7 +379,7 @@ int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begi
 /* Per-handle execution options (nothing here changes results beyond rounding; no process-wide switches):
  * SSAK_W2V2_OPT_DYNAMIC_TILES  0 / 1: ssak_gemm_desc.dynamic_tiles of every product the engine launches -- the data-parallel
  *                              trainers set it, RCCL's kernels share the chip with the persistent GEMMs;
- * SSAK_W2V2_OPT_ATTENTION_BWD  SSAK_ATTN_BWD_*: the form of the fused attention backward;
+ * SSAK_W2V2_OPT_ATTENTION_BWD  SSAK_ATTN_BWD_* (one form since ABI 400; kept so that callers need not change);
  * SSAK_W2V2_OPT_POSCONV_DIRECT  1 (default) / 0: the grouped positional convolution (forward, input gradient and weight gradient)
  *                              as direct convolutions with the input rows resident in LDS (group widths 48 and 64) or as the
  *                              Toeplitz GEMMs of rounds 1-2 (kept for other geometries and as the comparison path of the tests);

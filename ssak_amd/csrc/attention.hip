@@ -42,6 +42,7 @@ struct AttnParams {
   const bf16* dctx;    // [B*F, H]    backward input
   float* delta;        // [B, nh, F]  rowsum(dO * O)
   bf16* dqkv;          // [B*F, 3H]   backward output
+  float* bias_part;    // [B * blocks, 3H] or null: column sums of this workgroup's rows of dqkv (the q|k|v bias gradient's first stage)
   int B, F, nh, H, Fp;
   float scale;
   uint64_t seed;
@@ -188,6 +189,36 @@ __device__ __forceinline__ AttnBlock attn_block() {
   r.h = bh % nh;
   return r;
 }
+
+// Column sums of a workgroup's output rows, for the q|k|v bias gradient (the separate column-sum pass read all of dqkv again:
+// 74 MB per layer).  `acc` is an output tile in the transposed orientation all three gradients use (row = d = 16 i + 4 g + r on
+// the registers, output row on lane & 15), already rounded to bf16 like the stored values and zero for rows that are not stored.
+// 16-lane butterflies, the four waves through LDS (the streamed tiles are dead: one barrier first), one float per d written to
+// the workgroup's slot -- no atomics, fixed summation order.
+__device__ __forceinline__ void bias_partial(float (&cs)[4][4], char* smem, float* dst /* slot row + column base */, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = cs[i][r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      cs[i][r] = v;
+    }
+  float* red = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave * HD + 16 * i + 4 * (lane >> 4) + r] = cs[i][r];
+  }
+  __syncthreads();
+  if (wave == 0) dst[lane] = (red[lane] + red[HD + lane]) + (red[2 * HD + lane] + red[3 * HD + lane]);
+}
+__device__ __forceinline__ float bf16_round(float v) { return (float)(bf16)v; }
 
 // ================================================================================================ forward
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -513,6 +544,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
       *reinterpret_cast<bf16x4*>(dst + 16 * i) = o;
     }
   }
+  if (p.bias_part) {  // (uniform)
+    float cs[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int qs = 0; qs < NQS; ++qs) v += qrow[qs] < F ? bf16_round(dq[qs][i][r]) : 0.f;
+        cs[i][r] = v;
+      }
+    bias_partial(cs, smem, p.bias_part + ((long)b * gridDim.x + ab.blk) * ld + h * HD, wave, lane);
+  }
 }
 
 // dK, dV: workgroup = 128 keys of one (b, h) (4 waves x 32 keys); sweeps the queries in tiles of 64.
@@ -698,426 +742,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       *reinterpret_cast<bf16x4*>(dvd + 16 * i) = c;
     }
   }
-}
-
-// ================================================================================================ fused backward
-// ONE pass over the scores for dQ, dK and dV.  The two-kernel form evaluates P (exp), the dropout words and dS once per
-// kernel and runs seven matrix products where five are algorithmic; both kernels are VALU-bound (rocprofv3: ~22 VALU
-// instructions per score element, MFMA busy 19-24 %), so the element-wise work is what a fused form halves (measured:
-// 36.7 M VALU instructions per launch against 27.6 M + 35.1 M, MFMA-busy cycles 62.9 M against 88 M).
-//
-//   workgroup = one (b, h), 4 waves, two workgroups per CU; it walks the keys in blocks of 128 (a wave owns 32 keys of the
-//   block: K and V fragments and the dK / dV accumulators stay in registers) and, per block, sweeps the queries 32 at a time.
-//   Orientation of the dK/dV kernel: S[q][key] = Q K^T, dP[q][key] = dO V^T with the key on the lane, so P*keep and dS are the
-//   B operands of dV^T = dO^T Pd and dK^T = Q^T dS (contraction over the 32 queries of the step: the accumulator row index).
-//   dQ needs the contraction over KEYS, which sit on the lanes: every wave writes its dS block (bf16) into a [key][q] tile in
-//   LDS, and after a barrier wave w forms dQ^T[16 d of block w][32 q] = K^T dS^T over the 128 keys of the block -- the K^T
-//   fragments (one 16 x 128 strip per wave) stay in registers for the whole block, the dS^T fragments come back through
-//   ds_read_b64_tr_b16.  A step's dQ tile is complete for this key block when it is formed: the first block stores it (bf16), a
-//   later block reads the stored value back, adds and stores -- same workgroup, fixed order, no atomics.
-//   What was measured on the way (B = 32, F = 499, 12 heads; the two-kernel form: 149 us without / 166 us with dropout):
-//   * a head split over two workgroups (256 keys each) adding dQ tiles with global_atomic_pk_add_bf16 -- correct and
-//     deterministic (two addends commute) -- 254 us: the 12 M packed adds of a launch alone take 110 us, the L2 retires them a
-//     dword at a time;
-//   * one 8-wave workgroup per CU, 256-key blocks, read-add-store: 168 / 183 us.  Counters: every pipe does less than in the
-//     two-kernel form but they run one after the other (MFMA 19 % + LDS 26 % + VALU ~55 % of the CU-busy cycles): with all
-//     eight waves between the same two barriers nothing overlaps, and 384 heads on 256 CUs are two rounds;
-//   * this form, two independent 4-wave workgroups per CU as the two-kernel form has: 184 / 193 us.  The skeleton alone (no
-//     element-wise math, no dQ phase) takes 125 us: two barriers per 1024 score elements per wave (the two-kernel form: one per
-//     2048) leave every wave in the same phase, so the LDS bursts, the MFMA blocks and the VALU work of a step queue up one
-//     behind the other.  At B = 64 (768 heads, whole rounds) the 8-wave form is 9-11 % ahead of the two-kernel form, at
-//     B = 32 behind.  NOT the default (mode SSAK_ATTN_BWD_FUSED of ssak_attention_bwd / the engine option selects it;
-//     parity-tested against the two-kernel form for every shape class).  A producer / consumer wave-specialised variant (waves
-//     that only do S, dP and the element-wise math next to waves that only run the dK / dV / dQ products, P and dS handed over
-//     through double-buffered LDS tiles) was built in round 2, measured at 195-205 us and removed in round 3.
-//   Pipeline: the query tiles (Q and dO as row and transpose images, O rows, lse) run through three LDS stages filled by LDS-DMA
-//   two steps ahead with counted vmcnt waits; raw s_barriers (__syncthreads() drains vmcnt(0)) and ds_read_b64_tr_b16 as inline
-//   asm (the builtin makes the compiler drain the DMA pipeline before every read).  The wait for tile t+1 sits in front of the
-//   step's SECOND barrier (the dS^T exchange), after which its row statistics are formed from LDS by the wave that owns 8 of
-//   the 32 rows: delta = sum_d dO O (v_dot2 + an 8-lane DPP sum) and lse' = lse * log2 e - log2 scale.
-//   Softmax scale: P' = P * scale comes out of the exponent, so dS = P' (dPd - delta) needs no multiply, and dV is accumulated
-//   from P' keep and rescaled by 1 / scale once at the end.  Keys beyond the key length start their S accumulator at -3e38
-//   (exp2 -> 0) instead of a select per element.
-constexpr int FQ = 32;                         // queries per step
-constexpr int FNW = 4;                         // waves per workgroup
-constexpr int FK = 32 * FNW;                   // keys per block
-constexpr int FT = FQ * HD * 2;                // 4 KiB: one staged image of 32 rows x 128 B
-constexpr int F_NST = 3;                       // stages
-constexpr int F_STAGE = 5 * FT + 512;          // Q rows | Q transpose | dO rows | dO transpose | O rows | lse (256 B) | 4-byte dummies (256 B)
-constexpr int F_STAT = 3 * 64 * 4;             // x 2: lse'[64] | delta[64] | dropout row seed[64]
-constexpr int F_DST = FK * FQ * 2;             // 8 KiB: dS^T tile, [key][32 q] (rows of 64 B), 8-byte chunk ch of key row r at ch ^ dst_swz(r)
-constexpr int F_LDS = F_NST * F_STAGE + 2 * F_STAT + F_DST;
-static_assert(F_NST * F_STAGE >= FK * HD * 2, "the K transpose image of a block's prologue aliases the stages");
-static_assert(2 * F_LDS <= 160 * 1024, "two workgroups per CU");
-
-// one 1-KiB piece (8 rows x 128 B) of a row / transpose image; `r0` = first image row of the piece
-__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rsrc, char* lds_img, uint32_t col_byte, long ld_bytes, int row0,
-                                          int nrows_total, bool transpose_image, int piece, int lane) {
-  const int S = piece * 64 + lane;
-  const int r = S >> 3, pc = S & 7;
-  const int c = transpose_image ? (pc ^ (r & 6)) : (pc ^ ((r >> 1) & 7));
-  const int gr = row0 + r;
-  const uint32_t off = gr < nrows_total ? (uint32_t)((long)gr * ld_bytes + col_byte + c * 16) : 0x80000000u;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_img + piece * 1024), 16, off, 0, 0, 0);
-}
-// dS^T tile swizzle: a transposing read takes rows 4 g + q4 (chunk 4 qh + p4), a write rows (lane & 15) (chunk 4 qh + g): row
-// bits 2 and 3 go to chunk bits 2 and 1, which spreads either over all 64 banks per 32 lanes (an earlier (r >> 2 & 3) << 1
-// left the reads two-way conflicted: 48 conflict cycles per wave and step)
-__device__ __forceinline__ int dst_swz(int r) { return (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1); }
-
-// ds_read_b64_tr_b16 as inline asm: for the builtin the compiler cannot tell the read from the LDS-DMA writes in flight and
-// drains vmcnt(0) in front of it (the two-kernel form pays that in the middle of every tile).  Ordering here is by the
-// counted wait + barrier at the top of a step; the caller waits lgkmcnt(0) before it uses the values.  OFF = immediate
-// byte offset: one address register serves every fragment of a phase.
-template <int OFF>
-__device__ __forceinline__ s16x4 tr_read(uint32_t addr) {
-  s16x4 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-__device__ __forceinline__ uint32_t lds_addr(const char* a) {
-  typedef __attribute__((address_space(3))) char lds_char;
-  return (uint32_t)(uintptr_t)(lds_char*)a;
-}
-__device__ __forceinline__ bf16x8 join8(const s16x4& lo, const s16x4& hi) {
-  s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-// byte offset of this lane's ds_read_b64_tr_b16 inside a transpose image (rows of 128 B) for column block ci, first tile row
-// 0: the element order is frag_cols_perm's (j < 4: row 4 g + j, j >= 4: row 16 + 4 g + j - 4; the second read is + 16 rows)
-__device__ __forceinline__ int tr_img_off(int ci, int lane) {
-  const int g = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-  const int r = 4 * g + q4;
-  const int ch = 2 * ci + (p4 >> 1);
-  return r * 128 + ((ch ^ (r & 6)) << 4) + (p4 & 1) * 8;
-}
-// ... inside the dS^T tile (rows of 64 B = 32 queries of one key): column q = 16 * qh + (lane & 15), key rows 4 g + j | + 16
-__device__ __forceinline__ int tr_dst_off(int qh, int lane) {
-  const int g = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-  const int r = 4 * g + q4;
-  const int ch = 4 * qh + p4;
-  return r * 64 + ((ch ^ dst_swz(r)) << 3);  // rows + 16 / + 32 keep bits 2 and 3: same swizzle
-}
-
-#define ATT_BARRIER()                    \
-  do {                                   \
-    __builtin_amdgcn_sched_barrier(0);   \
-    __builtin_amdgcn_s_barrier();        \
-    __builtin_amdgcn_sched_barrier(0);   \
-  } while (0)
-#define ATT_WAIT_LDS()                                      \
-  do {                                                      \
-    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */    \
-    __builtin_amdgcn_sched_barrier(0);                      \
-  } while (0)
-
-// N fragment pairs at addr + BASE + i * STRIDE (and + HI for the second half of each)
-template <int BASE, int STRIDE, int HI, int... I>
-__device__ __forceinline__ void tr_seq(uint32_t addr, s16x4* lo, s16x4* hi, std::integer_sequence<int, I...>) {
-  ((lo[I] = tr_read<BASE + I * STRIDE>(addr), hi[I] = tr_read<BASE + I * STRIDE + HI>(addr)), ...);
-}
-
-template <bool DROP>
-__global__ __launch_bounds__(64 * FNW, 2) void attn_bwd_fused_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.x, b = blockIdx.y;
-  const int F = p.F, H = p.H;
-  const long ld = 3L * H;
-  const bf16* base = p.qkv + (long)b * F * ld;
-  const int kl = p.klens ? min(max(p.klens[b], 0), F) : F;
-  const int nqt = (F + FQ - 1) / FQ, nkb = (F + FK - 1) / FK;
-  __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_lse = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + ((long)b * p.nh + h) * F), 0, F * 4, 0x00020000);
-  const uint32_t qcol = (uint32_t)(h * HD * 2), kcol = (uint32_t)((H + h * HD) * 2);
-  const int g = lane >> 4;
-  float* const stat0 = reinterpret_cast<float*>(smem + F_NST * F_STAGE);
-  char* const dst_tile = smem + F_NST * F_STAGE + 2 * F_STAT;
-
-  const float c2 = p.scale * 1.4426950408889634f;
-  const float log2scale = __log2f(p.scale);
-  const uint32_t thi = p.thresh16 << 16;
-  const int par = lane & 1;  // = parity of this lane's keys
-  // per-lane read offsets inside the transpose images (the stage base is added per step) and the dS^T tile (per query sub-tile)
-  int off_tr[4];
+  if (p.bias_part) {  // (uniform)
+    float* slot = p.bias_part + ((long)b * gridDim.x + ab.blk) * ld + h * HD;
+    float cs[4][4];
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci) off_tr[ci] = tr_img_off(ci, lane);
-  const uint32_t dst_rd[2] = {lds_addr(dst_tile) + tr_dst_off(0, lane), lds_addr(dst_tile) + tr_dst_off(1, lane)};
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-
-  // LDS-DMA per wave and step: five 16-byte slots (slot s = 5 wave + j < 20: piece (s & 3) of image (s >> 2)) + one 4-byte
-  // instruction (wave 0: the 32 lse values; the others a dummy with an out-of-range source), so that every wave issues the
-  // same count and the issue has no branches.  Per lane the source offset is a constant + qt * (bytes per tile); rows beyond
-  // F fall outside the buffer descriptor's range and come back as zeros.
-  uint32_t dma_off[5];
-  uint32_t dma_step[5], dma_dst[5];
-  __amdgpu_buffer_rsrc_t dma_rs[5];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int slot = wave * 5 + j;  // uniform
-    const int img = slot >> 2, piece = slot & 3;
-    const int S = piece * 64 + lane;
-    const int r = S >> 3, pc = S & 7;
-    const bool tr = img == 1 || img == 3;
-    const int c = tr ? (pc ^ (r & 6)) : (pc ^ ((r >> 1) & 7));
-    const long row_bytes = slot < 8 ? ld * 2 : (long)H * 2;
-    dma_off[j] = (uint32_t)(r * row_bytes + qcol + c * 16);
-    dma_step[j] = (uint32_t)(FQ * row_bytes);
-    dma_dst[j] = (uint32_t)(img * FT + piece * 1024);
-    const void* bp = slot < 8 ? (const void*)base : slot < 16 ? (const void*)(p.dctx + (long)b * F * H) : (const void*)(p.ctx + (long)b * F * H);
-    const long bytes = slot < 8 ? (long)F * ld * 2 : (long)F * H * 2;
-    dma_rs[j] = __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, (int)bytes, 0x00020000);
-  }
-  const uint32_t lse_off = (wave == 0 && lane < FQ) ? (uint32_t)(lane * 4) : 0x80000000u;
-  const uint32_t lse_dst = wave == 0 ? (uint32_t)(5 * FT) : (uint32_t)(5 * FT + 256);
-  auto issue = [&](int qt, int stage) {
-    char* const s0 = smem + stage * F_STAGE;
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rs[j], (lds_void_t*)(s0 + dma_dst[j]), 16, dma_off[j] + (uint32_t)qt * dma_step[j], 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lse, (lds_void_t*)(s0 + lse_dst), 4, lse_off + (uint32_t)qt * (uint32_t)(FQ * 4), 0, 0, 0);
-  };
-  // Row statistics of tile qt from its stage (landed and published by a barrier), by the wave that owns rows 8 w + (lane >> 3):
-  // delta = sum_d dO O (8 lanes x 8 d), lse' = lse * log2 e - log2 scale (+inf for a row without a valid key); row seeds by wave 3
-  auto rows_stat = [&](int qt, int stage, int sbuf) {
-    const char* const s0 = smem + stage * F_STAGE;
-    const int r = 8 * wave + (lane >> 3), part = lane & 7;
-    const int o16 = r * 128 + ((part ^ ((r >> 1) & 7)) << 4);
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(s0 + 2 * FT + o16);
-    const bf16x8 o = *reinterpret_cast<const bf16x8*>(s0 + 4 * FT + o16);
-    float v = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) v = __builtin_amdgcn_fdot2_f32_bf16((bf16x2_t){a[e], a[e + 1]}, (bf16x2_t){o[e], o[e + 1]}, v, false);
-    v += dpp_f<0xB1, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E, 0xf>(0.f, v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141, 0xf>(0.f, v);  // row_half_mirror: every lane holds its 8-lane total
-    if (part == 0) {
-      const float ls = reinterpret_cast<const float*>(s0 + 5 * FT)[r];  // (zero for rows beyond F)
-      float* st = stat0 + sbuf * 3 * 64 + r;
-      st[0] = ls > -INFINITY ? fmaf(ls, 1.4426950408889634f, -log2scale) : INFINITY;
-      st[64] = v;
-    }
-    if (DROP && wave == FNW - 1 && lane < FQ)
-      reinterpret_cast<uint32_t*>(stat0)[sbuf * 3 * 64 + 128 + lane] = drop_rowseed(p, b, h, qt * FQ + lane);
-  };
-
-#pragma unroll 1
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int key0 = kb * FK;
-    // ---- block prologue: this wave's keys as B operands of S and dP; the K^T strip of the dQ phase through a transpose image
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the previous block's pipeline and stores have drained
-    ATT_BARRIER();
-    int krow[2];
-    bf16x8 kf[2][2], vf[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      krow[ks] = key0 + 32 * wave + 16 * ks + (lane & 15);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        kf[ks][kk] = load_row_frag(base + H + h * HD, ld, krow[ks], F, kk, lane);
-        vf[ks][kk] = load_row_frag(base + 2 * H + h * HD, ld, krow[ks], F, kk, lane);
+        for (int ks = 0; ks < NKS; ++ks) v += krow[ks] < F ? bf16_round(dk[ks][i][r]) : 0.f;
+        cs[i][r] = v;
       }
-    }
+    bias_partial(cs, smem, slot + H, wave, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_piece(rs_qkv, smem, kcol, ld * 2, key0, F, true, wave * 4 + j, lane);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-    ATT_BARRIER();
-    bf16x8 ktf[4];  // K^T[d = 16 wave + (lane & 15)][keys of the block], 32 keys per fragment
-    {
-      s16x4 lo[4], hi[4];
-      tr_seq<0, 32 * 128, 16 * 128>(lds_addr(smem) + tr_img_off(wave, lane), lo, hi, std::make_integer_sequence<int, 4>());
-      ATT_WAIT_LDS();
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int s8 = 0; s8 < 4; ++s8) ktf[s8] = join8(lo[s8], hi[s8]);
-    }
-    ATT_BARRIER();  // the image is read out before the stages are filled
-    const uint32_t kphi0 = (uint32_t)(krow[0] >> 1) * DROP_PHI;  // sub-tile 1: + 8 * DROP_PHI
-    // keys beyond the key length start S at -3e38: exp2(-huge) = 0 (one register per sub-tile, splat where it is used)
-    const float sbias[2] = {krow[0] < kl ? 0.f : -3.0e38f, krow[1] < kl ? 0.f : -3.0e38f};
-    f32x4 dk[2][4], dv[2][4];
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        dk[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dv[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < NKS; ++ks) v += krow[ks] < F ? bf16_round(dv[ks][i][r] * inv_scale) : 0.f;
+        cs[i][r] = v;
       }
-    issue(0, 0);
-    issue(1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0f76);  // vmcnt(6): tile 0 has landed (this wave's share)
-    ATT_BARRIER();
-    rows_stat(0, 0, 0);
-
-    int cur = 0;  // stage of tile qt
-#pragma unroll 1
-    for (int qt = 0; qt < nqt; ++qt) {
-      const int nxt = cur == F_NST - 1 ? 0 : cur + 1, nx2 = nxt == F_NST - 1 ? 0 : nxt + 1;
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's statistics words are in LDS
-      ATT_BARRIER();                       // tile qt (waited for in front of the previous step's second barrier) and its statistics
-      // previous blocks' dQ of this wave's two tiles (this workgroup stored them; the block prologue drained the stores).
-      // Read in the first block too, and ignored there: no branch, no merge of a loaded value before its use.
-      bf16* dq_ptr[2];
-      bf16x4 dq_prev[2];
-#pragma unroll
-      for (int qh = 0; qh < 2; ++qh) {
-        const int q = qt * FQ + 16 * qh + (lane & 15);
-        dq_ptr[qh] = p.dqkv + ((long)b * F + min(q, F - 1)) * ld + h * HD + 16 * wave + 4 * g;
-        dq_prev[qh] = *reinterpret_cast<const bf16x4*>(dq_ptr[qh]);
-      }
-      issue(qt + 2, nx2);  // tiles beyond the last: out-of-range sources, zeros
-      const char* q_rows = smem + cur * F_STAGE;
-      const char* do_rows = q_rows + 2 * FT;
-      const uint32_t tr_base = lds_addr(q_rows + FT);  // Q transpose image; the dO transpose image is 2 * FT further
-      const float* lse_s = stat0 + (qt & 1) * 3 * 64;
-      const float* dl_s = lse_s + 64;
-      const uint32_t* seed_s = reinterpret_cast<const uint32_t*>(lse_s + 128);
-
-      bf16x8 pdb[2], dsb[2];  // per key sub-tile, over the 32 queries of the step
-      {
-        f32x4 s[2][2], dp[2][2];  // [key sub-tile][query sub-tile]: rows = queries 16 qh + 4 g + r, column = key
-#pragma unroll
-        for (int qh = 0; qh < 2; ++qh) {
-          const bf16x8 qa = frag_rows(q_rows, qh, 0, lane), qb = frag_rows(q_rows, qh, 1, lane);
-          const bf16x8 da = frag_rows(do_rows, qh, 0, lane), db = frag_rows(do_rows, qh, 1, lane);
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            float sb = sbias[ks];
-            asm volatile("" : "+v"(sb));  // keeps the splat out of the loop-invariant registers
-            f32x4 a = {sb, sb, sb, sb}, c = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf[ks][1], a, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db, vf[ks][1], c, 0, 0, 0);
-            s[ks][qh] = a;
-            dp[ks][qh] = c;
-          }
-        }
-#pragma unroll
-        for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {  // row pairs r = 2 i, 2 i + 1
-            // Dropout words (as the two-kernel form): a word covers a key PAIR, which sits in two adjacent lanes, so each lane
-            // mixes the word of ONE of the two rows (row 2 i + par) per sub-tile and takes the other row's from its partner by DPP.
-            uint32_t W[2][2];
-            if (DROP) {
-              const uint32_t rs = seed_s[16 * qh + 4 * g + 2 * i + par];
-#pragma unroll
-              for (int ks = 0; ks < 2; ++ks) {
-                const uint32_t mine = drop_word(rs + kphi0 + (uint32_t)(8 * ks) * DROP_PHI);
-                const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);
-                W[ks][0] = par ? other : mine;
-                W[ks][1] = par ? mine : other;
-              }
-            }
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2) {
-              const int r = 2 * i + r2;
-              const int ql = 16 * qh + 4 * g + r;
-              const float lsc = lse_s[ql], dl = dl_s[ql];
-#pragma unroll
-              for (int ks = 0; ks < 2; ++ks) {
-                  const float pr = __builtin_amdgcn_exp2f(fmaf(s[ks][qh][r], c2, -lsc));  // P * scale
-                  float dpv = dp[ks][qh][r], pd = pr;
-                  if (DROP) {
-                    const uint32_t w = W[ks][r2];
-                    const bool k = par ? drop_keep_odd(w, thi) : drop_keep_even(w, thi);
-                    const float keep = k ? p.drop_scale : 0.f;
-                    dpv *= keep;
-                    pd *= keep;
-                  }
-                  s[ks][qh][r] = pd;                // P keep / (1 - p) * scale
-                  dp[ks][qh][r] = pr * (dpv - dl);  // dS (scale included)
-                }
-            }
-          }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          pdb[ks] = pack_p(s[ks][0], s[ks][1]);
-          dsb[ks] = pack_p(dp[ks][0], dp[ks][1]);
-        }
-      }
-      // ---- dS^T block of this wave -> LDS: key row 32 wave + 16 ks + (lane & 15), queries 16 qh + 4 g .. + 3 (8 bytes)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int row = 32 * wave + 16 * ks + (lane & 15);
-        const int sw = dst_swz(row);
-        const bf16x4 lo4 = {dsb[ks][0], dsb[ks][1], dsb[ks][2], dsb[ks][3]};
-        const bf16x4 hi4 = {dsb[ks][4], dsb[ks][5], dsb[ks][6], dsb[ks][7]};
-        *reinterpret_cast<bf16x4*>(dst_tile + row * 64 + (((0 + g) ^ sw) << 3)) = lo4;
-        *reinterpret_cast<bf16x4*>(dst_tile + row * 64 + (((4 + g) ^ sw) << 3)) = hi4;
-      }
-      // ---- dV^T += dO^T Pd, dK^T += Q^T dS  (k = the 32 queries, in the accumulator order of pdb / dsb)
-#pragma unroll
-      for (int i2 = 0; i2 < 4; i2 += 2) {
-        s16x4 qlo[2], qhi[2], dlo[2], dhi[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint32_t a = tr_base + off_tr[i2 + i];
-          qlo[i] = tr_read<0>(a);
-          qhi[i] = tr_read<16 * 128>(a);
-          dlo[i] = tr_read<2 * FT>(a);
-          dhi[i] = tr_read<2 * FT + 16 * 128>(a);
-        }
-        ATT_WAIT_LDS();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bf16x8 doa = join8(dlo[i], dhi[i]), qa = join8(qlo[i], qhi[i]);
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            dv[ks][i2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa, pdb[ks], dv[ks][i2 + i], 0, 0, 0);
-            dk[ks][i2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, dsb[ks], dk[ks][i2 + i], 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // vm operations of this wave per step: [2 dQ read-backs + 6 DMA of tile qt+2, in the compiler's order] [2 dQ stores].
-      // Tile qt+1 must have landed behind the barrier (its row statistics are formed below; the next step reads it): younger
-      // than its DMA are the two stores of step qt-1 (none for the prologue's tiles) and this step's eight -> vmcnt(8);
-      // lgkmcnt(0): this wave's dS^T block is written.
-      __builtin_amdgcn_s_waitcnt(0x0078);
-      ATT_BARRIER();  // ... every wave's
-      // ---- dQ^T[16 wave + 4 g + r][16 qh + (lane & 15)] = sum over the 128 keys K^T dS^T, both query sub-tiles
-      {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        s16x4 lo[2][4], hi[2][4];
-        tr_seq<0, 32 * 64, 16 * 64>(dst_rd[0], lo[0], hi[0], std::make_integer_sequence<int, 4>());
-        tr_seq<0, 32 * 64, 16 * 64>(dst_rd[1], lo[1], hi[1], std::make_integer_sequence<int, 4>());
-        ATT_WAIT_LDS();
-#pragma unroll
-        for (int s8 = 0; s8 < 4; ++s8)
-#pragma unroll
-          for (int qh = 0; qh < 2; ++qh)
-            acc[qh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[s8], join8(lo[qh][s8], hi[qh][s8]), acc[qh], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool first = kb == 0;
-#pragma unroll
-        for (int qh = 0; qh < 2; ++qh) {
-          const bf16x4 out = {(bf16)(acc[qh][0] + (first ? 0.f : (float)dq_prev[qh][0])), (bf16)(acc[qh][1] + (first ? 0.f : (float)dq_prev[qh][1])),
-                              (bf16)(acc[qh][2] + (first ? 0.f : (float)dq_prev[qh][2])), (bf16)(acc[qh][3] + (first ? 0.f : (float)dq_prev[qh][3]))};
-          if (qt * FQ + 16 * qh + (lane & 15) < F) *reinterpret_cast<bf16x4*>(dq_ptr[qh]) = out;  // (rows beyond F: masked lanes)
-        }
-      }
-      rows_stat(qt + 1, nxt, (qt + 1) & 1);  // published by the next step's first barrier
-      cur = nxt;
-    }
-    const float inv_scale = 1.f / p.scale;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int key = krow[ks];
-      if (key >= F) continue;
-      bf16* dkd = p.dqkv + ((long)b * F + key) * ld + H + h * HD + 4 * g;
-      bf16* dvd = dkd + H;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bf16x4 a = {(bf16)dk[ks][i][0], (bf16)dk[ks][i][1], (bf16)dk[ks][i][2], (bf16)dk[ks][i][3]};
-        const bf16x4 c = {(bf16)(dv[ks][i][0] * inv_scale), (bf16)(dv[ks][i][1] * inv_scale), (bf16)(dv[ks][i][2] * inv_scale),
-                          (bf16)(dv[ks][i][3] * inv_scale)};
-        *reinterpret_cast<bf16x4*>(dkd + 16 * i) = a;
-        *reinterpret_cast<bf16x4*>(dvd + 16 * i) = c;
-      }
-    }
+    bias_partial(cs, smem, slot + 2 * H, wave, lane);
   }
 }
+
+// (A fused single-pass backward -- one evaluation of P, the dropout words and dS for dQ, dK and dV -- lived here through round 3 as
+// an opt-in mode.  It lost to the two-kernel form at the train step's shape in every variant measured (184-193 us against 149-166 us
+// per launch at B = 32, F = 499: profiles/r03_bench_attn.log) and was removed in round 4.)
 
 AttnParams make_params(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens, const bf16* dctx, float* delta, bf16* dqkv,
                        int B, int F, int nh, int H, const DropSpec& drop) {
@@ -1129,6 +782,7 @@ AttnParams make_params(const bf16* qkv, bf16* ctx, float* lse, const int32_t* kl
   p.dctx = dctx;
   p.delta = delta;
   p.dqkv = dqkv;
+  p.bias_part = nullptr;
   p.B = B;
   p.F = F;
   p.nh = nh;
@@ -1177,26 +831,24 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens
   return SSAK_OK;
 }
 
+size_t k_attention_bwd_bias_floats(int B, int F, int H) {
+  // the bias partials need the two kernels to cut the frames into the same blocks (they do unless the development switch says otherwise)
+#ifdef SSAK_AB_NO_ATTN_BIAS  // A/B build: the separate column-sum pass of rounds 1-3
+  return 0;
+#endif
+  return attn_tile(1) == attn_tile(2) ? (size_t)B * ssak_cdiv(F, 64 * attn_tile(1)) * 3 * H : 0;
+}
+
 int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const int32_t* klens, const bf16* dctx, float* delta,
-                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode, hipStream_t st) {
+                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode, hipStream_t st, float* bias_part,
+                    float* bias_grad) {
   SSAK_REQUIRE(k_attention_supported(H, nh), "attention: fused kernels are built for head_dim 64 (got %d)", nh ? H / nh : 0);
-  SSAK_REQUIRE(mode >= 0 && mode <= 2, "attention_bwd: mode %d (0 / 1 = two kernels, the default; 2 = fused single pass)", mode);
-  const AttnParams p = make_params(qkv, const_cast<bf16*>(ctx), const_cast<float*>(lse), klens, dctx, delta, dqkv, B, F, nh, H, drop);
+  SSAK_REQUIRE(mode == SSAK_ATTN_BWD_DEFAULT || mode == SSAK_ATTN_BWD_TWO_KERNEL,
+               "attention_bwd: mode %d (0 / 1 = two kernels; the single-pass form, 2, was removed in ABI 400)", mode);
+  SSAK_REQUIRE(!bias_part == !bias_grad && (!bias_part || k_attention_bwd_bias_floats(B, F, H) > 0), "attention_bwd: bias partials need both pointers and equal block sizes");
+  AttnParams p = make_params(qkv, const_cast<bf16*>(ctx), const_cast<float*>(lse), klens, dctx, delta, dqkv, B, F, nh, H, drop);
+  p.bias_part = bias_part;
   ProfScope prof_scope(PROF_ATTN_BWD, 8.0 * B * nh * (double)F * F * HD, st);  // dV, dP, dQ, dK (the recomputed S is not algorithmic work)
-  if (mode == SSAK_ATTN_BWD_FUSED) {  // single pass, every wave in every role (4-wave workgroups)
-    static bool fused_attr = false;
-    if (!fused_attr) {
-      SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-      SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-      fused_attr = true;
-    }
-    if (p.thresh16)
-      attn_bwd_fused_kernel<true><<<dim3(nh, B), 64 * FNW, F_LDS, st>>>(p);
-    else
-      attn_bwd_fused_kernel<false><<<dim3(nh, B), 64 * FNW, F_LDS, st>>>(p);
-    SSAK_LAUNCH_CHECK();
-    return SSAK_OK;
-  }
   const int nqs = attn_tile(1), nks = attn_tile(2);
 #define ATT_LAUNCH_DQ(D, N) attn_bwd_dq_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p)
   if (p.thresh16) {
@@ -1223,6 +875,14 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
   }
 #undef ATT_LAUNCH_DKV
   SSAK_LAUNCH_CHECK();
+  if (bias_part) {
+    // second stage: with the caller's queued reductions (ReduceSink) when there is one, else here
+    const int slots = B * ssak_cdiv(F, 64 * nqs);
+    if (!(g_reduce_sink && g_reduce_sink->push(bias_part, 3L * H, slots, 3 * H, bias_grad))) {
+      const int rc = k_colsum_rows(bias_part, slots, 3 * H, bias_grad, st);
+      if (rc != SSAK_OK) return rc;
+    }
+  }
   return SSAK_OK;
 }
 
@@ -1247,4 +907,26 @@ extern "C" int ssak_attention_bwd(const void* qkv, const void* ctx, const float*
   d.stream = stream_id;
   return k_attention_bwd((const bf16*)qkv, (const bf16*)ctx, lse, klens, (const bf16*)dctx, delta, (bf16*)dqkv, B, F, nh, H, d, mode,
                          (hipStream_t)stream);
+}
+
+// as ssak_attention_bwd, and bias_grad[3H] += the column sums of dqkv (the q|k|v projection bias gradient), taken inside the kernels
+extern "C" size_t ssak_attention_bwd_bias_workspace_bytes(int B, int F, int H) {
+  return (size_t)B * ssak_cdiv(F > 0 ? F : 1, 64) * 3 * (H > 0 ? H : 0) * sizeof(float);
+}
+extern "C" int ssak_attention_bwd_bias(const void* qkv, const void* ctx, const float* lse, const int32_t* klens, const void* dctx,
+                                       float* delta, void* dqkv, float* bias_grad, int B, int F, int nh, int H, float drop_p,
+                                       uint64_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
+  SSAK_REQUIRE(qkv && ctx && lse && dctx && delta && dqkv && bias_grad && workspace, "attention_bwd_bias: null pointer");
+  SSAK_REQUIRE(workspace_bytes >= ssak_attention_bwd_bias_workspace_bytes(B, F, H), "attention_bwd_bias: workspace too small");
+  DropSpec d;
+  d.p = drop_p;
+  d.seed = seed;
+  d.stream = stream_id;
+  if (k_attention_bwd_bias_floats(B, F, H) == 0) {  // (development switch SSAK_ATTN_TILE with unequal blocks)
+    const int rc = k_attention_bwd((const bf16*)qkv, (const bf16*)ctx, lse, klens, (const bf16*)dctx, delta, (bf16*)dqkv, B, F, nh, H, d,
+                                   SSAK_ATTN_BWD_DEFAULT, (hipStream_t)stream);
+    return rc != SSAK_OK ? rc : k_colsum((const bf16*)dqkv, 3L * H, B * F, 3 * H, bias_grad, (hipStream_t)stream);
+  }
+  return k_attention_bwd((const bf16*)qkv, (const bf16*)ctx, lse, klens, (const bf16*)dctx, delta, (bf16*)dqkv, B, F, nh, H, d,
+                         SSAK_ATTN_BWD_DEFAULT, (hipStream_t)stream, (float*)workspace, bias_grad);
 }

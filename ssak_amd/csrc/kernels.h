@@ -145,8 +145,13 @@ int k_posconv_pack_t(const T* h, T* pg, int B, int F, int H, int G, int K, hipSt
 bool k_attention_supported(int H, int nh);
 int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens, int B, int F, int nh, int H,
                     const DropSpec& drop, hipStream_t st);
+// bias_part / bias_grad (both or neither): the kernels leave the column sums of their rows of dqkv in bias_part
+// [k_attention_bwd_bias_floats] and bias_grad [3H] += their total (through the caller's ReduceSink when there is one) -- the q|k|v bias gradient
+size_t k_attention_bwd_bias_floats(int B, int F, int H);  // 0: the kernels' block sizes differ (development switch), sum dqkv's columns separately
 int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const int32_t* klens, const bf16* dctx, float* delta,
-                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode /* SSAK_ATTN_BWD_* */, hipStream_t st);
+                    bf16* dqkv, int B, int F, int nh, int H, const DropSpec& drop, int mode /* SSAK_ATTN_BWD_* */, hipStream_t st,
+                    float* bias_part = nullptr, float* bias_grad = nullptr);
+int k_colsum_rows(const float* partial, int slots, int N, float* out, hipStream_t st);  // out[n] += sum over slots of partial[slot][n]
 
 // posconv.hip: the grouped positional convolution as a direct convolution (input window resident in LDS)
 bool k_posconv_direct_supported(int H, int G, int K);

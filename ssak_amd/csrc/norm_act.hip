@@ -728,6 +728,13 @@ int k_colsum_t(const T* X, long ld, int M, int N, float* out, hipStream_t st, fl
 
 thread_local ReduceSink* g_reduce_sink = nullptr;
 
+int k_colsum_rows(const float* partial, int slots, int N, float* out, hipStream_t st) {
+  ProfScope prof_scope(PROF_ROWWISE, (double)slots * N * 4.0, st);
+  colsum_rows_kernel<<<ssak_cdiv(N, 64), 1024, 0, st>>>(partial, slots, N, out);
+  SSAK_LAUNCH_CHECK();
+  return SSAK_OK;
+}
+
 int k_reduce_flush(ReduceSink& sink, hipStream_t st) {
   int done = 0;
   double bytes = 0.0;

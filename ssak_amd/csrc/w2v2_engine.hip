@@ -452,7 +452,8 @@ int make_plan(const ssak_w2v2* e, int B, int T, int training, Plan& p) {
     p.lnpart = cv.take((size_t)LN_BWD_BLOCKS * 3 * std::max(H, C) * sizeof(float));
     // partial sums of the reductions whose second stage is deferred to one launch per pair of encoder layers (kernels.h:
     // ReduceSink): per layer two LayerNorm backward slabs, the FFN bias sums of the dX epilogue and the qkv bias sums
-    p.redring_floats = 3 * ((size_t)2 * LN_BWD_BLOCKS * 3 * H + (size_t)std::max(ssak_cdiv(M, 64), 64) * I + (size_t)64 * 3 * H);
+    p.redring_floats = 3 * ((size_t)2 * LN_BWD_BLOCKS * 3 * H + (size_t)std::max(ssak_cdiv(M, 64), 64) * I +
+                              std::max((size_t)64 * 3 * H, (size_t)B * ssak_cdiv(p.F, 64) * 3 * H));  // (qkv bias partials: <= one slot per 64 frames)
     p.redring = cv.take(p.redring_floats * sizeof(float));
     // split-K slabs: the largest weight-gradient product is [I,H] (or [3H,H]); at most 32 slices
     const size_t big = (size_t)std::max(std::max(I * H, 3 * H * H), std::max(H * C, V * H));
@@ -827,7 +828,7 @@ extern "C" int ssak_w2v2_set_option(ssak_w2v2* e, int option, int value) {
   if (option == SSAK_W2V2_OPT_DYNAMIC_TILES) {
     e->dynamic_tiles = value ? 1 : 0;
   } else if (option == SSAK_W2V2_OPT_ATTENTION_BWD) {
-    SSAK_REQUIRE(value >= SSAK_ATTN_BWD_DEFAULT && value <= SSAK_ATTN_BWD_FUSED, "w2v2_set_option: attention backward form %d", value);
+    SSAK_REQUIRE(value == SSAK_ATTN_BWD_DEFAULT || value == SSAK_ATTN_BWD_TWO_KERNEL, "w2v2_set_option: attention backward form %d (the single-pass form was removed in ABI 400)", value);
     e->attn_bwd_mode = value;
   } else if (option == SSAK_W2V2_OPT_POSCONV_DIRECT) {
     e->posconv_direct = value ? 1 : 0;
@@ -1418,7 +1419,9 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     TRY(red_get(ln_part_floats, &ln_part2));
     const size_t ffn_part_floats = (size_t)std::max(ssak_cdiv(M, 64), 64) * I;  // (>= 64 rows: the non-fused fallback's partials)
     TRY(red_get(ffn_part_floats, &ffn_part));
-    TRY(red_get((size_t)64 * 3 * H, &qkv_part));
+    // q|k|v bias gradient: first stage inside the fused attention backward kernels when they run, else a column-sum pass over dqkv
+    const size_t qkv_fused_floats = (p.fused_attn && !EXACT) ? k_attention_bwd_bias_floats(B, F, H) : 0;
+    TRY(red_get(std::max((size_t)64 * 3 * H, qkv_fused_floats), &qkv_part));
     AT* dR = stable ? free_buf(gA, gB, Gres) : BF(p.dC);  // grad wrt r2
     const int set = kept % p.wgrad_sets;
     ++kept;
@@ -1469,7 +1472,8 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     if (p.fused_attn) {
       if constexpr (!EXACT)
         TRY(k_attention_bwd(qkv, BF(lb.ctx), FP(lb.lse), flens, dctx, FP(p.delta), dqkv, B, F, nh, H,
-                            DS(c.attention_dropout, ds_attn(l)), e->attn_bwd_mode, st));
+                            DS(c.attention_dropout, ds_attn(l)), e->attn_bwd_mode, st, qkv_fused_floats ? qkv_part : nullptr,
+                            qkv_fused_floats ? Gd + L.bqkv : nullptr));
     } else {
       TRY(GemmX<EXACT>(F, hd, F).a(BF(lb.Pd), Fp, true).b(dctx, H, true).c(dqkv + 2 * H, 3 * H)
               .batch(B, nh, sp1, sp2, sh1, hd, sq1, hd).run(st));  // dV = Pd^T dctx
@@ -1482,7 +1486,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
     }
     TRY(wq_push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true), set));
-    TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
+    if (!qkv_fused_floats) TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
     TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b_wt(EXACT ? nullptr : e->wt(l, 0), 3 * H, W + L.wqkv, H).bfrag(e->wt(l, 0) ? nullptr : e->frag(l, 3)).c(dX, H).run(st));
     wq.ann_off[wq.n_ann] = L.wqkv;
     wq.ann_last[wq.n_ann++] = wq.pushed - 1;  // announced once the qkv product -- the layer's last -- has been launched

@@ -88,6 +88,8 @@ def _load():
         "ssak_prof_collect": (i32, [vp, C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
         "ssak_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, i32, vp]),
+        "ssak_attention_bwd_bias_workspace_bytes": (sz, [i32, i32, i32]),
+        "ssak_attention_bwd_bias": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp, sz, vp]),
         "ssak_grad_sumsq": (i32, [vp, C.c_long, vp, vp, sz, vp]),
         "ssak_adamw_step": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
         "ssak_w2v2_create": (i32, [C.POINTER(W2V2Config), C.POINTER(vp)]),
@@ -396,13 +398,13 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
     return ctx, lse
 
 
-ATTN_BWD_DEFAULT, ATTN_BWD_TWO_KERNEL, ATTN_BWD_FUSED = 0, 1, 2
+ATTN_BWD_DEFAULT, ATTN_BWD_TWO_KERNEL = 0, 1
 W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD, W2V2_OPT_POSCONV_DIRECT, W2V2_OPT_FRAGMENT_WEIGHTS, W2V2_OPT_TRANSPOSED_WEIGHTS = 1, 2, 3, 4, 5
 
 
 def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0,
                   mode=ATTN_BWD_DEFAULT):
-    """``mode``: ATTN_BWD_TWO_KERNEL (= default: dQ; dK + dV) or ATTN_BWD_FUSED (one pass), per call."""
+    """``mode``: ATTN_BWD_DEFAULT = ATTN_BWD_TWO_KERNEL (dQ; dK + dV); the single-pass form (2) was removed in ABI 400."""
     H = qkv.shape[1] // 3
     dqkv = torch.full_like(qkv, float("nan"))  # poisoned: the kernels write every element
     delta = torch.empty((B, nh, F), dtype=torch.float32, device=qkv.device)
@@ -411,3 +413,20 @@ def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop
     check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), ptr(klens), ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H,
                                  float(drop_p), seed, stream_id, int(mode), stream()))
     return dqkv
+
+
+def attention_bwd_bias(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0, bias_grad=None):
+    """attention_bwd + the q|k|v projection bias gradient (column sums of dqkv, taken inside the kernels): ``bias_grad`` [3H] fp32
+    is ADDED to (zeros when None).  Returns (dqkv, bias_grad)."""
+    H = qkv.shape[1] // 3
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty((B, nh, F), dtype=torch.float32, device=qkv.device)
+    if bias_grad is None:
+        bias_grad = torch.zeros(3 * H, dtype=torch.float32, device=qkv.device)
+    if klens is not None:
+        klens = klens.to(device=qkv.device, dtype=torch.int32).contiguous()
+    nbytes = lib.ssak_attention_bwd_bias_workspace_bytes(B, F, H)
+    ws = _ws(nbytes, qkv.device)
+    check(lib.ssak_attention_bwd_bias(ptr(qkv), ptr(ctx), ptr(lse), ptr(klens), ptr(dctx), ptr(delta), ptr(dqkv), ptr(bias_grad), B, F,
+                                      nh, H, float(drop_p), seed, stream_id, ptr(ws), nbytes, stream()))
+    return dqkv, bias_grad

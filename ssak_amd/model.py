@@ -391,7 +391,7 @@ class Wav2Vec2ForCTC:
 
     def set_option(self, option: int, value: int):
         """Per-handle execution options (``ssak_w2v2_set_option``): hip.W2V2_OPT_DYNAMIC_TILES (ticket tile order of the
-        persistent GEMMs, for data-parallel runs), hip.W2V2_OPT_ATTENTION_BWD (hip.ATTN_BWD_*)."""
+        persistent GEMMs, for data-parallel runs), hip.W2V2_OPT_ATTENTION_BWD (hip.ATTN_BWD_*; one form since ABI 400)."""
         hip.check(hip.lib.ssak_w2v2_set_option(self._h, int(option), int(value)))
 
     def set_param_event(self, event: Optional[torch.cuda.Event], stall_begin=None, stall_end=None):

@@ -106,46 +106,6 @@ def test_base_gradients_projections_and_full_tensors(gold):
     print("base vs oracle, full tensors: worst", worst)
 
 
-@pytest.mark.parametrize("mode", [2])
-def test_base_step_with_single_pass_attention_backward(gold, mode):
-    """The engine's train step with the opt-in single-pass attention backward kernel (hip.ATTN_BWD_FUSED, a per-handle option)
-    on wav2vec2-base with the train script's regularisers ON (attention
-    dropout 0.1: the kernels must regenerate the forward's mask): same logits, and every gradient tensor within 2e-2 relative
-    L2 of the default two-kernel form's (same seeds, so the same dropout / LayerDrop / SpecAugment draws; measured 2e-3)."""
-    from oracle import w2v2_ref as R
-    from oracle.gen_golden import base_inputs
-    from ssak_amd import hip
-    from ssak_amd.config import Wav2Vec2Config
-    from ssak_amd.model import Wav2Vec2ForCTC
-    x, labels = base_inputs()
-    oc = R.W2V2Config.base()  # script defaults: dropouts, LayerDrop, SpecAugment
-    params = R.init_params(oc, 69)
-
-    def run(m):
-        model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc), seed=123).train()
-        model.set_option(hip.W2V2_OPT_ATTENTION_BWD, m)  # per handle
-        model.load_state_dict(params)
-        out = model(torch.tensor(x), labels=torch.tensor(labels))
-        model.grads[:model.num_trainable].fill_(float("nan"))
-        model.backward()
-        return out.logits.clone(), {n: model.grad(n).clone() for n in model.layout if model.layout[n][0] < model.num_trainable}
-
-    lg_ref, g_ref = run(1)
-    lg, g = run(mode)
-    assert torch.equal(lg, lg_ref)  # the forward is the same code
-    gmax = max(float(v.abs().max()) for v in g_ref.values())
-    worst = ("", 0.0)
-    for n, v in g_ref.items():
-        assert torch.isfinite(g[n]).all(), n
-        if float(v.abs().max()) < 2e-4 * gmax:
-            continue
-        e = rel_l2(g[n].cpu(), v.cpu())
-        if e > worst[1]:
-            worst = (n, e)
-        assert e < 2e-2, (n, e)
-    print("single-pass attention backward, mode", mode, "worst gradient difference", worst)
-
-
 # ------------------------------------------------------------------------------------------------ config 5
 def test_xlsr_large_ragged_vs_hf_golden(gold):
     """Wav2Vec2-large-XLSR topology at FULL size (24 x 1024, 16 heads, layer-norm feature encoder with bias, stable LN),

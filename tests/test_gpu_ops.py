@@ -405,14 +405,12 @@ def test_fused_attention_dropout_consistency(hip):
 @pytest.mark.parametrize("B,F,nh,ragged,p", [(2, 499, 12, False, 0.1), (3, 200, 4, True, 0.0), (3, 500, 2, True, 0.25),
                                               (1, 64, 2, False, 0.3), (2, 512, 3, False, 0.1), (1, 257, 1, False, 0.0),
                                               (2, 33, 8, True, 0.1), (2, 1500, 2, False, 0.1), (3, 749, 16, True, 0.05)])
-@pytest.mark.parametrize("mode", [2])  # hip.ATTN_BWD_FUSED (the wave-specialised variant of round 2 was removed)
-def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, p, mode):
-    """The single-pass backward forms (mode 0: producer / consumer wave specialisation; mode 2: every wave in every role) --
-    dQ, dK, dV from one evaluation of P / the dropout words / dS; a workgroup per head walks the keys in blocks and adds each
-    block's dQ tiles onto what it stored for the previous blocks -- against the two-kernel
-    form on the same inputs and the same dropout stream: same mask, so the results differ by bf16 rounding only (<= 1e-2
-    relative L2 per block of columns, the distance either sits from the fp32 reference).  The output buffer is poisoned
-    (NaN): every element of dqkv must be written and the first key block must not read it.  Two fused runs are bit-identical."""
+def test_attention_backward_sums_the_qkv_bias_gradient(hip, B, F, nh, ragged, p):
+    """ssak_attention_bwd_bias: the two backward kernels also leave the column sums of the rows of dqkv they hold (one partial
+    row per workgroup, fixed-order second stage) -- the gradient of the q|k|v projection bias, which the engine used to take
+    with a separate pass over dqkv.  dqkv must be bit-identical to ssak_attention_bwd's, the sums equal to the column sums
+    of the STORED (bf16) dqkv to fp32 summation noise, added onto what bias_grad held, bit-identical between two runs; frame
+    counts that leave partial blocks and whole waves without rows, ragged key lengths, dropout."""
     g = torch.Generator().manual_seed(F * 7 + nh)
     H = nh * 64
     qkv = (torch.randn(B * F, 3 * H, generator=g) * 0.8).to(torch.bfloat16).cuda()
@@ -420,14 +418,25 @@ def test_fused_attention_backward_equals_two_kernel_form(hip, B, F, nh, ragged, 
     klens = torch.tensor([F, max(1, F // 3), F - 7][:B]) if ragged else None
     kw = dict(drop_p=p, seed=99, stream_id=5) if p else {}
     ctx, lse = hip.attention_fwd(qkv, B, F, nh, klens, **kw)
-    ref = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, mode=hip.ATTN_BWD_TWO_KERNEL, **kw)
-    got = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, mode=mode, **kw)
-    again = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, mode=mode, **kw)
-    assert torch.isfinite(got.float()).all() and torch.isfinite(ref.float()).all()
-    assert torch.equal(got, again)
-    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
-    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
-        assert rel(got[:, sl], ref[:, sl]) < 1e-2, (name, rel(got[:, sl], ref[:, sl]))
+    ref = hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, klens, **kw)
+    start = torch.randn(3 * H, generator=g).cuda()
+    got, bias = hip.attention_bwd_bias(qkv, ctx, lse, dctx, B, F, nh, klens, bias_grad=start.clone(), **kw)
+    again, bias2 = hip.attention_bwd_bias(qkv, ctx, lse, dctx, B, F, nh, klens, bias_grad=start.clone(), **kw)
+    assert torch.equal(got, ref) and torch.equal(again, ref) and torch.equal(bias, bias2)
+    want = ref.double().sum(0)
+    tol = 2e-6 * ref.double().abs().sum(0) + 1e-6
+    assert bool(((bias.double() - start.double() - want).abs() <= tol).all()), float((bias.double() - start.double() - want).abs().max())
+
+
+def test_attention_backward_single_pass_mode_is_gone(hip):
+    """Mode 2 (the fused single-pass backward of rounds 2-3, slower than the two-kernel form at the train step's shape) was
+    removed in ABI 400: asking for it is an argument error, not a silent fallback."""
+    B, F, nh = 1, 64, 1
+    qkv = torch.randn(B * F, 3 * 64).to(torch.bfloat16).cuda()
+    dctx = torch.randn(B * F, 64).to(torch.bfloat16).cuda()
+    ctx, lse = hip.attention_fwd(qkv, B, F, nh)
+    with pytest.raises(ValueError):
+        hip.attention_bwd(qkv, ctx, lse, dctx, B, F, nh, mode=2)
 
 
 # ------------------------------------------------------------------ evaluation metric on the device (f3)
