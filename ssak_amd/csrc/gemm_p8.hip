@@ -328,7 +328,12 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
     sa.template issue<1>(buf1 + 1 * P8_PIECE, c.kt0 + 1, c.kt1, p.K, kpp, kpn);
   };
   // vector-memory instructions the LDS-free epilogue issues per wave (stores only; vmcnt counts them like the DMA)
-  const int epi_vm = (p.split_k > 1 || p.out_f32 || ((p.epilogue == SSAK_EPI_GELU || p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) && p.aux_out)) ? 8 * MH : 4 * MH;
+  // (bf16 rows: two 16-byte stores per 16-row group, 4 MH per wave; + a bf16 side output: 8 MH; + the one-byte factor codes of
+  // GELU_SAVE_GRAD: one more store per group, 6 MH -- a count ABOVE the real one would let the wait below pass with primed
+  // pieces still in flight)
+  const int epi_vm = (p.split_k > 1 || p.out_f32 || (p.epilogue == SSAK_EPI_GELU && p.aux_out)) ? 8 * MH
+                     : (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD && p.aux_out)                      ? 6 * MH
+                                                                                                 : 4 * MH;
   static_assert(EPI != P8_EPI_PLAIN_F32 || GROUPED, "the fp32 form is instantiated for the grouped weight gradients");
   const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD && p.epilogue != SSAK_EPI_MUL_AUX && !p.colsum;  // epilogues that only store (a fixed count)
 
@@ -371,6 +376,8 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8_kernel(const GemmParams p,
       wait_vmcnt<10>();  // BL(0), AT(0), BR(0) landed (this wave's share): the first load phase reads all three
     } else if (epi_vm == 8 * MH) {
       wait_vmcnt<8 * MH>();  // everything older than the previous epilogue's stores: the eight primed pieces
+    } else if (epi_vm == 6 * MH) {
+      wait_vmcnt<6 * MH>();
     } else {
       wait_vmcnt<4 * MH>();
     }
@@ -675,7 +682,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8bd_kernel(const GemmParams 
     sa.template issue<0>(smem + 2 * P8BD_STAGE + 0 * P8_PIECE, 2, nkt, p.K, kpp, kpn);
     sa.template issue<1>(smem + 2 * P8BD_STAGE + 1 * P8_PIECE, 2, nkt, p.K, kpp, kpn);
   };
-  const int epi_vm = (((p.epilogue == SSAK_EPI_GELU || p.epilogue == SSAK_EPI_GELU_SAVE_GRAD) && p.aux_out)) ? 8 * MH : 4 * MH;
+  const int epi_vm = (p.epilogue == SSAK_EPI_GELU && p.aux_out) ? 8 * MH : (p.epilogue == SSAK_EPI_GELU_SAVE_GRAD && p.aux_out) ? 6 * MH : 4 * MH;
   const bool epi_early = !p.accumulate && p.epilogue != SSAK_EPI_MUL_GELU_GRAD && p.epilogue != SSAK_EPI_MUL_AUX && !p.colsum;
 
   int* const tile_ctr = p.tile_ctr ? p.tile_ctr + (blockIdx.x & 7) : nullptr;
@@ -698,6 +705,8 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_p8bd_kernel(const GemmParams 
       wait_vmcnt<18>();  // AT(0) landed (this wave's share): AB(0), B(0) and the six pieces of tiles 1, 2 may still fly
     } else if (epi_vm == 8 * MH) {
       wait_vmcnt<8 * MH>();  // everything older than the previous epilogue's stores
+    } else if (epi_vm == 6 * MH) {
+      wait_vmcnt<6 * MH>();
     } else {
       wait_vmcnt<4 * MH>();
     }

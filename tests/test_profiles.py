@@ -56,6 +56,8 @@ def test_round_profile_artefacts_are_one_build():
     flat = " | ".join(n.replace("(anonymous namespace)::", "").replace("void ", "") for n in names)
     missing = []
     for k in roof["kernels"]:
+        if k.get("workload"):
+            continue  # a slot measured in one of the secondary workloads (log-mel: the Whisper window step), not in the traced headline step
         ident = k["kernel"].split(" (")[0]
         if ident.startswith("row / element-wise") or ident.startswith("positional-conv") or ident.startswith("softmax"):
             continue  # class slots that bundle many small helpers under a descriptive name

@@ -1,14 +1,19 @@
 #!/bin/bash
-# A/B of two builds on the SAME box (the pool's boxes differ by several per cent): alternates bench.py runs of the current
-# libssak_hip.so and of the build named by $SSAK_AB_BASE (default tools/ab_base.so (git-ignored like every .so), kept OUTSIDE the package so that it never
-# ships next to the product library; it must have the ABI of the current binding, ssak_amd/hip.py refuses another one),
-# printing utt/s, ms/step and the top kernel slots.  Make the baseline with: git stash; make; cp ssak_amd/lib/libssak_hip.so tools/ab_base.so; git stash pop; make
-BASE=${SSAK_AB_BASE:-$PWD/tools/ab_base.so}
-N=${1:-3}
+# Same-box A/B of builds of the same ABI (the pool's boxes differ by several per cent, so only runs on ONE box compare):
+#   tools/ab.sh [-n ROUNDS] other1.so [other2.so ...]
+# alternates bench.py runs of the shipped library and of each other build (SSAK_HIP_LIB; ssak_amd/hip.py refuses another ABI)
+# and prints, per run: utterances/s and ms per step of the timed region, of the 100-step run after it (free of start-up
+# effects), and the GEMM / attention slots of the survey.  Other builds are made next to the product, never inside the package:
+#   make OBJ=build/obj_x LIB=tools/ab_x.so EXTRA=-DSOME_VARIANT        (every .so is git-ignored; tools/*.so travel to the GPU box)
+N=3
+if [ "$1" = "-n" ]; then N=$2; shift 2; fi
 show='import json,sys
-d=json.loads(sys.stdin.read()); r=d["roofline"]
-print(sys.argv[1], d["value"], d["ms_per_step"], " | ".join("%s %.0f" % (k["kernel"].split("(")[0][:34], k["us_per_step"]) for k in r["kernels"][:9]))'
+d=json.loads(sys.stdin.read()); r=d["roofline"]; lr=d.get("long_run") or {}
+print("%-12s %8.1f %7.3f | long %8.1f %7.3f | %s" % (sys.argv[1], d["value"], d["ms_per_step"], lr.get("value", 0), lr.get("ms_per_step", 0),
+      " | ".join("%s %.0f" % (k["kernel"].replace("gemm_", "").replace("_kernel", "")[:34], k["us_per_step"]) for k in r["kernels"][:12] if "gemm" in k["kernel"] or "attn" in k["kernel"])))'
 for i in $(seq $N); do
-  python bench.py --steps 60 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$show" "new "
-  SSAK_HIP_LIB=$BASE python bench.py --steps 60 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$show" "base"
+  python bench.py --steps 20 --warmup 5 --long-steps 100 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "$show" "ship"
+  for lib in "$@"; do
+    SSAK_HIP_LIB=$PWD/${lib#$PWD/} python bench.py --steps 20 --warmup 5 --long-steps 100 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "$show" "$(basename $lib .so)"
+  done
 done

@@ -1,5 +1,5 @@
 """Fused attention kernels on the train-step shape (B x 12 heads x 499 frames, head_dim 64): time per launch with and
-without dropout, backward in both forms (fused single pass / two kernels).  Buffers are allocated once and the library is
+without dropout, the backward alone and with the q|k|v bias sums taken in its kernels.  Buffers are allocated once and the library is
 called directly, so the figures are kernel time + launch.  usage: PYTHONPATH=. python tools/bench_attn.py [B=32] [F=499] [nh=12]"""
 import sys
 import torch
@@ -38,7 +38,11 @@ for p in (0.0, 0.1):
     bwd = lambda mode=1: h.check(lib.ssak_attention_bwd(ptr(qkv), ptr(ctx), ptr(lse), None, ptr(dctx), ptr(delta), ptr(dqkv), B, F, nh, H, p, 1, 3, mode, st()))
     tf = timeit(fwd)
     out = [f"p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s)"]
-    for mode, name in ((2, "fused"), (1, "two-kernel")):
-        tb = timeit(lambda: bwd(mode))
-        out.append(f"bwd {name:10s} {tb:7.1f} us ({2 * fl / tb / 1e6:6.1f} TF/s)")
+    tb = timeit(bwd)
+    out.append(f"bwd (dQ; dK + dV) {tb:7.1f} us ({2 * fl / tb / 1e6:6.1f} TF/s)")
+    bias = torch.zeros(3 * H, dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib.ssak_attention_bwd_bias_workspace_bytes(B, F, H), dtype=torch.uint8, device="cuda")
+    tbb = timeit(lambda: h.check(lib.ssak_attention_bwd_bias(ptr(qkv), ptr(ctx), ptr(lse), None, ptr(dctx), ptr(delta), ptr(dqkv), ptr(bias),
+                                                             B, F, nh, H, p, 1, 3, ptr(ws), ws.numel(), st())))
+    out.append(f"bwd + q|k|v bias sums {tbb:7.1f} us")
     print("   ".join(out))

@@ -17,7 +17,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "ssak_amd", "lib", "libssak_hip.so")
+# the library a run LOADS: SSAK_HIP_LIB redirects the binding (ssak_amd/hip.py), and an artefact must be labelled with what was measured
+LIB = os.environ.get("SSAK_HIP_LIB") or os.path.join(ROOT, "ssak_amd", "lib", "libssak_hip.so")
 COMMIT_FILE = os.path.join(ROOT, "profiles", ".commit.json")
 
 
@@ -55,7 +56,10 @@ def current() -> dict:
                 commit, dirty = note["commit"], note.get("dirty")
         except (OSError, ValueError, KeyError):
             pass
-    return {"commit": commit, "sources_modified_since_commit": dirty, "source_sha256": src, "lib_sha256": lib_sha256()}
+    st = {"commit": commit, "sources_modified_since_commit": dirty, "source_sha256": src, "lib_sha256": lib_sha256()}
+    if os.environ.get("SSAK_HIP_LIB"):
+        st["lib_path"] = os.path.relpath(LIB, ROOT)  # not the product library: an A/B or development build (its flags are not in source_sha256)
+    return st
 
 
 def fetch(round_name: str):
