@@ -193,30 +193,38 @@ __device__ __forceinline__ AttnBlock attn_block() {
 // Column sums of a workgroup's output rows, for the q|k|v bias gradient (the separate column-sum pass read all of dqkv again:
 // 74 MB per layer).  `acc` is an output tile in the transposed orientation all three gradients use (row = d = 16 i + 4 g + r on
 // the registers, output row on lane & 15), already rounded to bf16 like the stored values and zero for rows that are not stored.
-// 16-lane butterflies, the four waves through LDS (the streamed tiles are dead: one barrier first), one float per d written to
+// 16-lane DPP reductions, the four waves through LDS (the streamed tiles are dead: one barrier first), one float per d written to
 // the workgroup's slot -- no atomics, fixed summation order.
-__device__ __forceinline__ void bias_partial(float (&cs)[4][4], char* smem, float* dst /* slot row + column base */, int wave, int lane) {
+template <int NS>
+__device__ __forceinline__ void bias_partial(float (&cs)[NS][4][4], char* smem, float* dst /* slot row + column base */, int set_stride,
+                                             int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = cs[i][r];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
-      cs[i][r] = v;
-    }
-  float* red = reinterpret_cast<float*>(smem);
-  __syncthreads();
-  if ((lane & 15) == 0) {
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave * HD + 16 * i + 4 * (lane >> 4) + r] = cs[i][r];
+      for (int r = 0; r < 4; ++r) {
+        float v = cs[s][i][r];  // DPP steps at VALU rate (a __shfl_xor butterfly goes through ds_bpermute: +8 us on the dK / dV launch)
+        v += dpp_f<0xB1, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
+        v += dpp_f<0x4E, 0xf>(0.f, v);   // quad_perm [2,3,0,1]
+        v += dpp_f<0x141, 0xf>(0.f, v);  // row_half_mirror
+        v += dpp_f<0x140, 0xf>(0.f, v);  // row_mirror: every lane holds its 16-lane row total
+        cs[s][i][r] = v;
+      }
+  float* red = reinterpret_cast<float*>(smem);  // [set][wave][64 d]
+  __syncthreads();
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(red + (s * 4 + wave) * HD + 16 * i + 4 * (lane >> 4)) = (f32x4){cs[s][i][0], cs[s][i][1], cs[s][i][2], cs[s][i][3]};
   }
   __syncthreads();
-  if (wave == 0) dst[lane] = (red[lane] + red[HD + lane]) + (red[2 * HD + lane] + red[3 * HD + lane]);
+  if (wave < NS) {  // wave s adds up set s
+    const float* rs = red + wave * 4 * HD;
+    dst[wave * set_stride + lane] = (rs[lane] + rs[HD + lane]) + (rs[2 * HD + lane] + rs[3 * HD + lane]);
+  }
 }
 __device__ __forceinline__ float bf16_round(float v) { return (float)(bf16)v; }
 
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     }
   }
   if (p.bias_part) {  // (uniform)
-    float cs[4][4];
+    float cs[1][4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -553,9 +561,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         float v = 0.f;
 #pragma unroll
         for (int qs = 0; qs < NQS; ++qs) v += qrow[qs] < F ? bf16_round(dq[qs][i][r]) : 0.f;
-        cs[i][r] = v;
+        cs[0][i][r] = v;
       }
-    bias_partial(cs, smem, p.bias_part + ((long)b * gridDim.x + ab.blk) * ld + h * HD, wave, lane);
+    bias_partial<1>(cs, smem, p.bias_part + ((long)b * gridDim.x + ab.blk) * ld + h * HD, 0, wave, lane);
   }
 }
 
@@ -743,28 +751,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     }
   }
   if (p.bias_part) {  // (uniform)
-    float* slot = p.bias_part + ((long)b * gridDim.x + ab.blk) * ld + h * HD;
-    float cs[4][4];
+    float cs[2][4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
+        float vk = 0.f, vv = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) v += krow[ks] < F ? bf16_round(dk[ks][i][r]) : 0.f;
-        cs[i][r] = v;
+        for (int ks = 0; ks < NKS; ++ks) {
+          vk += krow[ks] < F ? bf16_round(dk[ks][i][r]) : 0.f;
+          vv += krow[ks] < F ? bf16_round(dv[ks][i][r] * inv_scale) : 0.f;
+        }
+        cs[0][i][r] = vk;
+        cs[1][i][r] = vv;
       }
-    bias_partial(cs, smem, slot + H, wave, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) v += krow[ks] < F ? bf16_round(dv[ks][i][r] * inv_scale) : 0.f;
-        cs[i][r] = v;
-      }
-    bias_partial(cs, smem, slot + 2 * H, wave, lane);
+    bias_partial<2>(cs, smem, p.bias_part + ((long)b * gridDim.x + ab.blk) * ld + H + h * HD, H, wave, lane);
   }
 }
 
