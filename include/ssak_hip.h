@@ -164,7 +164,7 @@ typedef struct {
   int accumulate; /* C += result (fp32 out only) */
   int split_k;
   float drop_p;        /* > 0: dropout fused into the epilogue (after GELU / on the GELU-grad product) */
-  uint32_t drop_stream; /* mask bit = hash(drop_seed, drop_stream, element offset in C): replayable in backward */
+  uint32_t drop_stream; /* keep(drop_seed, drop_stream, output row z * M + m, output column n): replayable in backward */
   uint64_t drop_seed;
   long bias_s2; /* bias element stride per second-level batch index (grouped conv: one bias slice per group) */
   int pads_are_zero; /* caller guarantees that elements between the logical extent and the next multiple of 8
@@ -482,10 +482,13 @@ int ssak_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* wor
  * (transformers draws torch's global generator at modeling_wav2vec2.py:433,458,568,571,596,692,1698; the reference passes the
  * probabilities at ssak/train/transformers/wav2vec_train.py:313-318).  These two entries write the bits out so that the CPU
  * restatement oracle/dropout_hash.py -- which feeds the SAME masks to transformers.Wav2Vec2ForCTC for the regularisers-on
- * goldens -- is pinned bit for bit against the device functions.  keep [n] uint8 over flat element offsets (row-major
- * [rows, channels] sites); attention: keep [B, nh, F, F] (query-major).  site = the engine's stream id of the dropout site;
+ * goldens -- is pinned bit for bit against the device functions.  Since ABI 500 one definition serves every site:
+ * keep(seed, site, row, col) = rowkey(seed, site, row) * colmul(col) mod 2^32 >= round(p * 65536) << 16, with (row, col) of the
+ * site's row-major [rows, cols] tensor (cols <= 16 384) and, for attention, row = (b * nh + h) * F + q, col = key.  keep
+ * [rows, cols] uint8; attention: keep [B, nh, F, F] (query-major).  site = the engine's stream id of the dropout site;
  * *scale_out (host, may be NULL) = the factor kept elements are multiplied by.  Never called on the hot path. */
-int ssak_debug_dropout_mask(uint64_t seed, uint32_t site, float p, long n, uint8_t* keep, float* scale_out /*host*/, void* stream);
+int ssak_debug_dropout_mask(uint64_t seed, uint32_t site, float p, long rows, int cols, uint8_t* keep, float* scale_out /*host*/,
+                            void* stream);
 int ssak_debug_attention_dropout_mask(uint64_t seed, uint32_t site, float p, int B, int nh, int F, uint8_t* keep, void* stream);
 
 #ifdef __cplusplus

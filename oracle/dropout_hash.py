@@ -1,14 +1,22 @@
 """numpy restatement of the engine's counter-hash dropout masks.  TEST INFRASTRUCTURE ONLY.
 
-The HIP engine never stores a dropout mask: every site recomputes ``keep(seed, site, element)`` in its forward and
-backward kernels (ssak_amd/csrc/common.h ``hash_u32`` / ``keep_bit``; ssak_amd/csrc/attention.hip ``drop_rowseed`` /
-``drop_word``).  This file restates those integer functions so that ``oracle/gen_golden_dropout.py`` can hand the SAME masks
-to ``transformers.Wav2Vec2ForCTC`` in ``train()`` mode (its ``nn.Dropout`` modules and the ``nn.functional.dropout`` call of
-``eager_attention_forward`` are patched to consume them) -- which pins WHERE each of the seven sites sits, and its
-``1 / (1 - p)`` scale, against the third-party model the reference trains
-(``ssak/train/transformers/wav2vec_train.py:161-165,313-325``; transformers ``modeling_wav2vec2.py:429-434`` feature projection,
-``:458`` attention probabilities, ``:565-572`` feed-forward (activation + hidden), ``:591-608`` / ``:631-654`` layer residual,
-``:692`` / ``:765`` encoder input, ``:1697-1700`` head).  Pinned bit-for-bit against the device functions by
+The HIP engine never stores a dropout mask: every site recomputes ``keep(seed, site, row, column)`` in its forward and
+backward kernels (ssak_amd/csrc/common.h ``drop_rowkey`` / ``drop_colmul`` / ``drop_keep``).  Since round 5 ONE definition
+serves every site::
+
+    word(row, col) = rowkey(seed, site, row) * colmul(col)  mod 2^32          keep  iff  word >= thresh16(p) << 16
+    rowkey = hash_u32(seed, site, row) | 1          colmul = hash_u32(COL_SEED, COL_STREAM, col) | 1
+
+with (row, col) of the site's row-major ``[rows, cols]`` tensor and, for the attention probabilities, row = (b * nh + h) * F + q,
+col = key.  (Rounds 1-4 drew a 16-bit field of a two-multiply hash per element pair; the mask generator is the build's own --
+torch's generator cannot be reproduced on the device and the reference asks for no particular bits -- so it was replaced by
+the cheapest form that passes ``quality_report``: one full-rate integer multiply per element.)  This file restates those
+integer functions so that ``oracle/gen_golden_dropout.py`` can hand the SAME masks to ``transformers.Wav2Vec2ForCTC`` in
+``train()`` mode (its ``nn.Dropout`` modules and the ``nn.functional.dropout`` call of ``eager_attention_forward`` are patched to
+consume them) -- which pins WHERE each of the seven sites sits, and its ``1 / (1 - p)`` scale, against the third-party model the
+reference trains (``ssak/train/transformers/wav2vec_train.py:161-165,313-325``; transformers ``modeling_wav2vec2.py:429-434``
+feature projection, ``:458`` attention probabilities, ``:565-572`` feed-forward (activation + hidden), ``:591-608`` / ``:631-654``
+layer residual, ``:692`` / ``:765`` encoder input, ``:1697-1700`` head).  Pinned bit-for-bit against the device functions by
 ``tests/test_gpu_dropout.py::test_dropout_hash_matches_device`` through the debug C-ABI entries ``ssak_debug_dropout_mask`` /
 ``ssak_debug_attention_dropout_mask``.
 
@@ -19,7 +27,7 @@ from __future__ import annotations
 import numpy as np
 
 DS_FEATPROJ, DS_ENCIN, DS_FINAL, DS_LAYER0 = 1, 2, 3, 16
-DROP_PHI = 0x9E3779B9
+COL_SEED, COL_STREAM = 0x5EED0C01A11CE5, 0x51  # common.h DROP_COL_SEED / DROP_COL_STREAM
 _M32 = np.uint64(0xFFFFFFFF)
 
 
@@ -73,36 +81,55 @@ def engine_scale(p: float) -> float:
     return float(np.float32(1.0) / (np.float32(1.0) - np.float32(t) / np.float32(65536.0))) if t else 1.0
 
 
+def rowkey(seed: int, stream: int, rows) -> np.ndarray:
+    """common.h ``drop_rowkey``: the mixer of the row index under (seed, site), forced odd."""
+    return hash_u32(seed, stream, rows) | np.uint64(1)
+
+
+def colmul(cols) -> np.ndarray:
+    """common.h ``drop_colmul``: the mixer of the column (key) index under a fixed key, forced odd."""
+    return hash_u32(COL_SEED, COL_STREAM, cols) | np.uint64(1)
+
+
 def keep_mask(seed: int, stream: int, shape, p: float) -> np.ndarray:
-    """common.h ``keep_bit`` over the flat row-major element offsets of ``shape``: one hash per element PAIR
-    (low 16 bits -> even offset, high 16 bits -> odd offset), keep iff the field >= thresh16(p)."""
-    n = int(np.prod(shape))
+    """keep[row, col] over the row-major view ``[prod(shape[:-1]), shape[-1]]`` of ``shape``: word = rowkey(row) * colmul(col)
+    mod 2^32, keep iff word >= thresh16(p) << 16."""
+    shape = tuple(int(v) for v in shape)
     t = thresh16(p)
     if t == 0:
         return np.ones(shape, dtype=bool)
-    idx = np.arange(n, dtype=np.uint64)
-    w = hash_u32(seed, stream, idx >> np.uint64(1))
-    u = np.where((idx & np.uint64(1)) == 1, w >> np.uint64(16), w & np.uint64(0xFFFF))
-    return (u >= np.uint64(t)).reshape(shape)
+    cols = shape[-1]
+    rows = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+    rk = rowkey(seed, stream, np.arange(rows, dtype=np.uint64))[:, None]
+    cm = colmul(np.arange(cols, dtype=np.uint64))[None, :]
+    w = (rk * cm) & _M32
+    return (w >= np.uint64(t << 16)).reshape(shape)
 
 
 def attention_keep_mask(seed: int, stream: int, B: int, nh: int, F: int, p: float, Fk: int | None = None) -> np.ndarray:
-    """attention.hip: row (b, h, q) has seed hash_u32(seed, stream, (b * nh + h) * F + q); the word of key pair kp of that row
-    is one multiply-xorshift round of (row seed + kp * golden ratio); even key <- low 16 bits, odd key <- high 16 bits.
-    Returns bool [B, nh, F, Fk] (Fk = F unless given)."""
-    Fk = F if Fk is None else Fk
-    t = thresh16(p)
-    if t == 0:
-        return np.ones((B, nh, F, Fk), dtype=bool)
-    rows = np.arange(B * nh * F, dtype=np.uint64)
-    rs = hash_u32(seed, stream, rows)[:, None]
-    k = np.arange(Fk, dtype=np.uint64)[None, :]
-    x = (rs + _mul32(k >> np.uint64(1), DROP_PHI)) & _M32
-    x ^= x >> np.uint64(15)
-    x = _mul32(x, 0x2C1B3C6D)
-    x ^= x >> np.uint64(12)
-    u = np.where((k & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
-    return (u >= np.uint64(t)).reshape(B, nh, F, Fk)
+    """attention.hip: the same function with row = (b * nh + h) * F + q and col = key.  bool [B, nh, F, Fk] (Fk = F unless given)."""
+    return keep_mask(seed, stream, (B * nh * F, F if Fk is None else Fk), p).reshape(B, nh, F, F if Fk is None else Fk)
+
+
+def quality_report(p: float, rows: int = 4096, cols: int = 3072, seed: int = 1234, site: int = 17) -> dict:
+    """Statistics the mask generator is held to (tests/test_oracle.py): drop rate, correlation of the drop indicators between
+    neighbouring columns / rows / diagonal neighbours / another site / another seed, and the variance of the per-row and
+    per-column drop counts relative to a binomial.  ``sigma`` is the iid standard error of a correlation over rows * cols samples;
+    the rank-one structure of the words (rows + cols random numbers) makes the real spread a few times that."""
+    d = (~keep_mask(seed, site, (rows, cols), p)).astype(np.float64)
+    rate = d.mean()
+    d -= p
+    v = p * (1 - p)
+
+    def corr(x, y):
+        return float((x * y).mean() / v)
+    d2 = (~keep_mask(seed, site + 1, (rows, cols), p)).astype(np.float64) - p
+    d3 = (~keep_mask(seed + 1, site, (rows, cols), p)).astype(np.float64) - p
+    cnt_r, cnt_c = (d + p).sum(1), (d + p).sum(0)
+    return {"rate": float(rate), "rate_sigma": float(np.sqrt(v / d.size)), "sigma": float(1 / np.sqrt(d.size)),
+            "col1": corr(d[:, :-1], d[:, 1:]), "col2": corr(d[:, :-2], d[:, 2:]), "col64": corr(d[:, :-64], d[:, 64:]),
+            "row1": corr(d[:-1], d[1:]), "diag": corr(d[:-1, :-1], d[1:, 1:]), "site": corr(d, d2), "seed": corr(d, d3),
+            "row_count_var": float(cnt_r.var() / (cols * v)), "col_count_var": float(cnt_c.var() / (rows * v))}
 
 
 def step_seed_sequence(seed: int, n: int):

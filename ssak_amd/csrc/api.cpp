@@ -18,7 +18,7 @@ void ssak_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int ssak_version(void) { return 400; }  // round 4: ssak_gemm_desc.plan_tile, ssak_comm_* / ssak_allreduce, SSAK_W2V2_OPT_TRANSPOSED_WEIGHTS
+extern "C" int ssak_version(void) { return 500; }  // round 5: one dropout-mask definition (row key x column multiplier), ssak_debug_dropout_mask(rows, cols)
 extern "C" const char* ssak_last_error(void) { return g_err; }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around launches, on the launch's own stream ----

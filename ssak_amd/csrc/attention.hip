@@ -14,9 +14,10 @@
 //            gradient needs cross-workgroup atomics: dQ (workgroup owns 128 queries, sweeps keys; same orientation
 //            as the forward) and dK/dV (workgroup owns 128 keys, sweeps queries; S = Q K^T orientation so that P and
 //            dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS).
-// Dropout bits come from a counter hash of (seed, stream, row, key pair): 16-bit uniforms, two per hash; the
-// forward and both backward kernels regenerate identical masks.  Key-padding masks (ragged batches) are applied as
-// -inf before the softmax, as create_bidirectional_mask does.
+// Dropout bits (common.h): word(row, key) = rowkey(seed, stream, (b * nh + h) * F + q) * colmul(key) mod 2^32, keep iff
+// word >= thresh16 << 16 -- one integer multiply, one compare and one select per score element; the forward and both
+// backward kernels regenerate identical masks.  Key-padding masks (ragged batches) are applied as -inf before the
+// softmax, as create_bidirectional_mask does.
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -33,6 +34,7 @@ constexpr int TILE_BYTES = KT * HD * 2;  // 8 KiB
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 struct AttnParams {
   const bf16* qkv;     // [B*F, 3H]: q | k | v
@@ -65,16 +67,19 @@ __device__ __forceinline__ int opaque_s(int v) {
   return v;
 }
 
-// Dropout bits.  Every (utterance, head, query) row has a seed = hash(seed, stream, row index), computed once per row and
-// kernel; the 32-bit word of key pair kp of that row is one multiply-xorshift round of (row seed + kp * golden ratio):
-// low 16 bits -> even key, high 16 bits -> odd key, keep iff the field >= thresh16.  8 VALU slots per word instead of the
-// 14 of a full hash per pair; neighbouring keys / rows / pairs measured uncorrelated (|rho| < 2e-3 on 2M samples).
+// Dropout bits.  Every (utterance, head, query) row has a key = hash(seed, stream, row index) | 1, computed once per row and
+// kernel; every key index has a multiplier colmul(key) = hash(key) | 1 (a function of the key alone).  Kernels with the key on
+// the accumulator rows (forward, dQ) keep the multipliers of all keys in LDS behind their tiles and read four consecutive ones
+// per `ds_read_b128`; the dK / dV kernel has the key on the lane and keeps its multipliers in registers.  Per element: one
+// `v_mul_lo_u32` (full rate on gfx950), one compare against thresh16 << 16, one select.  Rounds 2-4 spent 5.5 VALU per element
+// on a word per key PAIR (add, xor-shift, multiply, xor-shift, two field tests); statistics of this form: common.h.
 __device__ __forceinline__ uint32_t drop_rowseed(const AttnParams& p, int b, int h, int q) {
-  return attn_drop_rowseed(p.seed, p.stream, (uint32_t)(b * p.nh + h) * (uint32_t)p.F + (uint32_t)min(q, p.F - 1));
+  return drop_rowkey(p.seed, p.stream, (uint64_t)((uint32_t)(b * p.nh + h) * (uint32_t)p.F + (uint32_t)min(q, p.F - 1)));
 }
-// keep tests against thi = thresh16 << 16 (no field extraction: the odd key's field is the word's top half)
-__device__ __forceinline__ bool drop_keep_even(uint32_t w, uint32_t thi) { return (w << 16) >= thi; }
-__device__ __forceinline__ bool drop_keep_odd(uint32_t w, uint32_t thi) { return w >= thi; }
+// the multipliers of keys [0, n) into LDS (n a multiple of 64; visible after the next workgroup barrier)
+__device__ __forceinline__ void fill_colmul(uint32_t* cmt, int n) {
+  for (int k = threadIdx.x; k < n; k += 256) cmt[k] = drop_colmul((uint32_t)k);
+}
 
 // LDS tile images (64 rows x 128 B each):
 //   row-read image  : chunk c of row r at c ^ ((r >> 1) & 7)      -> ds_read_b128 fragments (row on the lane)
@@ -268,6 +273,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   uint32_t rowseed[NQS];
 #pragma unroll
   for (int qs = 0; qs < NQS; ++qs) rowseed[qs] = drop_rowseed(p, b, h, qrow[qs]);
+  const uint32_t* cmt = reinterpret_cast<const uint32_t*>(smem + 2 * 2 * TILE_BYTES);  // [nkt * 64] key multipliers (DROP)
+  if (DROP) fill_colmul(reinterpret_cast<uint32_t*>(smem + 2 * 2 * TILE_BYTES), nkt * KT);
   f32x4 oacc[NQS][4];
 #pragma unroll
   for (int qs = 0; qs < NQS; ++qs)
@@ -308,6 +315,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     // in the tile that crosses the key length; the dropout scale is applied once, to O, at the end.
     bf16x8 pb[NQS][2];
     const bool edge = k0 + KT > kl;  // uniform
+    u32x4_t cm[4];  // multipliers of this lane's keys k0 + 16 ks + 4 g + r (shared by the query sub-tiles)
+    if (DROP) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) cm[ks] = *reinterpret_cast<const u32x4_t*>(cmt + k0 + 16 * ks + 4 * g);
+    }
 #pragma unroll
     for (int qs = 0; qs < NQS; ++qs) {
       if (edge) {
@@ -336,7 +348,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qs], c2, -mc));  // first tile: exp2(-inf) = 0 on a zero accumulator
       f32x2 rs2 = {0.f, 0.f};  // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): the pair's two exponent arguments and the row sum
       const f32x2 c2v = {c2, c2}, mcv = {-mc, -mc};
-      const uint32_t xrow = rowseed[qs] + (uint32_t)((k0 >> 1) + 2 * g) * DROP_PHI;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -345,9 +356,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
           f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
           rs2 += e;
           if (DROP) {
-            const uint32_t w = drop_word(xrow + (uint32_t)(8 * ks + (r2 >> 1)) * DROP_PHI);
-            e[0] = drop_keep_even(w, thi) ? e[0] : 0.f;
-            e[1] = drop_keep_odd(w, thi) ? e[1] : 0.f;
+            e[0] = drop_keep(rowseed[qs], cm[ks][r2], thi) ? e[0] : 0.f;
+            e[1] = drop_keep(rowseed[qs], cm[ks][r2 + 1], thi) ? e[1] : 0.f;
           }
           s[qs][ks][r2] = e[0];
           s[qs][ks][r2 + 1] = e[1];
@@ -461,6 +471,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   for (int qs = 0; qs < NQS; ++qs)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const uint32_t* cmt = reinterpret_cast<const uint32_t*>(smem + 2 * 2 * TILE_BYTES);  // [nkt * 64] key multipliers (DROP)
+  if (DROP) fill_colmul(reinterpret_cast<uint32_t*>(smem + 2 * 2 * TILE_BYTES), nkt * KT);
   auto issue = [&](int kt, int stage) {
     char* s0 = smem + stage * 2 * TILE_BYTES;
     dma_tile(rsrc, s0, kcol, ld * 2, kt * KT, F, 2, wave, lane);
@@ -508,21 +520,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
               for (int r = 0; r < 4; ++r)
                 if (k0 + 16 * (2 * t2 + kh) + 4 * g + r >= klo) s[qs][kh][r] = -INFINITY;
         }
+        u32x4_t cm[2];  // multipliers of this lane's keys of this half (shared by the query sub-tiles)
+        if (DROP) {
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) cm[kh] = *reinterpret_cast<const u32x4_t*>(cmt + k0 + 16 * (2 * t2 + kh) + 4 * g);
+        }
 #pragma unroll
         for (int qs = 0; qs < NQS; ++qs) {
           // P'' = exp2(s * c2 - lsc) = P * scale / (1 - p); dS = P'' (keep ? dP : 0 - delta (1 - p)).  Rows without any valid
           // key have lse = -inf -> lsc = +inf -> P'' = 0.  Packed fp32 over the key pair.
           const f32x2 c2v = {c2, c2}, lscv = {-lse2[qs], -lse2[qs]}, dlv = {dl[qs], dl[qs]};
-          const uint32_t xrow = rowbase[qs] + (uint32_t)((k0 >> 1) + 2 * g) * DROP_PHI;
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int r2 = 0; r2 < 4; r2 += 2) {
               f32x2 d = {dp[qs][kh][r2], dp[qs][kh][r2 + 1]};
               if (DROP) {
-                const uint32_t w = drop_word(xrow + (uint32_t)(8 * (2 * t2 + kh) + (r2 >> 1)) * DROP_PHI);
-                d[0] = drop_keep_even(w, thi) ? d[0] : 0.f;
-                d[1] = drop_keep_odd(w, thi) ? d[1] : 0.f;
+                d[0] = drop_keep(rowbase[qs], cm[kh][r2], thi) ? d[0] : 0.f;
+                d[1] = drop_keep(rowbase[qs], cm[kh][r2 + 1], thi) ? d[1] : 0.f;
               }
               const f32x2 a = (f32x2){s[qs][kh][r2], s[qs][kh][r2 + 1]} * c2v + lscv;
               const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
@@ -599,11 +614,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     }
   }
   const float c2 = p.scale * 1.4426950408889634f;
-  const float log2scale = __log2f(p.scale);
+  // exponent offset: P'' = P * scale / (1 - p) -- Pd = keep ? P'' : 0 and dS = P'' (keep ? dP : 0 - delta (1 - p)) need no multiply
+  // by the dropout scale (delta is rescaled once per row when it is staged), as in the dQ kernel
+  const float log2scale = __log2f(p.scale * p.drop_scale);
+  const float inv_drop_scale = 1.f / p.drop_scale;
   const uint32_t thi = p.thresh16 << 16;
-  uint32_t kphi[NKS];
+  uint32_t cmk[NKS];  // dropout multiplier of this lane's key (common.h)
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) kphi[ks] = (uint32_t)(krow[ks] >> 1) * DROP_PHI;
+  for (int ks = 0; ks < NKS; ++ks) cmk[ks] = DROP ? drop_colmul((uint32_t)krow[ks]) : 1u;
   // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
   f32x4 sinit[NKS];
 #pragma unroll
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       // rows beyond F or without a valid key: +inf here makes P = exp2(.. - inf) = 0 without a select per element; the softmax
       // scale rides in the exponent (P' = P * scale: dS needs no multiply, dV is rescaled once at the end)
       stat[stage * 3 * KT + threadIdx.x] = ls > -INFINITY ? fmaf(ls, 1.4426950408889634f, -log2scale) : INFINITY;
-      stat[stage * 3 * KT + KT + threadIdx.x] = q < F ? p.delta[o] : 0.f;
+      stat[stage * 3 * KT + KT + threadIdx.x] = q < F ? p.delta[o] * inv_drop_scale : 0.f;
       reinterpret_cast<uint32_t*>(stat)[stage * 3 * KT + 2 * KT + threadIdx.x] = drop_rowseed(p, b, h, q);
     }
   };
@@ -671,23 +689,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
         }
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
-          // Dropout words of this lane's 4 queries x 2 keys.  A word covers a key PAIR and the pair sits in two adjacent
-          // lanes, so each lane mixes two of the four query rows and takes the other two from its partner by DPP.
-          uint32_t W[NKS][4];
-          if (DROP) {
-            const int par = lane & 1;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const uint32_t rs = seed_s[16 * (2 * t2 + qh) + 4 * g + par + 2 * i];  // row par + 2i of this lane's four
-#pragma unroll
-              for (int ks = 0; ks < NKS; ++ks) {
-                const uint32_t mine = drop_word(rs + kphi[ks]);
-                const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);  // row 1 - par + 2i
-                W[ks][2 * i] = par ? other : mine;
-                W[ks][2 * i + 1] = par ? mine : other;
-              }
-            }
-          }
+          // dropout keys of this lane's 4 query rows (staged with lse / delta): one 16-byte LDS read
+          u32x4_t rk = {1u, 1u, 1u, 1u};
+          if (DROP) rk = *reinterpret_cast<const u32x4_t*>(seed_s + 16 * (2 * t2 + qh) + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; r += 2) {  // packed fp32 over the row pair
             const int ql = 16 * (2 * t2 + qh) + 4 * g + r;  // query inside the tile
@@ -695,20 +699,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
               const f32x2 a = (f32x2){s[ks][qh][r], s[ks][qh][r + 1]} * c2v + lscv;
-              f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};  // P * scale
+              const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};  // P * scale / (1 - p)
               f32x2 dpv = {dp[ks][qh][r], dp[ks][qh][r + 1]}, pd = pr;
               if (DROP) {
-                f32x2 keep;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                  const uint32_t w = W[ks][r + e];
-                  const bool k = (krow[ks] & 1) ? drop_keep_odd(w, thi) : drop_keep_even(w, thi);
-                  keep[e] = k ? p.drop_scale : 0.f;
+                  const bool k = drop_keep(rk[r + e], cmk[ks], thi);
+                  dpv[e] = k ? dpv[e] : 0.f;
+                  pd[e] = k ? pd[e] : 0.f;
                 }
-                dpv *= keep;
-                pd *= keep;
               }
-              const f32x2 ds2 = pr * (dpv - dlv);  // dS (scale included)
+              const f32x2 ds2 = pr * (dpv - dlv);  // dS (softmax scale included)
               s[ks][qh][r] = pd[0];                 // Pd * scale
               s[ks][qh][r + 1] = pd[1];
               dp[ks][qh][r] = ds2[0];
@@ -821,7 +822,15 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse, const int32_t* klens
   const AttnParams p = make_params(qkv, ctx, lse, klens, nullptr, nullptr, nullptr, B, F, nh, H, drop);
   ProfScope prof_scope(PROF_ATTN_FWD, 4.0 * B * nh * (double)F * F * HD, st);  // S = Q K^T and O = P V
   const int nqs = attn_tile(0);
-#define ATT_LAUNCH_FWD(D, N) attn_fwd_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p)
+  SSAK_REQUIRE(!p.thresh16 || F <= DROP_TABLE_N, "attention: dropout is built for at most %d frames", DROP_TABLE_N);
+  const int cm_lds = p.thresh16 ? ssak_cdiv(F, KT) * KT * 4 : 0;  // the keys' dropout multipliers behind the tiles
+  static bool fwd_attr_done = false;
+  if (!fwd_attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * TILE_BYTES + DROP_TABLE_N * 4));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * TILE_BYTES + DROP_TABLE_N * 4));
+    fwd_attr_done = true;
+  }
+#define ATT_LAUNCH_FWD(D, N) attn_fwd_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 2 * TILE_BYTES + cm_lds, st>>>(p)
   if (p.thresh16) {
     if (nqs == 1) ATT_LAUNCH_FWD(true, 1); else ATT_LAUNCH_FWD(true, 2);
   } else {
@@ -851,7 +860,15 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
   p.bias_part = bias_part;
   ProfScope prof_scope(PROF_ATTN_BWD, 8.0 * B * nh * (double)F * F * HD, st);  // dV, dP, dQ, dK (the recomputed S is not algorithmic work)
   const int nqs = attn_tile(1), nks = attn_tile(2);
-#define ATT_LAUNCH_DQ(D, N) attn_bwd_dq_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 2 * TILE_BYTES, st>>>(p)
+  SSAK_REQUIRE(!p.thresh16 || F <= DROP_TABLE_N, "attention: dropout is built for at most %d frames", DROP_TABLE_N);
+  const int cm_lds = p.thresh16 ? ssak_cdiv(F, KT) * KT * 4 : 0;  // the keys' dropout multipliers behind the tiles
+  static bool dq_attr_done = false;
+  if (!dq_attr_done) {
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * TILE_BYTES + DROP_TABLE_N * 4));
+    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * TILE_BYTES + DROP_TABLE_N * 4));
+    dq_attr_done = true;
+  }
+#define ATT_LAUNCH_DQ(D, N) attn_bwd_dq_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, 2 * 2 * TILE_BYTES + cm_lds, st>>>(p)
   if (p.thresh16) {
     if (nqs == 1) ATT_LAUNCH_DQ(true, 1); else ATT_LAUNCH_DQ(true, 2);
   } else {

@@ -894,6 +894,7 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
   p.colsum = nullptr;
   SSAK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p must be in [0,1)");
   SSAK_REQUIRE(!(d->drop_p > 0.f && d->split_k > 1), "gemm: dropout epilogue is not available with split_k");
+  SSAK_REQUIRE(!(d->drop_p > 0.f) || d->N <= DROP_TABLE_N, "gemm: the dropout epilogue is built for at most %d output columns", DROP_TABLE_N);
   const int nkt = ssak_cdiv(d->K, BK);
   p.kt_per_split = ssak_cdiv(nkt, split);
   if (split > 1)

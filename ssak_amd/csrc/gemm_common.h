@@ -5,6 +5,8 @@
 
 namespace {
 
+SSAK_DEFINE_DROP_TABLE
+
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
 
@@ -149,6 +151,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int n = bn0 + wn0 + 8 * cp;
     long o = S ? (long)(bm0 + wm0 + r0) * p.N + n : coff + (long)(bm0 + wm0 + r0) * p.ldc + n;
     const long ostep = (long)RPI2 * (S ? (long)p.N : p.ldc);
+    // dropout (common.h): word = rowkey(seed, site, output row) * colmul(output column); this lane's 8 columns are fixed
+    uint32_t cm[8];
+    if (p.drop_thresh) {
+      const uint4 t0 = *reinterpret_cast<const uint4*>(g_drop_colmul.v + n), t1 = *reinterpret_cast<const uint4*>(g_drop_colmul.v + n + 4);
+      cm[0] = t0.x, cm[1] = t0.y, cm[2] = t0.z, cm[3] = t0.w, cm[4] = t1.x, cm[5] = t1.y, cm[6] = t1.z, cm[7] = t1.w;
+    }
+    const uint32_t thi = p.drop_thresh << 16;
 #pragma unroll 2
     for (int row = r0; row < 16 * MI; row += RPI2, o += ostep) {
       const int c0 = (2 * cp) ^ (row & (CPR - 1));
@@ -201,15 +210,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       }
       if (p.drop_thresh) {
+        const uint32_t rk = drop_rowkey(p.drop_seed, p.drop_stream, (uint64_t)z * p.M + (bm0 + wm0 + row));
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const uint32_t w = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o + 2 * h);
-          v[2 * h] = ((w & 0xffffu) >= p.drop_thresh) ? v[2 * h] * p.drop_scale : 0.f;
-          v[2 * h + 1] = ((w >> 16) >= p.drop_thresh) ? v[2 * h + 1] * p.drop_scale : 0.f;
-          if (save_grad) {  // (the factor's code carries the mask; its 1 / (1 - p) is applied at decode)
-            gd[2 * h] = ((w & 0xffffu) >= p.drop_thresh) ? gd[2 * h] : 0.f;
-            gd[2 * h + 1] = ((w >> 16) >= p.drop_thresh) ? gd[2 * h + 1] : 0.f;
-          }
+        for (int h = 0; h < 8; ++h) {
+          const bool keep = drop_keep(rk, cm[h], thi);
+          v[h] = keep ? v[h] * p.drop_scale : 0.f;
+          if (save_grad) gd[h] = keep ? gd[h] : 0.f;  // (the factor's code carries the mask; its 1 / (1 - p) is applied at decode)
         }
       }
       if (save_grad && p.aux_out)
@@ -295,19 +301,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           if (n + r < p.N) v[r] *= gelu_grad_f((float)p.aux_in[o + r]);
       }
     }
-    if (p.drop_thresh) {
-      // o is a multiple of 4 (n = ... + 4*chunk, ldc % 4 == 0): two hashes give the four 16-bit uniforms
-      const uint32_t w0 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o);
-      const uint32_t w1 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)o + 2);
-      v[0] = ((w0 & 0xffffu) >= p.drop_thresh) ? v[0] * p.drop_scale : 0.f;
-      v[1] = ((w0 >> 16) >= p.drop_thresh) ? v[1] * p.drop_scale : 0.f;
-      v[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[2] * p.drop_scale : 0.f;
-      v[3] = ((w1 >> 16) >= p.drop_thresh) ? v[3] * p.drop_scale : 0.f;
-      if (save_grad) {
-        gd[0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[0] : 0.f;
-        gd[1] = ((w0 >> 16) >= p.drop_thresh) ? gd[1] : 0.f;
-        gd[2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[2] : 0.f;
-        gd[3] = ((w1 >> 16) >= p.drop_thresh) ? gd[3] : 0.f;
+    if (p.drop_thresh) {  // (edge tiles: the column multipliers by their hash, no table bounds to mind)
+      const uint32_t rk = drop_rowkey(p.drop_seed, p.drop_stream, (uint64_t)z * p.M + m);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool keep = drop_keep(rk, drop_colmul((uint32_t)(n + r)), p.drop_thresh << 16);
+        v[r] = keep ? v[r] * p.drop_scale : 0.f;
+        if (save_grad) gd[r] = keep ? gd[r] : 0.f;
       }
     }
     if (save_grad && p.aux_out) {
@@ -452,6 +452,18 @@ __device__ __forceinline__ void load_fq_codes(const GemmParams& p, FqCodes<MI>& 
 #pragma unroll
   for (int i = 0; i < MI; ++i) c.w[i] = 16 * i < rows_valid ? *reinterpret_cast<const u32x4*>(src + (long)16 * i * p.ldc) : (u32x4){0u, 0u, 0u, 0u};
 }
+// the 16 dropout column multipliers (common.h) of a lane's columns bn0 + wn0 + 16 j + 4 lq + r of a 64-column wave tile
+struct DropCols {
+  uint32_t v[4][4];
+};
+__device__ __forceinline__ void load_drop_cols(DropCols& d, int bn0, int wn0, int lane) {
+  const uint32_t* cmp = g_drop_colmul.v + bn0 + wn0 + 4 * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint4 t = *reinterpret_cast<const uint4*>(cmp + 16 * j);
+    d.v[j][0] = t.x, d.v[j][1] = t.y, d.v[j][2] = t.z, d.v[j][3] = t.w;
+  }
+}
 template <int MI, int EPI = -1>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 (&acc)[MI][4], const BiasRegs<4>& br, int bm0,
                                                      int bn0, int wm0, int wn0, int lane, int z, int z1, int z2, int split,
@@ -506,6 +518,28 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
   }
   constexpr bool WITH_COLSUM = GENERAL || EPI == SSAK_EPI_MUL_AUX;
   constexpr bool WITH_DROP = GENERAL || EPI == SSAK_EPI_GELU_SAVE_GRAD;
+  // The feed-forward up-projection (GELU_SAVE_GRAD + dropout) is the kernel's widest epilogue, at the register limit.  Its
+  // dropout needs the 16 column multipliers of this lane (common.h) for every 16-row group; they take the place of the 16 bias
+  // values: alpha and bias are applied to ALL accumulators first (the same one fma per element), after which the bias
+  // registers are dead.  (Read again per group instead, each group waited out an L1 round trip: +53 us per step, measured.)
+  constexpr bool PRE_BIAS = EPI == SSAK_EPI_GELU_SAVE_GRAD;
+  uint32_t cmv[PRE_BIAS ? 4 : 1][4];
+  if constexpr (PRE_BIAS) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * p.alpha + br.v[j][r];
+    if (p.drop_thresh) {
+      DropCols dc;  // (loaded here, not ahead of the next tile's priming: 16 more values live across the priming spilled at
+      load_drop_cols(dc, bn0, wn0, lane);  // 256-row tiles and cost the launch 5 %, profiles/r05_ab_dropout_hash.log)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cmv[j][r] = dc.v[j][r];
+    }
+  }
   float cs[4][4];  // column sums over this lane's rows (p.colsum)
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -520,7 +554,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] * p.alpha + br.v[j][r];
+      for (int r = 0; r < 4; ++r) v[j][r] = PRE_BIAS ? acc[i][j][r] : acc[i][j][r] * p.alpha + br.v[j][r];
     float gd[4][4];  // SSAK_EPI_GELU_SAVE_GRAD: gelu'(pre), masked and scaled like the output -- the backward's factor
     constexpr bool save_grad = EPI == SSAK_EPI_GELU_SAVE_GRAD;
     if ((GENERAL && p.epilogue == SSAK_EPI_GELU) || save_grad || EPI == P8_EPI_GELU_ONLY) {
@@ -567,19 +601,27 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, f32x4 
         }
     }
     if (WITH_DROP && p.drop_thresh) {
+      // dropout (common.h): word = rowkey(seed, site, output row) * colmul(output column) -- one hash per 16-row group and lane,
+      // the 16 column multipliers from the table (general form: read per group, the same 64 bytes per lane every time,
+      // L1-resident; the feed-forward form holds them in the registers the bias had: PRE_BIAS above)
+      const uint32_t rk = drop_rowkey(p.drop_seed, p.drop_stream, (uint64_t)z * p.M + (bm0 + wm0 + 16 * i + lm));
+      const uint32_t thi = p.drop_thresh << 16;
+      const uint32_t* cmp = g_drop_colmul.v + bn0 + wn0 + 4 * lq;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t w0 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)(oa + 16 * j));
-        const uint32_t w1 = hash_pair16(p.drop_seed, p.drop_stream, (uint64_t)(oa + 16 * j) + 2);
-        v[j][0] = ((w0 & 0xffffu) >= p.drop_thresh) ? v[j][0] * p.drop_scale : 0.f;
-        v[j][1] = ((w0 >> 16) >= p.drop_thresh) ? v[j][1] * p.drop_scale : 0.f;
-        v[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? v[j][2] * p.drop_scale : 0.f;
-        v[j][3] = ((w1 >> 16) >= p.drop_thresh) ? v[j][3] * p.drop_scale : 0.f;
-        if (save_grad) {  // (the factor's code carries the mask; its 1 / (1 - p) is applied at decode)
-          gd[j][0] = ((w0 & 0xffffu) >= p.drop_thresh) ? gd[j][0] : 0.f;
-          gd[j][1] = ((w0 >> 16) >= p.drop_thresh) ? gd[j][1] : 0.f;
-          gd[j][2] = ((w1 & 0xffffu) >= p.drop_thresh) ? gd[j][2] : 0.f;
-          gd[j][3] = ((w1 >> 16) >= p.drop_thresh) ? gd[j][3] : 0.f;
+        uint32_t cm[4];
+        if constexpr (PRE_BIAS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cm[r] = cmv[j][r];
+        } else {
+          const uint4 t = *reinterpret_cast<const uint4*>(cmp + 16 * j);
+          cm[0] = t.x, cm[1] = t.y, cm[2] = t.z, cm[3] = t.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool keep = drop_keep(rk, cm[r], thi);
+          v[j][r] = keep ? v[j][r] * p.drop_scale : 0.f;
+          if (save_grad) gd[j][r] = keep ? gd[j][r] : 0.f;  // (the factor's code carries the mask; its 1 / (1 - p) is applied at decode)
         }
       }
     }

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Params p) {
       v = gelu_s<float>(v);
     }
     if (p.drop_thresh) {
-      const bool keep = keep_bit(p.drop_seed, p.drop_stream, (uint64_t)o, p.drop_thresh);
+      const bool keep = keep_bit(p.drop_seed, p.drop_stream, (uint64_t)z * p.M + m, (uint32_t)n, p.drop_thresh);  // (row, column) of the output: common.h
       v = keep ? v * p.drop_scale : 0.f;
       gd = keep ? gd * p.drop_scale : 0.f;
     }

@@ -14,7 +14,18 @@
 
 namespace {
 
+SSAK_DEFINE_DROP_TABLE
+
 constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows per workgroup
+// the dropout column multipliers of a lane's chunk (common.h: word = rowkey * colmul): VEC consecutive table entries
+template <int VEC>
+__device__ __forceinline__ void load_colmul(uint32_t (&cm)[VEC], int col0) {
+#pragma unroll
+  for (int k = 0; k < VEC; k += 4) {
+    const uint4 t = *reinterpret_cast<const uint4*>(g_drop_colmul.v + col0 + k);
+    cm[k] = t.x, cm[k + 1] = t.y, cm[k + 2] = t.z, cm[k + 3] = t.w;
+  }
+}
 
 // chunk of VEC elements of type T (common.h: Chunk8 / Chunk4)
 template <typename T, int VEC>
@@ -53,6 +64,13 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams<T
   const int nch = p.C >> 3;
   float v[NCH][8];
   float s = 0.f;
+  // dropout words = row key (one hash per site and row) x column multiplier (table): common.h
+  const bool any_drop = (p.pre_thresh | p.mid_thresh | p.post_thresh) != 0;  // (uniform)
+  const uint32_t rk_pre = p.pre_thresh ? drop_rowkey(p.seed, p.pre_stream, (uint64_t)row) : 1u;
+  const uint32_t rk_mid = p.mid_thresh ? drop_rowkey(p.seed, p.mid_stream, (uint64_t)row) : 1u;
+  const uint32_t rk_post = p.post_thresh ? drop_rowkey(p.seed, p.post_stream, (uint64_t)row) : 1u;
+  const uint32_t thi_pre = p.pre_thresh << 16, thi_mid = p.mid_thresh << 16, thi_post = p.post_thresh << 16;
+  uint32_t cm[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
@@ -60,12 +78,12 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams<T
     for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
     if (ch < nch) {
       const size_t o = (size_t)row * p.C + ch * 8;
-      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
+      if (any_drop) load_colmul<8>(cm[i], ch * 8);
       if (p.y) {
         chunk_to_f(ld8<T>(p.y + o), v[i]);
         if (p.pre_thresh) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[i][k] = keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh) ? v[i][k] * p.pre_scale : 0.f;
+          for (int k = 0; k < 8; ++k) v[i][k] = drop_keep(rk_pre, cm[i][k], thi_pre) ? v[i][k] * p.pre_scale : 0.f;
         }
       }
       if (p.res) {
@@ -76,7 +94,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams<T
       }
       if (p.mid_thresh) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[i][k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? v[i][k] * p.mid_scale : 0.f;
+        for (int k = 0; k < 8; ++k) v[i][k] = drop_keep(rk_mid, cm[i][k], thi_mid) ? v[i][k] * p.mid_scale : 0.f;
       }
       if (p.r_out) {
         // round through the storage type so that forward and backward see the same LN input
@@ -110,7 +128,6 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams<T
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const size_t o = (size_t)row * p.C + ch * 8;
-      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       float g[8], b[8], w[8];
       *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(p.gamma + ch * 8);
       *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(p.gamma + ch * 8 + 4);
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams<T
       for (int k = 0; k < 8; ++k) {
         w[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
         if (p.post_gelu) w[k] = gelu_s<T>(w[k]);
-        if (p.post_thresh) w[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? w[k] * p.post_scale : 0.f;
+        if (p.post_thresh) w[k] = drop_keep(rk_post, cm[i][k], thi_post) ? w[k] * p.post_scale : 0.f;
       }
       st8<T>(p.out + o, f_to_chunk8<T>(w));
     }
@@ -156,14 +173,18 @@ struct LnBwdParams {
 // VEC = elements per lane chunk: 8 (16-byte accesses) in general; 4 (8-byte accesses) when that divides the row evenly over
 // the 64 lanes -- C = 768 is 96 chunks of 8, i.e. 64 + 32 lanes (a quarter of the lane slots and of the registers idle), but
 // exactly 3 chunks of 4 per lane.
-template <typename T, int NCH, int VEC>
+// PGELU: the forward applied GELU after the affine (p.beta non-null; XLSR feature-encoder conv layers) -- a template flag so
+// that the beta registers exist only in that instantiation; DROP: any dropout site active (the column multipliers stay in
+// registers for all of a wave's rows).
+template <typename T, int NCH, int VEC, bool PGELU, bool DROP>
 __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T> p) {
   using VecT = ChunkT<T, VEC>;
   __shared__ float red[3][ROW_THREADS / 64][NCH * VEC][64];  // [dgamma|dbeta|dy sum][wave][slot][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.C / VEC;
   const int wid = blockIdx.x * (ROW_THREADS / 64) + wave;
-  float ag[NCH][VEC], ab[NCH][VEC], gm[NCH][VEC], ay[NCH][VEC], bt[NCH][VEC];
+  float ag[NCH][VEC], ab[NCH][VEC], gm[NCH][VEC], ay[NCH][VEC], bt[PGELU ? NCH : 1][VEC];
+  uint32_t cm[DROP ? NCH : 1][VEC];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
@@ -173,9 +194,11 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
       ab[i][k] = 0.f;
       ay[i][k] = 0.f;
       gm[i][k] = (ch < nch) ? p.gamma[ch * VEC + k] : 0.f;
-      bt[i][k] = (ch < nch && p.beta) ? p.beta[ch * VEC + k] : 0.f;
+      if (PGELU) bt[i][k] = (ch < nch) ? p.beta[ch * VEC + k] : 0.f;
     }
+    if (DROP && ch < nch) load_colmul<VEC>(cm[i], ch * VEC);
   }
+  const uint32_t thi_pre = p.pre_thresh << 16, thi_mid = p.mid_thresh << 16, thi_post = p.post_thresh << 16;
   // raw operands of the row a wave works on are fetched one row ahead: a wave owns ~8 rows and every row is a dependent
   // chain load -> two wave reductions -> store, so without the prefetch the kernel ran at HBM latency, not bandwidth
   const int rstep = gridDim.x * (ROW_THREADS / 64);
@@ -189,7 +212,6 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
       const int ch = lane + 64 * i;
       if (ch < nch) {
         const size_t o = (size_t)row * p.C + ch * VEC;
-        __builtin_assume((o & (VEC - 1)) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
         ra[i] = *reinterpret_cast<const VecT*>(p.g1 + o);
         if (p.g2) rb[i] = *reinterpret_cast<const VecT*>(p.g2 + o);
         rx[i] = *reinterpret_cast<const VecT*>(p.r + o);
@@ -199,6 +221,12 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
   if (wid < p.M) fetch(wid);
   for (int row = wid; row < p.M; row += rstep) {
     const float mean = mean_n, rstd = rstd_n;
+    uint32_t rk_pre = 1u, rk_mid = 1u, rk_post = 1u;  // this row's dropout keys (common.h), one hash per active site
+    if (DROP) {
+      if (p.pre_thresh) rk_pre = drop_rowkey(p.seed, p.pre_stream, (uint64_t)row);
+      if (p.mid_thresh) rk_mid = drop_rowkey(p.seed, p.mid_stream, (uint64_t)row);
+      if (p.post_thresh) rk_post = drop_rowkey(p.seed, p.post_stream, (uint64_t)row);
+    }
     float dyv[NCH][VEC], xh[NCH][VEC];
     float s1 = 0.f, s2 = 0.f;
     VecT ca[NCH], cb[NCH], cx[NCH];
@@ -218,8 +246,6 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
         xh[i][k] = 0.f;
       }
       if (ch < nch) {
-        const size_t o = (size_t)row * p.C + ch * VEC;
-        __builtin_assume((o & (VEC - 1)) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
         float a[VEC], x[VEC];
         chunk_to_f(ca[i], a);
         if (p.g2) {
@@ -231,9 +257,9 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
         chunk_to_f(cx[i], x);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          if (p.post_thresh) a[k] = keep_bit(p.seed, p.post_stream, o + k, p.post_thresh) ? a[k] * p.post_scale : 0.f;
+          if (DROP && p.post_thresh) a[k] = drop_keep(rk_post, cm[i][k], thi_post) ? a[k] * p.post_scale : 0.f;
           xh[i][k] = (x[k] - mean) * rstd;
-          if (p.beta) a[k] *= gelu_grad_s<T>(fmaf(xh[i][k], gm[i][k], bt[i][k]));
+          if (PGELU) a[k] *= gelu_grad_s<T>(fmaf(xh[i][k], gm[i][k], bt[i][k]));
           ag[i][k] += a[k] * xh[i][k];
           ab[i][k] += a[k];
           dyv[i][k] = a[k] * gm[i][k];
@@ -249,7 +275,6 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
       const int ch = lane + 64 * i;
       if (ch < nch) {
         const size_t o = (size_t)row * p.C + ch * VEC;
-        __builtin_assume((o & (VEC - 1)) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
         float d[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) d[k] = rstd * (dyv[i][k] - s1 - xh[i][k] * s2);
@@ -259,15 +284,15 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
 #pragma unroll
           for (int k = 0; k < VEC; ++k) d[k] += e[k];
         }
-        if (p.mid_thresh) {
+        if (DROP && p.mid_thresh) {
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) d[k] = keep_bit(p.seed, p.mid_stream, o + k, p.mid_thresh) ? d[k] * p.mid_scale : 0.f;
+          for (int k = 0; k < VEC; ++k) d[k] = drop_keep(rk_mid, cm[i][k], thi_mid) ? d[k] * p.mid_scale : 0.f;
         }
         *reinterpret_cast<VecT*>(p.dr + o) = f_to_chunk<T, VEC>(d);
         if (p.dy) {
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
-            d[k] = (!p.pre_thresh || keep_bit(p.seed, p.pre_stream, o + k, p.pre_thresh)) ? d[k] * p.pre_scale : 0.f;
+            d[k] = (!(DROP && p.pre_thresh) || drop_keep(rk_pre, cm[i][k], thi_pre)) ? d[k] * p.pre_scale : 0.f;
             ay[i][k] += d[k];  // fp32 values, before the rounding of the store
           }
           *reinterpret_cast<VecT*>(p.dy + o) = f_to_chunk<T, VEC>(d);
@@ -412,16 +437,15 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_fwd_kernel(const SoftmaxP
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const size_t o = (size_t)row * p.ld + ch * 8;
-      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       float pr[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) pr[k] = v[i][k] * inv;
       st8<T>(p.P + o, f_to_chunk8<T>(pr));
       if (p.Pd) {
         // the fused attention kernels' bits (common.h attn_keep_bit): row = (b * nh + h) * F + q, key = column
-        const uint32_t rs = attn_drop_rowseed(p.seed, p.stream, (uint32_t)row);
+        const uint32_t rs = drop_rowkey(p.seed, p.stream, (uint64_t)row);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pr[k] = (!p.thresh || attn_keep_bit(rs, (uint32_t)(ch * 8 + k), p.thresh)) ? pr[k] * p.scale : 0.f;
+        for (int k = 0; k < 8; ++k) pr[k] = (!p.thresh || drop_keep(rs, drop_colmul((uint32_t)(ch * 8 + k)), p.thresh << 16)) ? pr[k] * p.scale : 0.f;
         st8<T>(p.Pd + o, f_to_chunk8<T>(pr));
       }
     }
@@ -447,7 +471,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
   const int nch = p.ld >> 3;
   float pr[NCH][8], dp[NCH][8];
   float dot = 0.f;
-  const uint32_t rs = attn_drop_rowseed(p.seed, p.stream, (uint32_t)row);
+  const uint32_t rs = drop_rowkey(p.seed, p.stream, (uint64_t)row);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ch = lane + 64 * i;
@@ -458,7 +482,6 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
     }
     if (ch < nch) {
       const size_t o = (size_t)row * p.ld + ch * 8;
-      __builtin_assume((o & 7) == 0);  // chunk base: lets the pair hashes of keep_bit be shared
       float g[8];
       chunk_to_f(ld8<T>(p.P + o), pr[i]);
       chunk_to_f(ld8<T>(p.dPd + o), g);
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_bwd_kernel(const SoftmaxB
       for (int k = 0; k < 8; ++k) {
         const bool in = ch * 8 + k < p.cols;
         pr[i][k] = in ? pr[i][k] : 0.f;
-        dp[i][k] = (in && (!p.thresh || attn_keep_bit(rs, (uint32_t)(ch * 8 + k), p.thresh))) ? g[k] * p.scale : 0.f;
+        dp[i][k] = (in && (!p.thresh || drop_keep(rs, drop_colmul((uint32_t)(ch * 8 + k)), p.thresh << 16))) ? g[k] * p.scale : 0.f;
         dot += pr[i][k] * dp[i][k];
       }
     }
@@ -651,14 +674,22 @@ int k_layernorm_bwd_t(const T* g1, const T* g2, const T* r, const float* mean, c
   const int grid = std::min(LN_BWD_BLOCKS, ssak_cdiv(M, ROW_THREADS / 64));
   const int nch = ssak_cdiv(C / 8, 64);
   ProfScope prof_scope(PROF_LN_BWD, (double)M * C * 2.0 * (2 + (g2 != nullptr) + (g_res != nullptr) + 1 + (dy != nullptr && dy != dr)), st);
+  const bool drop = (p.pre_thresh | p.post_thresh | p.mid_thresh) != 0;
+#define LN_BWD_LAUNCH(N_, V_)                                                                              \
+  do {                                                                                                     \
+    if (post_gelu_beta) ln_bwd_kernel<T, N_, V_, true, true><<<grid, ROW_THREADS, 0, st>>>(p);             \
+    else if (drop) ln_bwd_kernel<T, N_, V_, false, true><<<grid, ROW_THREADS, 0, st>>>(p);                 \
+    else ln_bwd_kernel<T, N_, V_, false, false><<<grid, ROW_THREADS, 0, st>>>(p);                          \
+  } while (0)
   if (C % 256 == 0 && C / 256 == 3 && (C / 8) % 64 != 0)  // (768: three chunks of 4 per lane, every lane busy)
-    ln_bwd_kernel<T, 3, 4><<<grid, ROW_THREADS, 0, st>>>(p);
+    LN_BWD_LAUNCH(3, 4);
   else if (nch == 1)
-    ln_bwd_kernel<T, 1, 8><<<grid, ROW_THREADS, 0, st>>>(p);
+    LN_BWD_LAUNCH(1, 8);
   else if (nch == 2)
-    ln_bwd_kernel<T, 2, 8><<<grid, ROW_THREADS, 0, st>>>(p);
+    LN_BWD_LAUNCH(2, 8);
   else
-    ln_bwd_kernel<T, 3, 8><<<grid, ROW_THREADS, 0, st>>>(p);
+    LN_BWD_LAUNCH(3, 8);
+#undef LN_BWD_LAUNCH
   SSAK_LAUNCH_CHECK();
   if (g_reduce_sink && g_reduce_sink->n + 3 <= ReduceSink::CAP) {  // second stage queued: one launch for many (kernels.h)
     g_reduce_sink->push(partial, 3L * C, grid, C, dgamma);
@@ -846,21 +877,19 @@ int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, f
 }
 
 // ---- debug: the dropout bits of one site, written out (tests/test_gpu_dropout.py pins oracle/dropout_hash.py against them).
-// The product kernels inline the same device functions (common.h keep_bit / attn_keep_bit); nothing on the hot path calls these.
-__global__ void debug_dropout_mask_kernel(uint64_t seed, uint32_t stream, uint32_t thresh, long n, uint8_t* keep) {
+// The product kernels inline the same device functions (common.h drop_rowkey / drop_colmul / drop_keep); nothing on the hot path
+// calls these.  Element-wise sites: (row, col) of their [rows, cols] tensor; attention: row = (b * nh + h) * F + q, col = key --
+// one definition since round 5, so the attention entry is the element-wise one on [B * nh * F, F].
+__global__ void debug_dropout_mask_kernel(uint64_t seed, uint32_t stream, uint32_t thresh, long rows, int cols, uint8_t* keep) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keep[i] = (!thresh || keep_bit(seed, stream, (uint64_t)i, thresh)) ? 1 : 0;
+  if (i >= rows * cols) return;
+  keep[i] = (!thresh || keep_bit(seed, stream, (uint64_t)(i / cols), (uint32_t)(i % cols), thresh)) ? 1 : 0;
 }
-__global__ void debug_attention_dropout_mask_kernel(uint64_t seed, uint32_t stream, uint32_t thresh, long rows, int Fk, uint8_t* keep) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * Fk) return;
-  const uint32_t row = (uint32_t)(i / Fk), key = (uint32_t)(i % Fk);
-  keep[i] = (!thresh || attn_keep_bit(attn_drop_rowseed(seed, stream, row), key, thresh)) ? 1 : 0;
-}
-extern "C" int ssak_debug_dropout_mask(uint64_t seed, uint32_t site, float p, long n, uint8_t* keep, float* scale_out /*host*/,
+extern "C" int ssak_debug_dropout_mask(uint64_t seed, uint32_t site, float p, long rows, int cols, uint8_t* keep, float* scale_out /*host*/,
                                        void* stream) {
-  SSAK_REQUIRE(keep && n > 0, "debug_dropout_mask: bad arguments");
-  debug_dropout_mask_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(seed, site, thresh_of(p), n, keep);
+  SSAK_REQUIRE(keep && rows > 0 && cols > 0, "debug_dropout_mask: bad arguments");
+  const long n = rows * cols;
+  debug_dropout_mask_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(seed, site, thresh_of(p), rows, cols, keep);
   SSAK_LAUNCH_CHECK();
   if (scale_out) *scale_out = scale_of(p);
   return SSAK_OK;
@@ -868,8 +897,5 @@ extern "C" int ssak_debug_dropout_mask(uint64_t seed, uint32_t site, float p, lo
 extern "C" int ssak_debug_attention_dropout_mask(uint64_t seed, uint32_t site, float p, int B, int nh, int F, uint8_t* keep,
                                                  void* stream) {
   SSAK_REQUIRE(keep && B > 0 && nh > 0 && F > 0, "debug_attention_dropout_mask: bad arguments");
-  const long rows = (long)B * nh * F, n = rows * F;
-  debug_attention_dropout_mask_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(seed, site, thresh_of(p), rows, F, keep);
-  SSAK_LAUNCH_CHECK();
-  return SSAK_OK;
+  return ssak_debug_dropout_mask(seed, site, p, (long)B * nh * F, F, keep, nullptr, stream);
 }

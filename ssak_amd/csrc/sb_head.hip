@@ -13,6 +13,7 @@
 #include "kernels.h"
 
 namespace {
+SSAK_DEFINE_DROP_TABLE
 
 uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)fminf(65535.f, roundf(p * 65536.f)); }
 float drop_scale(float p) { return p <= 0.f ? 1.f : 1.f / (1.f - (float)drop_thresh(p) / 65536.f); }
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_coef_from_sums_kernel(const double* __
   coef[c] = (float)(sums[c] / M);
   coef[C + c] = (float)(sums[C + c] / M);
 }
-// y = dropout(leaky_relu(gamma * (x - mean) * rstd + beta)); mask bit = keep_bit(seed, stream, r * C + c)
+// y = dropout(leaky_relu(gamma * (x - mean) * rstd + beta)); mask bit = common.h drop_keep(rowkey(seed, stream, r), colmul(c))
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ x, long ldx, bf16* __restrict__ y, long ldy, int M,
                                                        int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
@@ -197,6 +198,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
   const RowMap m(C, 256);
   if (!m.active) return;
   const int c0 = m.cc * 8;
+  uint32_t cm[8];  // dropout column multipliers of this thread's 8 columns (common.h)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cm[k] = thresh ? g_drop_colmul.v[c0 + k] : 1u;
   float mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -217,13 +221,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
     for (int u = 0; u < 4; ++u) {
       const int ru = r + u * stride;
       if (ru >= M) break;
-      const uint64_t o = (uint64_t)ru * C + c0;
+      const uint32_t rk = thresh ? drop_rowkey(seed, stream, (uint64_t)ru) : 1u;
       float v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float z = fmaf(((float)in[u][k] - mu[k]) * rs[k], gm[k], bt[k]);  // the expression the backward re-evaluates (same sign of z)
         z = z > 0.f ? z : z * slope;
-        if (thresh) z = keep_bit(seed, stream, o + k, thresh) ? z * dscale : 0.f;
+        if (thresh) z = drop_keep(rk, cm[k], thresh << 16) ? z * dscale : 0.f;
         v[k] = z;
       }
       store8(y + (long)ru * ldy + c0, v);
@@ -242,6 +246,9 @@ __global__ __launch_bounds__(BN_STAT_THREADS) void bn_bwd_partial_kernel(const b
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (m.active) {
     const int c0 = m.cc * 8;
+    uint32_t cm[8];  // dropout column multipliers of this thread's 8 columns (common.h)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cm[k] = thresh ? g_drop_colmul.v[c0 + k] : 1u;
     float mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -265,13 +272,13 @@ __global__ __launch_bounds__(BN_STAT_THREADS) void bn_bwd_partial_kernel(const b
       for (int u = 0; u < 2; ++u) {
         const int ru = r + u * stride;
         if (ru >= M) break;
-        const uint64_t o = (uint64_t)ru * C + c0;
+        const uint32_t rk = thresh ? drop_rowkey(seed, stream, (uint64_t)ru) : 1u;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float xh = ((float)xv[u][k] - mu[k]) * rs[k];
           const float z = fmaf(xh, gm[k], bt[k]);
           float g = z > 0.f ? (float)dv[u][k] : (float)dv[u][k] * slope;
-          if (thresh) g = keep_bit(seed, stream, o + k, thresh) ? g * dscale : 0.f;
+          if (thresh) g = drop_keep(rk, cm[k], thresh << 16) ? g * dscale : 0.f;
           s[k] += g;
           q[k] = fmaf(g, xh, q[k]);
         }
@@ -311,6 +318,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
   const RowMap m(C, 256);
   if (!m.active) return;
   const int c0 = m.cc * 8;
+  uint32_t cm[8];  // dropout column multipliers of this thread's 8 columns (common.h)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cm[k] = thresh ? g_drop_colmul.v[c0 + k] : 1u;
   float mu[8], rs[8], gm[8], bt[8], c1[8], c2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -336,14 +346,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
     for (int u = 0; u < 2; ++u) {
       const int ru = r + u * stride;
       if (ru >= M) break;
-      const uint64_t o = (uint64_t)ru * C + c0;
+      const uint32_t rk = thresh ? drop_rowkey(seed, stream, (uint64_t)ru) : 1u;
       float v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = ((float)xv[u][k] - mu[k]) * rs[k];
         const float z = fmaf(xh, gm[k], bt[k]);
         float g = z > 0.f ? (float)dv[u][k] : (float)dv[u][k] * slope;
-        if (thresh) g = keep_bit(seed, stream, o + k, thresh) ? g * dscale : 0.f;
+        if (thresh) g = drop_keep(rk, cm[k], thresh << 16) ? g * dscale : 0.f;
         v[k] = gm[k] * rs[k] * (g - c1[k] - xh * c2[k]);
       }
       store8(dx + (long)ru * lddx + c0, v);
@@ -579,6 +589,7 @@ extern "C" int ssak_batchnorm_act_fwd(const void* x, void* y, int M, int C, cons
                                       void* stream) {
   SSAK_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && M > 0 && C > 0, "batchnorm_act_fwd: bad arguments");
   SSAK_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "batchnorm_act_fwd: C must be a multiple of 8, rows 16-byte aligned");
+  SSAK_REQUIRE(!(drop_p > 0.f) || C <= DROP_TABLE_N, "batchnorm_act_fwd: dropout sites are built for at most %d columns", DROP_TABLE_N);
   SSAK_REQUIRE(training || (running_mean && running_var), "batchnorm_act_fwd: evaluation needs the running statistics");
   SSAK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_act_fwd: running_mean and running_var go together");
   SSAK_REQUIRE(!global_sums || training, "batchnorm_act_fwd: global sums are a training-mode input");
@@ -620,6 +631,7 @@ extern "C" int ssak_batchnorm_act_bwd(const void* dy, const void* x, void* dx, i
   SSAK_REQUIRE(!global_sums || dx, "batchnorm_act_bwd: global sums come with dx");
   SSAK_REQUIRE(C % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0,
                "batchnorm_act_bwd: C must be a multiple of 8, rows 16-byte aligned");
+  SSAK_REQUIRE(!(drop_p > 0.f) || C <= DROP_TABLE_N, "batchnorm_act_bwd: dropout sites are built for at most %d columns", DROP_TABLE_N);
   SSAK_REQUIRE(workspace && workspace_bytes >= ssak_batchnorm_workspace_bytes(C), "batchnorm_act_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const BnGrid gd(M, C);

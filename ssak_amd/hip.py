@@ -13,7 +13,7 @@ import torch
 
 _DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")
 _LIB_PATH = os.environ.get("SSAK_HIP_LIB") or _DEFAULT_LIB  # (the override names another build OF THE SAME ABI: A/B runs, instrumented builds)
-ABI_VERSION = 400  # ssak_version() of the library this binding's struct layouts and signatures were written for
+ABI_VERSION = 500  # ssak_version() of the library this binding's struct layouts and signatures were written for
 
 
 class GemmDesc(C.Structure):
@@ -130,7 +130,7 @@ def _load():
         "ssak_comm_create": (i32, [C.POINTER(vp), i32, i32, vp]),
         "ssak_allreduce": (i32, [vp, vp, C.c_long, C.c_long, i32, vp]),
         "ssak_comm_destroy": (i32, [vp]),
-        "ssak_debug_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, C.c_long, vp, C.POINTER(f32), vp]),
+        "ssak_debug_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, C.c_long, i32, vp, C.POINTER(f32), vp]),
         "ssak_debug_attention_dropout_mask": (i32, [C.c_uint64, C.c_uint32, f32, i32, i32, i32, vp, vp]),
     }
     lib.ssak_version.restype = i32

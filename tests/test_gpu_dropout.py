@@ -37,20 +37,20 @@ def _cfg(Wav2Vec2Config, oc):
 # ------------------------------------------------------------------------------------------------ the hash itself
 @pytest.mark.parametrize("p", [0.05, 0.1, 0.25, 0.5])
 def test_dropout_hash_matches_device(p):
-    """oracle/dropout_hash.py == the device functions every kernel inlines (common.h keep_bit / attn_keep_bit), bit for bit:
-    element-wise sites over 1M + 3 offsets (odd count: the pair hash's tail), offsets beyond 2^32 are not reachable at these
-    sizes; attention over [2, 3, 77, 77] (odd key count); several seeds with high words set, several sites."""
+    """oracle/dropout_hash.py == the device functions every kernel inlines (common.h drop_rowkey / drop_colmul / drop_keep), bit for
+    bit: element-wise sites over [1 367, 771] (odd sizes); attention over [2, 3, 77, 77] (odd key count); several seeds with high
+    words set, several sites."""
     import ctypes as C
 
     import ssak_amd.hip as hip
     from oracle import dropout_hash as DH
     dev = "cuda:0"
     for seed, site in ((1, 1), (0xDEADBEEFCAFEF00D, 2), (0x5EED0BA5E, DH.ds_act(11)), ((1 << 64) - 1, DH.ds_attn(23))):
-        n = (1 << 20) + 3
-        keep = torch.empty(n, dtype=torch.uint8, device=dev)
+        rows, cols = 1367, 771
+        keep = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
         sc = C.c_float()
-        hip.check(hip.lib.ssak_debug_dropout_mask(C.c_uint64(seed), site, p, n, hip.ptr(keep), C.byref(sc), hip.stream()))
-        ref = DH.keep_mask(seed, site, (n,), p)
+        hip.check(hip.lib.ssak_debug_dropout_mask(C.c_uint64(seed), site, p, rows, cols, hip.ptr(keep), C.byref(sc), hip.stream()))
+        ref = DH.keep_mask(seed, site, (rows, cols), p)
         assert np.array_equal(keep.cpu().numpy().astype(bool), ref), (seed, site)
         assert abs(1.0 - ref.mean() - p) < 3e-3
         assert abs(sc.value - DH.engine_scale(p)) < 1e-7 and abs(sc.value - 1.0 / (1.0 - p)) < 2e-5 / (1.0 - p)
@@ -88,6 +88,35 @@ def test_fused_attention_kernel_draws_the_oracle_mask():
     got = ctx.float().reshape(B, F, nh, hd).permute(0, 2, 1, 3).cpu()  # [B, nh, q, d == k]
     assert torch.equal(got == 0, ~keep), "the kernel's zeros are not the oracle's mask"
     assert float((got - want).abs().max()) < 2e-2 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1000, 3072, 768, "gelu_save"), (15968, 3072, 768, "gelu_save"), (777, 776, 256, "gelu"),
+                                       (300, 72, 64, "none"), (2049, 1024, 128, "gelu")])
+def test_gemm_epilogue_draws_the_oracle_mask(M, N, K, epi):
+    """Every GEMM epilogue form (the persistent kernels' register epilogue with the table read per row group, the LDS round
+    trip of the older kernels, edge tiles, the fp32 GEMM of the exact mode) zeroes exactly the elements
+    oracle.dropout_hash.keep_mask(seed, site, (M, N)) drops: A = ones, B = ones, bias 1 -> every output is far from zero."""
+    import ssak_amd.hip as hip
+    from oracle import dropout_hash as DH
+    dev = "cuda:0"
+    A = torch.ones(M, K, dtype=torch.bfloat16, device=dev)
+    B = torch.ones(N, K, dtype=torch.bfloat16, device=dev) / K
+    bias = torch.ones(N, dtype=torch.float32, device=dev)
+    p, seed, site = 0.1, 0x1234567887654321, DH.ds_act(3)
+    keep = DH.keep_mask(seed, site, (M, N), p)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    kw = dict(lda=K, ldb=K, ldc=N, bias=bias, drop_p=p, drop_stream=site, drop_seed=seed)
+    if epi == "gelu_save":
+        f8 = torch.empty(M, N, dtype=torch.uint8, device=dev)
+        hip.gemm(A, B, out, M, N, K, epilogue=hip.EPI_GELU_SAVE_GRAD, aux_out=f8, **kw)
+        assert np.array_equal((f8.cpu().numpy() != 26), keep), "the saved factor's zero code is not the oracle's mask"
+    else:
+        hip.gemm(A, B, out, M, N, K, epilogue=hip.EPI_GELU if epi == "gelu" else hip.EPI_NONE, **kw)
+    assert np.array_equal((out.float().cpu().numpy() != 0), keep), "the epilogue's zeros are not the oracle's mask"
+    if M <= 2049:  # the exact mode's fp32 GEMM
+        o32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        hip.gemm_f32(A.float(), B.float(), o32, M, N, K, lda=K, ldb=K, ldc=N, bias=bias, drop_p=p, drop_stream=site, drop_seed=seed)
+        assert np.array_equal((o32.cpu().numpy() != 0), keep)
 
 
 # ------------------------------------------------------------------------------------------------ engine vs patched HF, tiny

@@ -290,3 +290,32 @@ def test_sb_head_oracle_vs_torch_modules():
     # NewBob: 10 -> 9 improves 10 %; 9 -> 8.99 improves 0.11 % < 0.25 %: anneal; 8.0 -> 8.0: anneal again
     assert S.new_bob([10, 9, 8.99, 8.0, 8.0], 1.0, 0.8) == pytest.approx([1.0, 1.0, 0.8, 0.8, 0.64])
     assert S.new_bob([5.0, 5.0, 5.0], 1e-4, 0.9, patient=1) == pytest.approx([1e-4, 1e-4, 0.9e-4])
+
+
+@pytest.mark.parametrize("p", [0.05, 0.1, 0.25, 0.5])
+def test_dropout_mask_generator_quality(p):
+    """The statistics the round-5 mask generator (one integer multiply per element: oracle/dropout_hash.py, common.h) is held to on a
+    4 096 x 3 072 site: drop rate within 3 sigma; drop indicators uncorrelated between neighbouring columns / rows / diagonal
+    neighbours / sites / seeds (|rho| < 2e-3: the iid standard error is 2.8e-4, the rank-one structure of the words widens it);
+    per-row and per-column drop counts binomial (variance ratio within 6 %)."""
+    from oracle import dropout_hash as DH
+    q = DH.quality_report(p)
+    assert abs(q["rate"] - DH.thresh16(p) / 65536.0) < 3 * q["rate_sigma"], q
+    for k in ("col1", "col2", "col64", "row1", "diag", "site", "seed"):
+        assert abs(q[k]) < 2e-3, (k, q)
+    assert abs(q["row_count_var"] - 1) < 0.06 and abs(q["col_count_var"] - 1) < 0.06, q
+
+
+KNOWN_COLMUL = [4102127511, 2960243731, 3929676619, 1507823451]
+KNOWN_ROWKEY = [2898601965, 3335941947, 1865774827]
+KNOWN_MASK = [[1, 1, 1, 1, 0, 1, 1, 0], [1, 0, 0, 1, 0, 1, 1, 1], [1, 1, 1, 1, 0, 1, 0, 1], [1, 1, 1, 1, 1, 1, 0, 0], [1, 1, 0, 0, 1, 1, 0, 1]]
+
+
+def test_dropout_mask_known_answers():
+    """Known answers of the integer functions (guards the numpy restatement itself against an accidental edit; the device pin is
+    tests/test_gpu_dropout.py::test_dropout_hash_matches_device)."""
+    from oracle import dropout_hash as DH
+    assert [int(v) for v in DH.colmul(np.arange(4, dtype=np.uint64))] == KNOWN_COLMUL
+    assert [int(v) for v in DH.rowkey(0xDEADBEEFCAFEF00D, 18, np.arange(3, dtype=np.uint64))] == KNOWN_ROWKEY
+    m = DH.keep_mask(7, 3, (5, 8), 0.25)
+    assert m.astype(int).tolist() == KNOWN_MASK
