@@ -186,8 +186,11 @@ typedef struct {
                  read.  Both must describe the same matrix: results are bit-identical either way.  Not with B batch strides. */
   int plan_tile; /* 0 (default): the library's cost model picks kernel, tile height and split.  256 / 192 / 128: run the product
                  on the persistent 256-column-tile kernels with this tile height whenever it qualifies for them (M, N >= 256,
-                 whole 16-byte chunks) -- for tests and tuning; results do not depend on it beyond the summation order. */
+                 whole 16-byte chunks) -- for tests and tuning; results do not depend on it beyond the summation order.
+                 SSAK_PLAN_TILE_CORESIDENT: the 128-row-tile kernel that runs two workgroups per CU (K-contiguous operands,
+                 K % 64 == 0, N % 256 == 0, bf16 out; otherwise the 256-row persistent kernels). */
 } ssak_gemm_desc;
+#define SSAK_PLAN_TILE_CORESIDENT 129
 /* Fragment-ordered copy of a B operand ([N, K] K-contiguous, or [K, N] with b_kmajor; ldb as in the descriptor):
  * out[(cb * nkt + kt)][j][kk][lane][8] = B(n = 64 cb + 16 j + (lane & 15), k = 64 kt + 32 kk + 8 (lane >> 4) + e), zeros
  * beyond N / K, cb < 4 * ceil(N / 256), nkt = ceil(K / 64): the 8 KB one wave column needs for one 64-deep K tile are
