@@ -242,6 +242,9 @@ typedef struct {
   int bound;
 } ssak_prof_entry;
 int ssak_prof_enable(void* stream, int on);
+/* as ssak_prof_enable(stream, 2 + i) for a LIST of slots (indices into ssak_prof_collect's list): a kernel that serves several
+ * products has one slot per (N, K); a benchmark that reports on the kernel times all of them. */
+int ssak_prof_enable_slots(void* stream, const int32_t* slots, int n);
 int ssak_prof_collect(void* stream, ssak_prof_entry* out /*host*/, int cap); /* cap >= 128; returns the number of entries */
 
 /* ---- a3 (part): first layer of the feature encoder -------------------------------------------

@@ -37,7 +37,8 @@ struct ProfRec {
   double work;
 };
 struct ProfStream {
-  int mode = 0;
+  int mode = 0;  // 0 off, 1 every launch, 2 + i only slot i, -1 the slots of `want`
+  std::vector<char> want;
   std::vector<ProfRec> recs;
 };
 struct ProfKey {
@@ -115,7 +116,9 @@ bool ssak_prof_wanted(int slot, hipStream_t st) {
   if (g_prof_active.load(std::memory_order_relaxed) == 0) return false;
   std::lock_guard<std::mutex> lock(g_prof_mu);
   auto it = g_prof_streams.find(prof_key(st));
-  return it != g_prof_streams.end() && (it->second.mode == 1 || it->second.mode == slot + 2);
+  if (it == g_prof_streams.end()) return false;
+  const ProfStream& ps = it->second;
+  return ps.mode == 1 || ps.mode == slot + 2 || (ps.mode == -1 && slot >= 0 && slot < (int)ps.want.size() && ps.want[slot]);
 }
 
 ProfScope::ProfScope(int slot, double work, hipStream_t st) : st_(st), slot_(slot), work_(work), on_(ssak_prof_wanted(slot, st)) {
@@ -142,6 +145,19 @@ extern "C" int ssak_prof_enable(void* stream, int on) {
   const int mode = on < 0 ? 0 : on;
   if ((ps.mode != 0) != (mode != 0)) g_prof_active.fetch_add(mode != 0 ? 1 : -1, std::memory_order_relaxed);
   ps.mode = mode;
+  return SSAK_OK;
+}
+
+// time only the launches of the listed slots (a kernel that serves several products has one slot per product)
+extern "C" int ssak_prof_enable_slots(void* stream, const int32_t* slots, int n) {
+  SSAK_REQUIRE(slots && n > 0, "prof_enable_slots: empty list");
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  ProfStream& ps = g_prof_streams[prof_key((hipStream_t)stream)];
+  if (ps.mode == 0) g_prof_active.fetch_add(1, std::memory_order_relaxed);
+  ps.mode = -1;
+  ps.want.assign(PROF_MAX_SLOTS, 0);
+  for (int i = 0; i < n; ++i)
+    if (slots[i] >= 0 && slots[i] < PROF_MAX_SLOTS) ps.want[slots[i]] = 1;
   return SSAK_OK;
 }
 

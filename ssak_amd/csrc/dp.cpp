@@ -34,11 +34,18 @@ std::mutex g_rccl_mu;
 int load_rccl() {
   std::lock_guard<std::mutex> lock(g_rccl_mu);
   if (g_rccl.so) return SSAK_OK;
+  // An RCCL that the process has already mapped comes first (RTLD_NOLOAD): a torch process carries its own copy, and a second,
+  // different librccl next to it would run two RCCL instances on one device.  Only then a fresh load.
   void* so = nullptr;
-  for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-    so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+  for (const char* name : {"librccl.so.1", "librccl.so"}) {
+    so = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     if (so) break;
   }
+  if (!so)
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (so) break;
+    }
   if (!so) {
     ssak_set_error("ssak_comm: librccl.so not found (%s)", dlerror());
     return SSAK_ERR_STATE;

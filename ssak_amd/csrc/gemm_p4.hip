@@ -77,11 +77,7 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
   // epilogues that store at least a fixed number of 16-byte rows per 16-row group may leave their stores in flight: the counted
   // waits of the next tile use that LOWER bound of what is younger than the primed K tiles (MUL_AUX: its column-sum stores are not
   // counted, its factor-code loads are consumed -- waited for, with everything older -- inside the epilogue)
-#ifdef SSAK_AB_NO_MULAUX_EARLY
-  constexpr bool EPI_EARLY = EPI == P8_EPI_PLAIN_BF16 || EPI == P8_EPI_GELU_ONLY || EPI == SSAK_EPI_GELU_SAVE_GRAD;
-#else
   constexpr bool EPI_EARLY = EPI == P8_EPI_PLAIN_BF16 || EPI == P8_EPI_GELU_ONLY || EPI == SSAK_EPI_GELU_SAVE_GRAD || EPI == SSAK_EPI_MUL_AUX;
-#endif
   constexpr int EPI_STORES = (EPI == SSAK_EPI_GELU_SAVE_GRAD ? 6 : 4) * NI;
   constexpr int MID_KEEP = SA == 3 ? NA : 0;  // LDS-DMA younger than what a K tile's barrier needs: the A tile staged last
   const int lane = threadIdx.x & 63;

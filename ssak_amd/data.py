@@ -273,10 +273,12 @@ class CharTokenizer:
 
 
 # ----------------------------------------------------------------------------- batching / collation
-def pad_waves(waves: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
-    """Right zero padding to the longest (processor.pad, wav2vec_train.py:79-85) -> ([B,T] float32, lengths)."""
+def pad_waves(waves: Sequence[np.ndarray], target_len: int | None = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Right zero padding to the longest (processor.pad, wav2vec_train.py:79-85) -> ([B,T] float32, lengths).  ``target_len``:
+    pad to this length instead (a rank's shard of a global batch is padded like the WHOLE batch: the reference's collator pads the
+    global batch before DataParallel scatters it, and an unmasked group-norm model's logits depend on the padding)."""
     lens = np.array([len(w) for w in waves], dtype=np.int32)
-    out = np.zeros((len(waves), int(lens.max())), dtype=np.float32)
+    out = np.zeros((len(waves), max(int(lens.max()), int(target_len or 0))), dtype=np.float32)
     for i, w in enumerate(waves):
         out[i, :len(w)] = w
     return out, lens

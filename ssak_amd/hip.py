@@ -85,6 +85,7 @@ def _load():
         "ssak_conv0_workspace_bytes": (sz, [i32, i32, i32]),
         "ssak_conv0_gn_gelu": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
         "ssak_prof_enable": (i32, [vp, i32]),
+        "ssak_prof_enable_slots": (i32, [vp, C.POINTER(C.c_int32), i32]),
         "ssak_prof_collect": (i32, [vp, C.POINTER(ProfEntry), i32]),
         "ssak_attention_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, vp]),
         "ssak_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint32, i32, vp]),
@@ -360,6 +361,12 @@ def prof_enable(mode: int):
     """Launch timing on the CURRENT stream: 0 = off, 1 = every launch, 2 + i = only the slot at index i of
     :func:`prof_collect`'s list.  Per stream: other streams / handles are neither slowed nor recorded."""
     check(lib.ssak_prof_enable(stream(), int(mode)))
+
+
+def prof_enable_slots(slots):
+    """Launch timing on the CURRENT stream for the slots at these indices of :func:`prof_collect`'s list only."""
+    arr = (C.c_int32 * len(slots))(*[int(v) for v in slots])
+    check(lib.ssak_prof_enable_slots(stream(), arr, len(slots)))
 
 
 BOUNDS = {0: "mfma", 1: "hbm", 2: "latency"}

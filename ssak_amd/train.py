@@ -132,7 +132,10 @@ def evaluate(model, tok, waves, labels, batch_size, rank: int = 0, world: int = 
     With a process group every rank evaluates ITS contiguous shard of each validation batch -- the reference's
     per_device_eval_batch_size = batch_size // num_devices (wav2vec_train.py:357) -- and ONE all-reduce of four sums
     (word edits, reference words, summed per-utterance loss, utterances) gives every rank the same metrics: no rank idles
-    at a barrier while rank 0 walks the whole set."""
+    at a barrier while rank 0 walks the whole set.  A shard is padded to the longest utterance of the GLOBAL batch, as the
+    reference's collator pads before DataParallel scatters (wav2vec_train.py:79-100): the group-norm base model runs without an
+    attention mask, so its logits depend on the padding, and eval_loss / eval_wer (hence best-checkpoint selection and early
+    stopping) must not depend on the world size."""
     from .metrics import WerAccumulator
     model.eval()
     acc = WerAccumulator(tok.vocab, tok.pad_token_id, model.device, tok.delim)
@@ -140,11 +143,12 @@ def evaluate(model, tok, waves, labels, batch_size, rank: int = 0, world: int = 
     n = 0
     for i in range(0, len(waves), batch_size):
         mine = list(range(i, min(i + batch_size, len(waves))))
+        global_len = max(len(waves[k]) for k in mine)
         if world > 1:
             mine = shard_batch(mine, rank, world)
             if not mine:
                 continue
-        x, lens = pad_waves([waves[k] for k in mine])
+        x, lens = pad_waves([waves[k] for k in mine], target_len=global_len)
         lab = torch.from_numpy(pad_labels([labels[k] for k in mine])).to(model.device)
         xd, ld = torch.from_numpy(x).to(model.device), torch.from_numpy(lens).to(model.device)
         use_mask = model.config.feat_extract_norm == "layer"
@@ -269,9 +273,19 @@ def main(argv=None):
         else:
             with open(rng_file) as f:  # plain JSON, no pickle
                 extra = json.load(f)
-            model._step_seed = int(extra["step_seed"])
-            kind, keys, pos, has_gauss, cached_g = extra["host_rng"]
-            model._host_rng.set_state((kind, np.asarray(keys, dtype=np.uint32), int(pos), int(has_gauss), float(cached_g)))
+            if rank > 0 and not rng_file.endswith(f"rng-rank{rank}.json"):
+                # the checkpoint was written by fewer ranks: ANOTHER rank's streams would make this rank draw the same dropout /
+                # LayerDrop / SpecAugment decisions as that rank for the rest of the run.  Keep the per-rank independence the
+                # trainer set up (seed + rank): the step-seed stream is offset by the rank, the host stream reseeded from
+                # (seed, rank, step).
+                print(f"warning: {last} holds no regulariser stream state for rank {rank} (written by fewer ranks): reseeding this rank's "
+                      f"streams from (seed {args.seed}, rank {rank}, step {int(state['global_step'])})")
+                model._step_seed = (int(extra["step_seed"]) + 0x9E3779B97F4A7C15 * rank) % (1 << 64)
+                model._host_rng = np.random.RandomState([args.seed % (1 << 32), rank, int(state["global_step"])])
+            else:
+                model._step_seed = int(extra["step_seed"])
+                kind, keys, pos, has_gauss, cached_g = extra["host_rng"]
+                model._host_rng.set_state((kind, np.asarray(keys, dtype=np.uint32), int(pos), int(has_gauss), float(cached_g)))
         best = state.get("best_model_checkpoint")
         if best is not None and not os.path.isdir(best):  # the output folder was moved: checkpoints are found by name
             state["best_model_checkpoint"] = os.path.join(out_dir, os.path.basename(best))
@@ -315,6 +329,7 @@ def main(argv=None):
                          "loss": float(torch.stack(run_loss).mean().item())}
                 run_loss = []
                 ck = os.path.join(out_dir, f"checkpoint-{step}")
+                trainer.drain_exchange()  # (exchange "c": its private communicator is idle before torch.distributed's is used)
                 metrics = evaluate(model, tok, vw, vl, args.batch_size, rank, world)  # every rank: its shard of each batch
                 if rank == 0:
                     state["log_history"].append(entry)
@@ -356,6 +371,7 @@ def main(argv=None):
             print(f"loading best model from {best} (wer {state['best_metric']:.4f})")
         save_pretrained(model, tok, os.path.join(out_dir, "final"))
         print(f"trained {step} steps in {time.time() - t0:.1f} s -> {out_dir}")
+    trainer.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -148,13 +148,15 @@ class Trainer:
 
     def __init__(self, model: Wav2Vec2ForCTC, optimizer: AdamW, normalize_on_device: bool = True,
                  grad_exchange_dtype: str | None = None, optimizer_stream: bool | None = None, measure_stall: bool = False,
-                 per_rank_seed: bool = True, exchange: str | None = None):
+                 per_rank_seed: bool = True, exchange: str | None = None, comm=None):
         """``grad_exchange_dtype``: "fp32" (default; or environment SSAK_DP_GRAD_DTYPE) or "bf16" -- the gradient buckets are
         rounded to bf16 for the all-reduce and widened again before the clip + update: half the bytes over xGMI (180 MB
         instead of 361 MB per step for the base model) at bf16 rounding of the exchanged sums.
         ``exchange``: "torch" (default; or environment SSAK_DP_EXCHANGE) = torch.distributed.all_reduce (backend nccl = RCCL), or
         "c" = the library's own ``ssak_allreduce`` (include/ssak_hip.h: RCCL through the C ABI, the path a host without
-        torch.distributed takes; torch.distributed then only carries the 128-byte communicator id)."""
+        torch.distributed takes; torch.distributed then only carries the 128-byte communicator id).  ``comm``: a communicator object
+        to use for exchange "c" instead of creating ``hip.Comm`` (``all_reduce(tensor, offset, count, stream_)`` asynchronous on the
+        given stream, ``close()``): tests drive the event ordering of this path with a stand-in for RCCL."""
         self.model, self.opt = model, optimizer
         self.exchange = exchange or os.environ.get("SSAK_DP_EXCHANGE", "torch")
         if self.exchange not in ("torch", "c"):
@@ -204,11 +206,38 @@ class Trainer:
             # for base), issued while the rest of the backward is still running; RCCL runs them on its own stream
             model.set_grad_ready_callback(self._on_grads_ready)
             if self.exchange == "c":
-                uid = [hip.Comm.unique_id() if torch.distributed.get_rank() == 0 else None]
-                torch.distributed.broadcast_object_list(uid, src=0)
                 with torch.cuda.device(model.device):
-                    self._comm = hip.Comm(self.world, torch.distributed.get_rank(), uid[0])
+                    if comm is not None:
+                        self._comm = comm
+                    else:
+                        uid = [hip.Comm.unique_id() if torch.distributed.get_rank() == 0 else None]
+                        torch.distributed.broadcast_object_list(uid, src=0)
+                        self._comm = hip.Comm(self.world, torch.distributed.get_rank(), uid[0])
                     self._xstream = torch.cuda.Stream()  # the collectives' own stream: they overlap the rest of the backward
+
+    def drain_exchange(self):
+        """Exchange "c" keeps a PRIVATE communicator whose collectives run on the trainer's own stream.  Two communicators with
+        collectives in flight at once deadlock unless every rank launches them in the same order, so before anything goes
+        through torch.distributed's communicator on this device (evaluation sums, broadcasts, barriers) the current stream --
+        the one torch's collective is ordered behind -- waits for the exchange stream and for the optimizer tail that consumes
+        it.  A no-op for exchange "torch"."""
+        if self._comm is None:
+            return
+        with torch.cuda.device(self.model.device):
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._xstream)
+            if self.opt_stream is not None:
+                cur.wait_stream(self.opt_stream)
+
+    def close(self):
+        """Destroys the private communicator of exchange "c" (ncclCommDestroy) after its stream has drained; idempotent."""
+        if self._comm is not None:
+            with torch.cuda.device(self.model.device):
+                self._xstream.synchronize()
+                if self.opt_stream is not None:
+                    self.opt_stream.synchronize()
+            self._comm.close()
+            self._comm = None
 
     def _on_grads_ready(self, offset: int, count: int):
         m = self.model
@@ -238,6 +267,7 @@ class Trainer:
 
     def broadcast_parameters(self):
         if self.dist:
+            self.drain_exchange()
             self.model.wait_params()
             torch.distributed.broadcast(self.model.params, src=0)
             self.model.sync_weights(full=True)

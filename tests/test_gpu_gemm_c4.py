@@ -94,7 +94,9 @@ def test_c4_feed_forward_pair(hip):
     # (the K rotation differs between the kernels: fp32 summation order, i.e. the last bf16 bit of a few outputs)
     assert float((y1.float() - y0.float()).abs().max()) <= 2.0 ** -7 * float(y0.float().abs().max())
     keep = torch.from_numpy(DH.keep_mask(kw["drop_seed"], kw["drop_stream"], (M, N), 0.1)).cuda()
-    assert torch.equal(f1 != 26, keep) and torch.equal(y1 != 0, keep & (y1 != 0))
+    # dropped elements: code 26 (= exactly 0) and a zero output; kept ones: the code of gelu'(x) (26 only where gelu' rounds to 0)
+    assert bool((f1[~keep] == 26).all()) and bool((y1[~keep] == 0).all())
+    assert float((f1[keep] != 26).float().mean()) > 0.98 and float((y1[keep] != 0).float().mean()) > 0.98
     assert int((f1.int() - f0.int()).abs().max()) <= 1
     # backward
     dY = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()

@@ -38,7 +38,11 @@ def _operands(M, N, K, seed, lo=-2, hi=3, nb=1):
 # tile row of 96 valid rows --; deep K; K = 256 (the shortest pipeline: no steady-state K tile at all); every tile height with
 # row tails that leave whole waves without rows
 SHAPES = [(300, 256, 256, 256), (15968, 768, 768, 0), (15968, 3072, 768, 0), (4000, 768, 3072, 192), (8193, 512, 256, 128),
-          (3077, 1024, 1024, 256), (15968, 2304, 768, 0), (70000, 256, 256, 128), (33000, 512, 384, 192), (257, 256, 512, 128)]
+          (3077, 1024, 1024, 256), (15968, 2304, 768, 0), (70000, 256, 256, 128), (33000, 512, 384, 192), (257, 256, 512, 128),
+          # odd K-tile counts (3, 5, 7): three A stages re-point to the next output tile inside the first K tile, and the B-stage
+          # parity carries over an odd count of K tiles from one output tile to the next; several rounds of tiles per workgroup
+          (40000, 512, 192, 128), (40000, 512, 192, 192), (70000, 256, 192, 256), (50000, 768, 320, 192), (66000, 512, 448, 256),
+          (33000, 512, 448, 128)]
 
 
 @pytest.mark.parametrize("M,N,K,tile", SHAPES)

@@ -247,6 +247,99 @@ def _dp_worker(rank, world, port, out, exchange="fp32"):
     torch.distributed.destroy_process_group()
 
 
+class _GlooStandInComm:
+    """Stand-in for hip.Comm (RCCL through the C ABI) with the same contract -- ``all_reduce(tensor, offset, count, stream_)``
+    ordered on the GIVEN stream, in-place sum over ranks -- carried by gloo through the host.  Everything else of
+    Trainer(exchange="c") is the real thing: the private exchange stream, the `ready` event behind the kernels that produced the
+    gradient range, the `done` event the optimizer stream waits for, the drain before torch.distributed's own collectives."""
+
+    def __init__(self):
+        self.calls = []
+
+    def all_reduce(self, t, offset=0, count=None, stream_=None):
+        n = t.numel() - offset if count is None else count
+        st = torch.cuda.ExternalStream(stream_.value)
+        self.calls.append((int(offset), int(n), int(stream_.value)))
+        with torch.cuda.stream(st):
+            host = t.view(-1)[offset:offset + n].float().cpu()  # (on `st`: behind whatever the caller ordered it behind)
+            torch.distributed.all_reduce(host)
+            t.view(-1)[offset:offset + n].copy_(host.to(t.dtype), non_blocking=True)
+
+    def close(self):
+        self.calls.append("closed")
+
+
+def _dp_c_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.data import shard_batch
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    oc, p0, x, labels = _dp_problem()
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
+    model.load_state_dict(p0)
+    comm = _GlooStandInComm()
+    tr = Trainer(model, AdamW(model, lr=1e-3, warmup_steps=2, total_steps=100, max_grad_norm=1.0), exchange="c", comm=comm, measure_stall=True)
+    tr.broadcast_parameters()
+    mine = shard_batch(list(range(8)), rank, world)
+    xd, ld = torch.tensor(x[mine]).cuda(), torch.tensor(labels[mine]).cuda()
+    losses = []
+    for step in range(4):
+        losses.append(float(tr.train_step(xd, None, ld, raw=False).item()))
+        if step == 1:  # a torch.distributed collective between two steps, as train.evaluate issues one: the exchange is drained first
+            tr.drain_exchange()
+            probe = torch.ones(1, device="cuda")
+            torch.distributed.all_reduce(probe)
+            assert float(probe.item()) == world
+    ranges = [(o, c) for o, c in model.announced_grad_ranges()]
+    per_step = [c for c in comm.calls if c != "closed"]
+    assert len(per_step) == 4 * len(ranges) and [(o, c) for o, c, _ in per_step[:len(ranges)]] == ranges
+    assert len({s for _, _, s in per_step}) == 1 and per_step[0][2] != torch.cuda.current_stream().cuda_stream  # its own stream
+    waits = tr.bucket_wait_us()
+    assert waits is not None and len(waits) == len(ranges)
+    tr.close()
+    tr.close()  # idempotent
+    assert comm.calls[-1] == "closed" and comm.calls.count("closed") == 1
+    if rank == 0:
+        torch.save({"params": model.params[:model.num_trainable].cpu(), "losses": losses}, out)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp2_exchange_c_event_ordering_with_a_stand_in_communicator(tmp_path):
+    """Trainer(exchange="c") -- the library's own communicator on a private stream -- on two ranks with gloo standing in for RCCL
+    behind the communicator's interface: the buckets arrive in the engine's announced order on ONE stream that is not the compute
+    stream, each behind the kernels that produced its range and ahead of the optimizer tail that consumes it (a mis-ordered event
+    reduces stale gradients and the parameters leave the single-process run), a torch.distributed collective between steps
+    follows a drained exchange, and close() destroys the communicator once.  What stays unexercised is RCCL itself."""
+    import socket
+    import torch.multiprocessing as mp
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dpc.pt")
+    mp.spawn(_dp_c_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    oc, p0, x, labels = _dp_problem()
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc)).train()
+    model.load_state_dict(p0)
+    tr = Trainer(model, AdamW(model, lr=1e-3, warmup_steps=2, total_steps=100, max_grad_norm=1.0))
+    xd, ld = torch.tensor(x).cuda(), torch.tensor(labels).cuda()
+    for _ in range(4):
+        tr.train_step(xd, None, ld, raw=False)
+    ref = model.params[:model.num_trainable].cpu()
+    start = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc))
+    start.load_state_dict(p0)
+    p_init = start.params[:start.num_trainable].cpu()
+    du_ref, du_dp = ref - p_init, got["params"] - p_init
+    rel = float((du_dp - du_ref).norm() / du_ref.norm())
+    assert du_ref.abs().max() > 1e-3 and rel < 0.1, rel
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("exchange", ["fp32", "bf16"])
 def test_dp2_trainer_equals_single_process(tmp_path, exchange):
@@ -472,13 +565,16 @@ def test_train_cli_two_rank_resume_restores_each_ranks_regulariser_streams(tmp_p
 
 
 @pytest.mark.timeout(900)
-def test_train_cli_sharded_evaluation_equals_single_process(tmp_path):
+@pytest.mark.parametrize("topology", ["layer", "group"])
+def test_train_cli_sharded_evaluation_equals_single_process(tmp_path, topology):
     """Every rank evaluates its contiguous shard of each validation batch (the reference's per_device_eval_batch_size =
     batch_size // num_devices, ssak/train/transformers/wav2vec_train.py:357) and one all-reduce of (edits, words, loss sum,
     utterances) gives the metrics: the initial evaluation of two ranks (gloo, one card) equals the single-process one -- word
-    error counts exactly, the loss to fp32 summation order -- on 11 utterances in batches of 4 (shards 2+2, 2+2, 2+1).  The
-    layer-norm (XLSR) topology is used: it runs with the attention mask, so an utterance's logits do not depend on how far
-    its batch was padded (a group-norm model sees the padding -- there the reference's per-device batches differ too)."""
+    error counts exactly, the loss to fp32 summation order -- on 11 utterances in batches of 4 (shards 2+2, 2+2, 2+1).  Both
+    topologies: the layer-norm (XLSR) model runs with the attention mask; the group-norm (base) model runs WITHOUT one, so its
+    logits depend on how far an utterance was padded -- every shard is therefore padded to the longest utterance of the GLOBAL
+    batch, as the reference's collator pads before DataParallel scatters (wav2vec_train.py:79-100), and the metrics do not depend
+    on the world size."""
     import socket
     from oracle import w2v2_ref as R
     from ssak_amd import data as D
@@ -496,7 +592,7 @@ def test_train_cli_sharded_evaluation_equals_single_process(tmp_path):
             fw.write(f"utt{i}\t{kd}/audio/u{i}.wav\n")
             ft.write(f"utt{i} {synth_text(rng, 3, 8)}\n")
             fd.write(f"utt{i} {n / 16000:.3f}\n")
-    oc = R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True).deterministic()
+    oc = (R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True) if topology == "layer" else R.W2V2Config.tiny()).deterministic()
     base = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc))
     base.load_state_dict(R.init_params(oc, 3))
     save_pretrained(base, D.CharTokenizer(VOCAB), str(tmp_path / "base"))
