@@ -488,7 +488,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import side_benches
             sec = []
-            for fn, kw in ((side_benches.whisper_step, dict(B=8, steps=10)), (side_benches.xlsr_bucketed, dict(B=16, N=320))):
+            for fn, kw in ((side_benches.whisper_sweep, dict()), (side_benches.xlsr_sweep, dict())):
                 try:
                     sec.append(fn(**kw))
                 except Exception as e:  # a secondary line must not take the headline down with it
@@ -502,13 +502,19 @@ def main():
                 out["roofline"]["kernels"].append({
                     "kernel": lm["kernel"], "bound": "hbm", "launches_per_step": 1.0, "us_per_step": lm["us_per_call"],
                     "avg_launch_us": lm["us_per_call"], "achieved": lm["achieved_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "algorithmic_mb_per_step": round(lm["algorithmic_mb_per_window"] * 8, 2), "frac": lm["frac"],
+                    "algorithmic_mb_per_step": round(lm["algorithmic_mb_per_window"] * sec[0].get("batch", 8), 2), "frac": lm["frac"],
                     "share_of_step": lm["share_of_step"],
-                    "workload": "secondary[0]: Whisper-small window step, B = 8 (per ssak_logmel_whisper call; share = of THAT step)"})
+                    "workload": f"secondary[0]: Whisper-small window step, B = {sec[0].get('batch', 8)} (per ssak_logmel_whisper call; share = of THAT step)"})
             try:
-                out["ingest"] = side_benches.ingest_rate(N=256)
+                out["ingest"] = side_benches.ingest_rate()
             except Exception as e:
                 out["ingest"] = {"error": repr(e)}
+            # the headline step fed from the section-8d Kaldi folder through `train.py --online`'s loop
+            try:
+                out["online"] = side_benches.online_steps(B=B)
+                out["online"]["vs_resident_batch"] = round(out["online"]["value"] / value, 4)
+            except Exception as e:
+                out["online"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -294,15 +294,30 @@ def pad_labels(label_lists: Sequence[Sequence[int]], pad_value: int = -100) -> n
 
 
 def length_grouped_batches(lengths: Sequence[float], batch_size: int, rng: np.random.RandomState,
-                           mega_factor: int = 50) -> List[List[int]]:
+                           mega_factor: int = 50, frame_budget: Optional[float] = None, max_batch: Optional[int] = None) -> List[List[int]]:
     """``group_by_length`` batching (wav2vec_train.py:355 -> HF LengthGroupedSampler, trainer.py:758-775):
-    shuffle, cut into mega-batches of ``mega_factor * batch_size``, sort each by length (longest first), slice."""
+    shuffle, cut into mega-batches of ``mega_factor * batch_size``, sort each by length (longest first), slice.
+
+    ``frame_budget`` (an extension; None = the reference's constant-COUNT slices): slice each sorted mega-batch so that every batch
+    holds about the same PADDED length instead -- count x longest utterance <= ``frame_budget`` (in the unit of ``lengths``), at
+    least one and at most ``max_batch`` (default 8 x batch_size) utterances -- i.e. many short utterances or few long ones per
+    step.  With mixed 1-15 s audio a constant count leaves the short batches with a fraction of the work of the long ones
+    (16 x 1.5 s = 1 200 frames: 19 output tiles for 256 CUs); a constant frame budget keeps every step's products the same size.
+    The same shuffle / mega-batch / sort as the count mode, so one epoch still visits every utterance exactly once."""
     idx = rng.permutation(len(lengths))
     mega = mega_factor * batch_size
     out = []
+    cap = max_batch or 8 * batch_size
     for i in range(0, len(idx), mega):
         chunk = sorted(idx[i:i + mega].tolist(), key=lambda j: -lengths[j])
-        out += [chunk[k:k + batch_size] for k in range(0, len(chunk), batch_size)]
+        if frame_budget is None:
+            out += [chunk[k:k + batch_size] for k in range(0, len(chunk), batch_size)]
+            continue
+        k = 0
+        while k < len(chunk):
+            n = int(max(1, min(cap, frame_budget // max(lengths[chunk[k]], 1))))  # (sorted: the first one is the longest)
+            out.append(chunk[k:k + n])
+            k += n
     return out
 
 

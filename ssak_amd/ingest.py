@@ -1,8 +1,8 @@
 """Kaldi-folder audio -> device batches: the counterpart of the reference's on-the-fly loading
 (``ssak/utils/dataset.py:630-645`` -> ``ssak/utils/audio.py:24-154``) with everything after the file read on the GPU.
 
-The host only finds the PCM byte range of each segment (``offset = int(start * sr)``, audio.py:85-92) and copies it into
-one pinned staging buffer; one asynchronous H2D copy later the device converts to mono fp32
+The host only finds the PCM byte range of each segment (``offset = int(start * sr)``, audio.py:85-92; the WAV header is parsed
+once per file) and reader threads ``preadv`` it straight into one pinned staging buffer; one asynchronous H2D copy later the device converts to mono fp32
 (``ssak_pcm_to_mono_f32``), converts the sample rate (``ssak_resample_sinc`` = torchaudio's windowed-sinc resampler) and
 normalises (``ssak_wave_normalize``, a1).  ``BatchPrefetcher`` reads the next batches on a background thread while the
 current step runs, which is what the reference's 6 dataloader workers are for (wav2vec_train.py:360).
@@ -13,8 +13,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 import queue
+import struct
 import threading
-import wave
+from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -23,32 +24,119 @@ import torch
 from . import hip
 
 
-def read_pcm_segment(path: str, start: Optional[float] = None, end: Optional[float] = None) -> Tuple[bytes, int, int, int, int]:
-    """(raw interleaved PCM bytes of the segment, sample_rate, channels, bytes per sample, frames)."""
+class WavInfo:
+    """Where the PCM samples of a RIFF / WAVE file sit: parsed once per path (RIFF chunk walk), cached."""
+    __slots__ = ("sample_rate", "channels", "sample_width", "data_offset", "frames")
+
+    def __init__(self, sample_rate, channels, sample_width, data_offset, frames):
+        self.sample_rate, self.channels, self.sample_width, self.data_offset, self.frames = sample_rate, channels, sample_width, data_offset, frames
+
+
+_WAV_CACHE: dict = {}
+_WAV_LOCK = threading.Lock()
+
+
+def wav_info(path: str) -> WavInfo:
+    """Header of a PCM WAV file (format tag 1, or WAVE_FORMAT_EXTENSIBLE with the PCM sub-format), as the reference's loader needs
+    it (sample rate, channels, frames: ssak/utils/audio.py:64-92).  RuntimeError for anything else, as audio.py:49-55 raises."""
+    info = _WAV_CACHE.get(path)
+    if info is not None:
+        return info
     if not os.path.isfile(path):
         raise RuntimeError(f"File not found: {path}")  # audio.py:49-51
     try:
-        with wave.open(path, "rb") as f:
-            sr, nch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
-            if f.getcomptype() != "NONE":
-                raise RuntimeError(f"{path}: compressed WAV is not supported (PCM only)")
-            s0 = min(n, int(float(start) * sr)) if start else 0                      # audio.py:85-87
-            cnt = min(n - s0, int((float(end) - float(start or 0)) * sr)) if end else n - s0  # audio.py:89-91
-            f.setpos(s0)
-            raw = f.readframes(max(0, cnt))
-    except (wave.Error, EOFError) as err:
+        with open(path, "rb") as f:
+            head = f.read(12)
+            if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+                raise RuntimeError(f"Could not read {path} as PCM WAV (sox/ffmpeg decoding is not built): not a RIFF / WAVE file")
+            fmt = None
+            pos = 12
+            while True:
+                f.seek(pos)
+                ck = f.read(8)
+                if len(ck) < 8:
+                    raise RuntimeError(f"Could not read {path} as PCM WAV (sox/ffmpeg decoding is not built): no data chunk")
+                cid, size = ck[:4], struct.unpack("<I", ck[4:])[0]
+                if cid == b"fmt ":
+                    body = f.read(min(size, 40))
+                    tag, nch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+                    if tag == 0xFFFE and len(body) >= 26:
+                        tag = struct.unpack("<H", body[24:26])[0]
+                    fmt = (tag, nch, sr, bits)
+                elif cid == b"data":
+                    if fmt is None:
+                        raise RuntimeError(f"Could not read {path} as PCM WAV (sox/ffmpeg decoding is not built): data before fmt")
+                    tag, nch, sr, bits = fmt
+                    if tag != 1:
+                        raise RuntimeError(f"{path}: compressed WAV is not supported (PCM only)")
+                    sw = (bits + 7) // 8
+                    if sw not in (1, 2, 4) or nch < 1:
+                        raise RuntimeError(f"{path}: unsupported sample width {sw}")
+                    avail = max(0, os.fstat(f.fileno()).st_size - (pos + 8))  # (a truncated file: what is really there)
+                    info = WavInfo(sr, nch, sw, pos + 8, min(size, avail) // (nch * sw))
+                    break
+                pos += 8 + size + (size & 1)
+    except (OSError, struct.error) as err:
         raise RuntimeError(f"Could not read {path} as PCM WAV (sox/ffmpeg decoding is not built): {err}") from err
-    if sw not in (1, 2, 4):
-        raise RuntimeError(f"{path}: unsupported sample width {sw}")
-    return raw, sr, nch, sw, len(raw) // (nch * sw)
+    with _WAV_LOCK:
+        _WAV_CACHE[path] = info
+    return info
+
+
+def segment_range(info: WavInfo, start: Optional[float], end: Optional[float]) -> Tuple[int, int]:
+    """(file offset, frames) of the segment: offset = int(start * sr) frames in, int((end - start) * sr) frames long, clipped to the
+    file (audio.py:85-92)."""
+    n, sr = info.frames, info.sample_rate
+    s0 = min(n, int(float(start) * sr)) if start else 0
+    cnt = min(n - s0, int((float(end) - float(start or 0)) * sr)) if end else n - s0
+    return info.data_offset + s0 * info.channels * info.sample_width, max(0, cnt)
+
+
+def read_pcm_segment(path: str, start: Optional[float] = None, end: Optional[float] = None) -> Tuple[bytes, int, int, int, int]:
+    """(raw interleaved PCM bytes of the segment, sample_rate, channels, bytes per sample, frames)."""
+    info = wav_info(path)
+    off, cnt = segment_range(info, start, end)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        raw = os.pread(fd, cnt * info.channels * info.sample_width, off)
+    finally:
+        os.close(fd)
+    return raw, info.sample_rate, info.channels, info.sample_width, len(raw) // (info.channels * info.sample_width)
+
+
+def _read_into(jobs):
+    """One reader-thread task: a share of a batch's segments, each straight into its slice of the pinned staging buffer
+    (os.preadv releases the GIL; no intermediate bytes object, no numpy copy).  A task per reader, not per file: the executor's
+    per-task hand-off costs as much as reading a cached 320 KB file."""
+    for path, off, view in jobs:
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            got, want = 0, len(view)
+            while got < want:
+                n = os.preadv(fd, [view[got:]], off + got)
+                if n <= 0:
+                    raise RuntimeError(f"{path}: short read ({got} of {want} bytes)")
+                got += n
+        finally:
+            os.close(fd)
+
+
+def _infos(paths):
+    return [wav_info(p) for p in paths]
 
 
 class DeviceIngest:
     """Turns lists of (path, start, end) into normalised fp32 batches on the device."""
 
-    def __init__(self, sample_rate: int = 16000, device="cuda:0", normalize: bool = True):
+    def __init__(self, sample_rate: int = 16000, device="cuda:0", normalize: bool = True, readers: Optional[int] = None):
+        """``readers``: file-reader threads (default: the CPUs this process may use, at most 8; the reference runs 6 dataloader
+        worker processes, wav2vec_train.py:360)."""
         self.sample_rate, self.device, self.normalize = sample_rate, torch.device(device), normalize
+        n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        self.readers = max(1, min(8, n_cpu) if readers is None else int(readers))
+        self._pool = ThreadPoolExecutor(max_workers=self.readers, thread_name_prefix="ssak-ingest")
         self._tables = {}
+        self._stream = None  # the device part's own stream (to_device_async)
         # ring of reusable pinned staging buffers: pinning a fresh buffer per batch costs milliseconds (and the caching host
         # allocator cannot recycle one whose copy is still pending); [tensor, event of the last H2D copy out of it]
         self._ring = [[None, None] for _ in range(6)]
@@ -72,25 +160,57 @@ class DeviceIngest:
             self._tables[sr] = (host.to(self.device), o.value, n.value)
         return self._tables[sr]
 
-    def stage(self, items: Sequence[Tuple[str, Optional[float], Optional[float]]]):
-        """Host part (thread-safe, no GPU work): read the byte ranges into ONE pinned buffer."""
-        segs = [read_pcm_segment(p, s, e) for p, s, e in items]
-        total = sum(len(r) for r, *_ in segs)
+    def stage(self, items: Sequence[Tuple[str, Optional[float], Optional[float]]], labels: Optional[np.ndarray] = None):
+        """Host part (no GPU work): the byte ranges of the segments (headers parsed once per file, in parallel) into ONE pinned
+        buffer, read by the reader threads straight into their slices of it.  ``labels`` (int64 [B, L], -100 padding): appended
+        to the same buffer, so that the batch's ONE H2D copy carries them too (a ``labels.to(device)`` from pageable memory on
+        the compute stream blocks the host until the previous step has drained)."""
+        paths = [p for p, _, _ in items]
+        if all(p in _WAV_CACHE for p in paths):
+            infos = [_WAV_CACHE[p] for p in paths]
+        else:  # first visit: the headers in parallel too (one small read per file)
+            k = self.readers
+            infos = [i for part in self._pool.map(_infos, [paths[j::k] for j in range(k)]) for i in part]
+            infos = [_WAV_CACHE[p] for p in paths]
+        ranges = [segment_range(i, s, e) for i, (_, s, e) in zip(infos, items)]
+        sizes = [cnt * i.channels * i.sample_width for i, (_, cnt) in zip(infos, ranges)]
+        audio = sum(sizes)
+        lab_off = (audio + 7) // 8 * 8
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int64)
+        total = audio if lab is None else lab_off + lab.nbytes
         slot = self._staging(total)
         pinned = slot[0]
-        view = pinned.numpy()
-        offs, pos = [], 0
-        for raw, *_ in segs:
-            view[pos:pos + len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+        mv = memoryview(pinned.numpy())
+        if lab is not None:
+            pinned.numpy()[lab_off:lab_off + lab.nbytes] = lab.reshape(-1).view(np.uint8)
+        offs, pos, jobs = [], 0, []
+        for (path, _, _), (foff, _), nbytes in zip(items, ranges, sizes):
             offs.append(pos)
-            pos += len(raw)
-        meta = [(sr, nch, sw, n) for _, sr, nch, sw, n in segs]
-        return (pinned[:max(total, 1)], slot), offs, meta
+            if nbytes:
+                jobs.append((path, foff, mv[pos:pos + nbytes]))
+            pos += nbytes
+        k = min(self.readers, max(1, len(jobs)))
+        list(self._pool.map(_read_into, [jobs[j::k] for j in range(k)]))  # (list: re-raises a reader's exception here)
+        meta = [(i.sample_rate, i.channels, i.sample_width, cnt) for i, (_, cnt) in zip(infos, ranges)]
+        return (pinned[:max(total, 1)], slot), offs, meta, (None if lab is None else (lab_off, lab.shape))
+
+    def to_device_async(self, staged):
+        """``to_device`` on the ingest's OWN stream: the H2D copy runs on a copy engine and the small decode / normalise kernels beside
+        the caller's work instead of in front of it.  Returns ((waves, lens[, labels]), event); the consumer's stream waits for the event
+        (``BatchPrefetcher`` does, one batch ahead)."""
+        with torch.cuda.device(self.device):
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            with torch.cuda.stream(self._stream):
+                out = self.to_device(staged)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+        return out, ev
 
     def to_device(self, staged):
         """Device part: H2D copy, PCM -> mono fp32 -> target rate -> zero-mean / unit-variance.  Returns (waves [B, T] fp32,
         lens [B] int32), both on the device; no host synchronisation."""
-        (pinned, slot), offs, meta = staged
+        (pinned, slot), offs, meta, lab_info = staged
         B = len(meta)
         dev = self.device
         with torch.cuda.device(dev):
@@ -125,6 +245,9 @@ class DeviceIngest:
                     waves[torch.tensor(idx, device=dev), :mono.shape[1]] = mono
             if self.normalize:
                 waves = hip.wave_normalize(waves, lens)
+            if lab_info is not None:
+                lo, shape = lab_info
+                return waves, lens, raw[lo:lo + 8 * int(np.prod(shape))].view(torch.int64).view(*shape)
         return waves, lens
 
     def load_batch(self, items):
@@ -134,25 +257,40 @@ class DeviceIngest:
 class BatchPrefetcher:
     """Iterates over batches of items; file reads + pinned staging of the next ``depth`` batches run on a background thread."""
 
-    def __init__(self, ingest: DeviceIngest, batches: Sequence[Sequence[Tuple[str, Optional[float], Optional[float]]]], depth: int = 2):
+    def __init__(self, ingest: DeviceIngest, batches: Sequence[Sequence[Tuple[str, Optional[float], Optional[float]]]], depth: int = 2,
+                 labels: Optional[Sequence[np.ndarray]] = None):
+        """``labels``: one int64 [B, L] array per batch (-100 padding); the iterator then yields (waves, lens, labels) with the labels
+        on the device too, carried by the batch's one H2D copy."""
         self.ingest, self.batches = ingest, list(batches)
+        self.labels = None if labels is None else list(labels)
         self.q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
         self.thread = threading.Thread(target=self._work, daemon=True)
         self.thread.start()
 
     def _work(self):
         try:
-            for b in self.batches:
-                self.q.put(self.ingest.stage(b))
+            for k, b in enumerate(self.batches):
+                self.q.put(self.ingest.stage(b, None if self.labels is None else self.labels[k]))
         except BaseException as err:  # surfaced on the consumer side
             self.q.put(err)
         self.q.put(None)
 
     def __iter__(self):
+        # the device part of batch k + 1 (H2D copy + decode + normalise on the ingest's stream) is issued before batch k is handed
+        # out: it overlaps the consumer's step instead of sitting in front of it on the consumer's stream
+        ahead = None
         while True:
             item = self.q.get()
-            if item is None:
-                return
             if isinstance(item, BaseException):
                 raise item
-            yield self.ingest.to_device(item)
+            nxt = None if item is None else self.ingest.to_device_async(item)
+            if ahead is not None:
+                out, ev = ahead
+                cur = torch.cuda.current_stream(self.ingest.device)
+                cur.wait_event(ev)
+                for t in out:
+                    t.record_stream(cur)  # (allocated on the ingest's stream, consumed on the caller's)
+                yield out
+            if item is None:
+                return
+            ahead = nxt

@@ -95,6 +95,9 @@ def build_parser():
     p.add_argument("--debug", default=False, action="store_true")
     p.add_argument("--gpus", default=None)
     p.add_argument("--online", default=False, action="store_true")
+    p.add_argument("--batch_audio", type=float, default=None,
+                   help="(extension, not a flag of the reference) seconds of PADDED audio per step: length-grouped batches of a constant "
+                        "padded length instead of a constant count (many short utterances or few long ones per step)")
     p.add_argument("--max_duration", default=15, type=int)
     p.add_argument("--min_duration", default=1, type=int)
     p.add_argument("--base_model", required=True, type=str, help="Model folder to adapt (HF layout)")
@@ -198,8 +201,11 @@ def main(argv=None):
     if len(train_u) < world:
         raise RuntimeError(f"{len(train_u)} training utterances for {world} ranks: nothing to shard")
     script = os.path.abspath(__file__)
-    out_dir = os.path.join(args.output_dir, train_folder_name(vars(args), script))
-    untrained_dir = os.path.join(args.output_dir, train_folder_name(vars(args), script, untrained=True))
+    # (the folder names are the reference's, built from ITS options in declaration order: the extension --batch_audio is not one
+    # of them and only adds a suffix when it is used)
+    named = {k: v for k, v in vars(args).items() if k != "batch_audio"}
+    out_dir = os.path.join(args.output_dir, train_folder_name(named, script) + ("" if args.batch_audio is None else f"_ba-{args.batch_audio:g}"))
+    untrained_dir = os.path.join(args.output_dir, train_folder_name(named, script, untrained=True))
     model, tok = load_pretrained(args.base_model, device=dev, freeze_feature_encoder=not args.no_freeze,
                                  attention_dropout=args.attention_dropout,
                                  hidden_dropout=args.hidden_dropout, feat_proj_dropout=args.feat_proj_dropout,
@@ -220,6 +226,10 @@ def main(argv=None):
     vw, vl = prepare(valid_u, tok)
     steps_per_epoch = max(1, -(-len(tl) // args.batch_size))  # dataloader_drop_last=False: the short last batch is a step
     total = round(args.num_epochs * len(tl) / args.batch_size)
+    if args.batch_audio is not None:  # constant padded length per step: the step count of an epoch follows from the plan
+        steps_per_epoch = max(1, len(length_grouped_batches(train_len, args.batch_size, np.random.RandomState(args.seed),
+                                                            frame_budget=args.batch_audio * 16000)))
+        total = round(args.num_epochs * steps_per_epoch)
     opt = AdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay, warmup_steps=500, total_steps=max(total, 1))
     trainer = Trainer(model, opt)
     trainer.broadcast_parameters()
@@ -295,7 +305,8 @@ def main(argv=None):
     while step < total:
         # (global batch, this rank's contiguous shard of it): shards may differ by one utterance on the short last batch and
         # may be empty; the trainer weights by utterance count
-        plan = [(idx, shard_batch(idx, rank, world) if world > 1 else idx) for idx in length_grouped_batches(train_len, args.batch_size, rng)]
+        plan = [(idx, shard_batch(idx, rank, world) if world > 1 else idx) for idx in length_grouped_batches(train_len, args.batch_size, rng,
+                                                                frame_budget=None if args.batch_audio is None else args.batch_audio * 16000)]
         plan = [gm for gm in plan if gm[0]][:total - step]
         if not plan:
             raise RuntimeError("empty batch plan: no training utterances")
@@ -305,7 +316,8 @@ def main(argv=None):
             if not plan:
                 continue
         if args.online:
-            feed = BatchPrefetcher(ingest, [[(train_u[i].path, train_u[i].start or None, train_u[i].end or None) for i in m] for _, m in plan if m])
+            feed = BatchPrefetcher(ingest, [[(train_u[i].path, train_u[i].start or None, train_u[i].end or None) for i in m] for _, m in plan if m],
+                                   labels=[pad_labels([tl[i] for i in m]) for _, m in plan if m])  # (the labels ride with the audio's H2D copy)
             feed = iter(feed)
         else:
             feed = (pad_waves([tw[i] for i in m]) for _, m in plan if m)
@@ -315,11 +327,12 @@ def main(argv=None):
             if not mine:  # this rank's shard of a short last batch is empty: zeros into the same collectives
                 loss = trainer.train_step(None, None, None, global_count=gc)
             else:
-                x, lens = next(feed)
-                lab = pad_labels([tl[i] for i in mine])
-                if args.online:  # already on the device and normalised
-                    loss = trainer.train_step(x, lens, torch.from_numpy(lab).to(dev), raw=False, global_count=gc)
+                if args.online:  # already on the device and normalised, labels included
+                    x, lens, lab_d = next(feed)
+                    loss = trainer.train_step(x, lens, lab_d, raw=False, global_count=gc)
                 else:
+                    x, lens = next(feed)
+                    lab = pad_labels([tl[i] for i in mine])
                     loss = trainer.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(lens).to(dev),
                                               torch.from_numpy(lab).to(dev), global_count=gc)
             run_loss.append(loss)

@@ -71,3 +71,32 @@ def test_ingest_prefetcher_and_errors(tmp_path):
     assert got[0][1] == [16000, 16500, 17000] and got[1][1] == [17500, 18000, 18500]
     with pytest.raises(RuntimeError):
         list(BatchPrefetcher(ing, [[(str(tmp_path / "missing.wav"), None, None)]]))
+
+
+def test_ingest_prefetcher_carries_labels_and_runs_one_batch_ahead(tmp_path):
+    """The prefetcher's device part runs on the ingest's own stream one batch ahead of the consumer (H2D copy + decode + normalise
+    beside the consumer's step, an event hand-off) and the label matrix of a batch rides in the same pinned buffer and H2D copy:
+    every batch's waves equal `load_batch` on the same items bit for bit, the labels come back unchanged, segments (start / end)
+    and files of different lengths included, while the consumer stream is kept busy."""
+    from ssak_amd.ingest import BatchPrefetcher, DeviceIngest
+    rng = np.random.default_rng(2)
+    items = []
+    for i in range(10):
+        p = str(tmp_path / f"w{i}.wav")
+        _write(p, _signal(rng, 20000 + 777 * i, 16000), 16000)
+        items.append((p, None, None) if i % 3 else (p, 0.25, 1.0))
+    batches = [items[:4], items[4:7], items[7:]]
+    labels = [rng.integers(-100, 31, (len(b), 5 + k)).astype(np.int64) for k, b in enumerate(batches)]
+    ing = DeviceIngest(16000)
+    want = [DeviceIngest(16000).load_batch(b) for b in batches]
+    busy = torch.randn(2048, 2048, device="cuda")
+    got = []
+    for w, l, y in BatchPrefetcher(ing, batches, depth=2, labels=labels):
+        for _ in range(20):
+            busy = busy @ busy * 1e-3  # (the consumer's stream has work queued while the next batch's device part is issued)
+        got.append((w.clone(), l.clone(), y.clone()))
+    torch.cuda.synchronize()
+    assert len(got) == 3
+    for (w, l, y), (ww, wl), lab in zip(got, want, labels):
+        assert torch.equal(w, ww) and torch.equal(l, wl)
+        assert y.dtype == torch.int64 and np.array_equal(y.cpu().numpy(), lab)

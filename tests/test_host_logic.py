@@ -359,3 +359,27 @@ def test_alignment_tool_cut_decision_pure_function():
             lines = [f"u_cut{i:02} rec {1.5 + a:.3f} {1.5 + b:.3f}\n" for i, a, b, _ in got if b > a]
             assert lines == want["segments"], (trial, refine)
             assert [f"u_cut{i:02} {t}\n" for i, a, b, t in got if b > a] == want["text"]
+
+
+def test_length_grouped_batches_with_a_frame_budget():
+    """ssak_amd.data.length_grouped_batches(frame_budget=...): the reference's shuffle / mega-batch / sort (HF LengthGroupedSampler,
+    docker/transformers_modified/trainer.py:758-775) with slices of a constant PADDED length instead of a constant count: every
+    utterance exactly once, count x longest <= budget (or a single utterance longer than the budget), the count capped, the
+    count mode untouched by the new argument."""
+    import numpy as np
+    from ssak_amd.data import length_grouped_batches
+    rng = np.random.default_rng(0)
+    L = (np.exp(rng.uniform(0, np.log(15), 1000)) * 16000).astype(int).tolist()
+    ref = length_grouped_batches(L, 16, np.random.RandomState(3))
+    assert ref == length_grouped_batches(L, 16, np.random.RandomState(3), frame_budget=None)
+    assert all(len(b) == 16 for b in ref[:-1]) and sorted(i for b in ref for i in b) == list(range(1000))
+    budget = 160 * 16000
+    got = length_grouped_batches(L, 16, np.random.RandomState(3), frame_budget=budget)
+    assert sorted(i for b in got for i in b) == list(range(1000))
+    for b in got:
+        assert L[b[0]] == max(L[i] for i in b)  # sorted inside a mega-batch: the first one is the longest
+        assert len(b) * L[b[0]] <= budget or len(b) == 1
+        assert 1 <= len(b) <= 8 * 16
+    assert max(len(b) for b in got) > 3 * min(len(b) for b in got)  # short utterances travel in larger batches
+    tight = length_grouped_batches(L, 16, np.random.RandomState(3), frame_budget=budget, max_batch=20)
+    assert max(len(b) for b in tight) == 20

@@ -107,7 +107,23 @@ def whisper_step(B=8, steps=10, warmup=2, device="cuda:0"):
             "loss": round(float(loss.item()), 4)}
 
 
-def xlsr_bucketed(B=16, N=320, device="cuda:0"):
+def whisper_sweep(batches=(8, 16, 32), steps=10, device="cuda:0"):
+    """"B in {8, 16, 32}; report best" for the Whisper window step -- the best line, with every batch's figures
+    under `sweep` (the log-mel slot is the best line's)."""
+    rows = []
+    for B in batches:
+        try:
+            rows.append(whisper_step(B=B, steps=steps if B <= 16 else max(4, steps // 2), device=device))
+        except Exception as e:  # (a batch that does not fit must not take the line down)
+            rows.append({"batch": B, "error": repr(e)})
+        torch.cuda.empty_cache()
+    ok = [r for r in rows if "value" in r]
+    best = dict(max(ok, key=lambda r: r["value"]))
+    best["sweep"] = [{k: r.get(k) for k in ("batch", "value", "ms_per_step", "whole_step_frac", "error") if k in r} for r in rows]
+    return best
+
+
+def xlsr_bucketed(B=16, N=320, device="cuda:0", frame_budget=None, model_trainer=None):
     """BASELINE configs[4] on one GPU: Wav2Vec2-large-XLSR CTC train step over mixed-length utterances (durations log-uniform in
     [1 s, 15 s], wav2vec_train.py:149-150), batched like HF's LengthGroupedSampler (docker/transformers_modified/trainer.py:758-775),
     right-padded with lengths.  One pass over all batches; algorithmic FLOPs counted on the real (unpadded) lengths."""
@@ -131,18 +147,24 @@ def xlsr_bucketed(B=16, N=320, device="cuda:0"):
         return (fe + 3.0 * rest) / 1e9
 
     assert abs(train_gflop(160000) - 1053.50) < 1.0, train_gflop(160000)  # XLSR-large @10 s
-    model = Wav2Vec2ForCTC(cfg, device=device, freeze_feature_encoder=True, seed=69).train()
-    model.load_state_dict(_w2v2_state(model))
-    opt = AdamW(model, lr=1e-4, warmup_steps=500)
-    trainer = Trainer(model, opt)
+    if model_trainer is None:
+        model = Wav2Vec2ForCTC(cfg, device=device, freeze_feature_encoder=True, seed=69).train()
+        model.load_state_dict(_w2v2_state(model))
+        opt = AdamW(model, lr=1e-4, warmup_steps=500)
+        trainer = Trainer(model, opt)
+    else:
+        model, trainer = model_trainer
     rng = np.random.default_rng(1234)
     durs = np.exp(rng.uniform(np.log(1.0), np.log(15.0), N))
     nsamp = (durs * 16000).astype(np.int64)
-    batches = [b for b in length_grouped_batches(nsamp.tolist(), B, np.random.RandomState(0)) if len(b) == B]
+    if frame_budget is None:
+        batches = [b for b in length_grouped_batches(nsamp.tolist(), B, np.random.RandomState(0)) if len(b) == B]
+    else:  # constant padded length per step (ssak_amd.data.length_grouped_batches: frame_budget, in samples here)
+        batches = length_grouped_batches(nsamp.tolist(), B, np.random.RandomState(0), frame_budget=frame_budget)
     dev_batches = []
     for idx in batches:
         T = (int(max(nsamp[i] for i in idx)) + 7) // 8 * 8
-        wav = np.zeros((B, T), np.float32)
+        wav = np.zeros((len(idx), T), np.float32)
         ids = []
         for r, i in enumerate(idx):
             wav[r, :nsamp[i]] = synth_wave(rng, int(nsamp[i]))
@@ -150,7 +172,7 @@ def xlsr_bucketed(B=16, N=320, device="cuda:0"):
             n = max(1, min(int(durs[i] * 8), (fl - 1) // 2))  # ~8 characters per second, always feasible for CTC
             ids.append(text_to_ids(synth_text(rng, n, n)))
         Lm = max(len(x) for x in ids)
-        lab = np.full((B, Lm), -100, np.int64)
+        lab = np.full((len(idx), Lm), -100, np.int64)
         for r, x in enumerate(ids):
             lab[r, :len(x)] = x
         dev_batches.append((torch.tensor(wav).to(device), torch.tensor(nsamp[idx].astype(np.int32)).to(device), torch.tensor(lab).to(device)))
@@ -163,20 +185,94 @@ def xlsr_bucketed(B=16, N=320, device="cuda:0"):
         loss = trainer.train_step(w, l, y)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    utts = B * len(dev_batches)
     used = [i for b in batches for i in b]
+    utts = len(used)
     audio = float(sum(durs[i] for i in used))
-    padded = float(sum(dev_batches[j][0].shape[1] * B for j in range(len(dev_batches)))) / 16000.0
+    padded = float(sum(dev_batches[j][0].shape[1] * dev_batches[j][0].shape[0] for j in range(len(dev_batches)))) / 16000.0
     tf = sum(train_gflop(int(nsamp[i])) for i in used) / dt / 1e3
-    del model, opt, trainer
     return {"workload": "Wav2Vec2-large-XLSR CTC train step, bf16, durations log-uniform 1-15 s, length-grouped batches, attention "
                         "mask (BASELINE.json configs[4] on 1 GPU)",
-            "value": round(utts / dt, 2), "unit": "utterances/sec", "audio_sec_per_sec": round(audio / dt, 1), "batch": B,
+            "value": round(utts / dt, 2), "unit": "utterances/sec", "audio_sec_per_sec": round(audio / dt, 1),
+            "batch": B if frame_budget is None else None,
+            "batching": (f"constant count: {B} utterances per step (HF LengthGroupedSampler, the reference's mode)" if frame_budget is None else
+                         f"constant padded length: count x longest <= {frame_budget / 16000:.0f} s of audio per step "
+                         f"({min(len(b) for b in batches)}-{max(len(b) for b in batches)} utterances; ssak_amd.data.length_grouped_batches frame_budget)"),
             "steps": len(dev_batches), "ms_per_step": round(dt / len(dev_batches) * 1e3, 3), "padding_overhead": round(padded / audio - 1.0, 4),
             "whole_step_tflops": round(tf, 1), "whole_step_frac": round(tf / PEAK_BF16_TFLOPS, 4), "loss": round(float(loss.item()), 4)}
 
 
-def ingest_rate(N=256, sr=16000, nch=1, B=32):
+def xlsr_sweep(batches=(16, 32, 64), budgets_s=(320.0,), N=640, device="cuda:0"):
+    """SURVEY.md section 8d for configs[4]: the bucketed epoch at B in {16, 32, 64} (constant count, the reference's batching) and
+    with a constant padded length per step; the best line, every configuration's figures under `sweep`.  One model for all."""
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer
+    cfg = Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                         feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
+    model = Wav2Vec2ForCTC(cfg, device=device, freeze_feature_encoder=True, seed=69).train()
+    model.load_state_dict(_w2v2_state(model))
+    trainer = Trainer(model, AdamW(model, lr=1e-4, warmup_steps=500))
+    rows = []
+    for B in batches:
+        rows.append(xlsr_bucketed(B=B, N=N, device=device, model_trainer=(model, trainer)))
+    for sec in budgets_s:
+        rows.append(xlsr_bucketed(B=16, N=N, device=device, frame_budget=sec * 16000, model_trainer=(model, trainer)))
+    best = dict(max(rows, key=lambda r: r["audio_sec_per_sec"]))
+    best["sweep"] = [{k: r[k] for k in ("batching", "value", "audio_sec_per_sec", "ms_per_step", "steps", "padding_overhead", "whole_step_frac")} for r in rows]
+    del model, trainer
+    return best
+
+
+def online_steps(B=32, steps=20, warmup=5, n_files=4096, device="cuda:0", keep_dir=None):
+    """The headline step fed from FILES: SURVEY.md section 8d's Kaldi folder (4 096 PCM16 mono 16 kHz WAV files of 10 s, wav.scp / text
+    / utt2dur) through the loop of `python -m ssak_amd.train --online` (ssak_amd/train.py: load_kaldi -> length-grouped batch plan
+    -> BatchPrefetcher(DeviceIngest) -> Trainer.train_step on the normalised device batch), `steps` timed steps after `warmup`.
+    Reference path: ssak/utils/dataset.py:498-645, ssak/utils/audio.py:24-105, 6 loader workers at wav2vec_train.py:360."""
+    import shutil
+    import tempfile
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.data import CharTokenizer, length_grouped_batches, load_kaldi, pad_labels, remove_special_words
+    from ssak_amd.ingest import BatchPrefetcher, DeviceIngest
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.synth import VOCAB, write_kaldi_folder
+    from ssak_amd.trainer import AdamW, Trainer
+    d = keep_dir or tempfile.mkdtemp(prefix="ssak_kaldi_")
+    t_gen = time.perf_counter()
+    if not os.path.exists(os.path.join(d, "wav.scp")):
+        write_kaldi_folder(d, n_files, threads=min(16, len(os.sched_getaffinity(0))))
+    t_gen = time.perf_counter() - t_gen
+    utts = load_kaldi(d, 1.0, 15.0)
+    tok = CharTokenizer(VOCAB)
+    labels = [tok.encode(remove_special_words(u.text)) for u in utts]
+    lens = [int(u.duration * 16000) for u in utts]
+    plan = length_grouped_batches(lens, B, np.random.RandomState(69))[:warmup + steps]
+    model = Wav2Vec2ForCTC(Wav2Vec2Config(), device=device, freeze_feature_encoder=True, seed=69).train()
+    model.load_state_dict(_w2v2_state(model))
+    trainer = Trainer(model, AdamW(model, lr=1e-4, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=500, total_steps=100000))
+    ingest = DeviceIngest(16000, device)
+    feed = iter(BatchPrefetcher(ingest, [[(utts[i].path, utts[i].start or None, utts[i].end or None) for i in m] for m in plan], depth=3,
+                                labels=[pad_labels([labels[i] for i in m]) for m in plan]))
+    t0 = None
+    for k, m in enumerate(plan):
+        if k == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        x, ln, lab = next(feed)
+        loss = trainer.train_step(x, ln, lab, raw=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = sum(len(m) for m in plan[warmup:])
+    if keep_dir is None:
+        shutil.rmtree(d, ignore_errors=True)
+    del model, trainer
+    return {"path": f"Kaldi folder of {n_files} x 10 s PCM16 WAV files -> load_kaldi -> length-grouped batches of {B} -> BatchPrefetcher "
+                    f"({ingest.readers} reader threads, preadv into a pinned ring, one H2D copy per batch) -> device decode + normalise -> "
+                    "the headline train step (the loop of `ssak_amd.train --online`)",
+            "value": round(n / dt, 2), "unit": "utterances/sec", "steps": len(plan) - warmup, "warmup": warmup, "ms_per_step": round(dt / (len(plan) - warmup) * 1e3, 3),
+            "batch": B, "folder_written_in_s": round(t_gen, 1), "final_loss": round(float(loss.item()), 4)}
+
+
+def ingest_rate(N=1024, sr=16000, nch=1, B=32):
     """10 s PCM16 WAV files -> normalised device batches of B through the prefetching device ingest
     (ssak_amd/ingest.py: file read, PCM decode + mono mix + resample on the device, waveform normalisation)."""
     import tempfile
@@ -196,6 +292,7 @@ def ingest_rate(N=256, sr=16000, nch=1, B=32):
         items.append((p, None, None))
     batches = [items[i:i + B] for i in range(0, N, B)]
     ing = DeviceIngest(16000)
+    readers = ing.readers
     for w, l in BatchPrefetcher(ing, batches[:2]):
         pass
     torch.cuda.synchronize()
@@ -208,5 +305,6 @@ def ingest_rate(N=256, sr=16000, nch=1, B=32):
         os.unlink(p)
     os.rmdir(d)
     return {"path": "Kaldi-style wav.scp entries -> PCM16 WAV read -> device decode / mono / resample -> ssak_wave_normalize -> batches of "
-                    f"{B} (ssak_amd/ingest.py, prefetch depth 3)", "utterances_per_sec": round(N / dt, 1), "files": N,
+                    f"{B} (ssak_amd/ingest.py: {readers} reader threads preadv into a pinned ring, prefetch depth 3)",
+            "utterances_per_sec": round(N / dt, 1), "files": N, "reader_threads": readers,
             "source": f"{sr} Hz x {nch} ch, 10 s"}
