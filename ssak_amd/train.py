@@ -95,9 +95,6 @@ def build_parser():
     p.add_argument("--debug", default=False, action="store_true")
     p.add_argument("--gpus", default=None)
     p.add_argument("--online", default=False, action="store_true")
-    p.add_argument("--batch_audio", type=float, default=None,
-                   help="(extension, not a flag of the reference) seconds of PADDED audio per step: length-grouped batches of a constant "
-                        "padded length instead of a constant count (many short utterances or few long ones per step)")
     p.add_argument("--max_duration", default=15, type=int)
     p.add_argument("--min_duration", default=1, type=int)
     p.add_argument("--base_model", required=True, type=str, help="Model folder to adapt (HF layout)")
@@ -118,6 +115,10 @@ def build_parser():
     p.add_argument("--data_augment_noise", default="", type=str, help="(used only with --data_augment)")
     p.add_argument("--data_augment_rir", default="", type=str, help="(used only with --data_augment)")
     p.add_argument("--output_dir", default=".", type=str)
+    # extensions (not flags of the reference; declared last and left out of the output-folder name unless used)
+    p.add_argument("--batch_audio", type=float, default=None,
+                   help="(extension, not a flag of the reference) seconds of PADDED audio per step: length-grouped batches of a constant "
+                        "padded length instead of a constant count (many short utterances or few long ones per step)")
     return p
 
 
