@@ -255,6 +255,10 @@ int ssak_prof_collect(void* stream, ssak_prof_entry* out /*host*/, int cap); /* 
 size_t ssak_conv0_workspace_bytes(int B, int T, int C);
 int ssak_conv0_gn_gelu(const float* x, const float* w, const float* gamma, const float* beta, void* out_bf16, void* workspace,
                        size_t workspace_bytes, int B, int T, int C, void* stream);
+/* the same on RAW full-length waveforms, the zero-mean / unit-variance normalisation folded into the GroupNorm statistics:
+ * out == ssak_conv0_gn_gelu(ssak_wave_normalize(x)) to fp32 rounding (SSAK_W2V2_OPT_RAW_INPUT uses it) */
+int ssak_conv0_gn_gelu_raw(const float* x, const float* w, const float* gamma, const float* beta, void* out_bf16, void* workspace,
+                       size_t workspace_bytes, int B, int T, int C, void* stream);
 
 /* ---- a7 (part): fused self-attention, head_dim 64 --------------------------------------------
  * Replaces Wav2Vec2Attention's softmax(QK^T d^-0.5 + key mask) -> dropout -> .V and its autograd
@@ -409,6 +413,12 @@ int ssak_w2v2_set_param_event(ssak_w2v2* h, void* params_ready, void* stall_begi
 #define SSAK_W2V2_OPT_POSCONV_DIRECT 3
 #define SSAK_W2V2_OPT_FRAGMENT_WEIGHTS 4
 #define SSAK_W2V2_OPT_TRANSPOSED_WEIGHTS 5
+/* SSAK_W2V2_OPT_RAW_INPUT  0 (default) / 1: `input_values` of ssak_w2v2_forward are RAW full-length waveforms (no padding inside the
+ * batch): the feature extractor's zero-mean / unit-variance normalisation (a1, ssak/utils/dataset.py:632) is folded into the
+ * GroupNorm statistics of the first conv layer -- conv0 is linear and bias-free, so only GroupNorm's epsilon changes (1e-5 sigma^2) --
+ * and the train step needs no ssak_wave_normalize pass.  wav2vec2 group-norm feature encoder, frozen, only; logits equal the
+ * two-pass form's to fp32 rounding.  Ragged batches and inference keep ssak_wave_normalize. */
+#define SSAK_W2V2_OPT_RAW_INPUT 6
 int ssak_w2v2_set_option(ssak_w2v2* h, int option, int value);
 /* The gradient ranges ssak_w2v2_backward announces, in announcement order, from the configuration alone (host arithmetic, no
  * device): head matrix, one range per encoder layer from the last to the first (a layer's q|k|v|out|ffn matrices are

@@ -298,7 +298,14 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 //   sum_t y[c,t]^2 = sum_{k,k'} w[c,k] w[c,k'] R[k,k'],  R[k,k'] = sum_t x[5t+k] x[5t+k']
 // i.e. 65 moments of the input per utterance (fp64) instead of a 512-channel convolution pass: the statistics pass drops
 // from 144 us to a few us.  Same output format as before (sums[b][c] = (sum y, sum y^2)), fixed summation order.
-constexpr int NMOM = KS0 + KS0 * (KS0 + 1) / 2;
+// Two more moments, sum x and sum x^2 over ALL samples of the utterance (slots NMOM - 2, NMOM - 1), fold the feature extractor's
+// zero-mean / unit-variance normalisation (a1: x_n = (x - mu) / sqrt(var + 1e-7), transformers feature_extraction_wav2vec2.py:
+// 78-97) into this GroupNorm for full-length utterances: conv0 is linear and bias-free, so conv(x_n) = (conv(x) - mu W_c) / sigma,
+// and GroupNorm over time is invariant under a per-channel shift and scale except for its epsilon:
+//     GN(conv(x_n)) = (y - mean_t y) / sqrt(var_t y + 1e-5 sigma^2),      y = conv(x) on the RAW waveform.
+// conv0_channel_stats_kernel adds 1e-5 (sigma^2 - 1) to the channel variances (through sum y^2) and the apply pass runs on raw
+// samples unchanged: the train step needs no normalisation pass at all (it was two launches and two passes over the waveform).
+constexpr int NMOM = KS0 + KS0 * (KS0 + 1) / 2 + 2;
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ x, int T, int T0, double* __restrict__ partial) {
   constexpr int FR0 = FR_STATS, NS0 = (FR0 - 1) * ST0 + KS0;
   __shared__ float xs[NS0];
@@ -314,6 +321,16 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restr
   double m[NMOM];
 #pragma unroll
   for (int i = 0; i < NMOM; ++i) m[i] = 0.0;
+  {
+    // every sample once: this workgroup's frames start at samples [5 f0, 5 (f0 + nfr)); the last workgroup takes the tail up to T
+    // (the last few samples of an utterance lie behind its last window: outside xs, straight from memory)
+    const int own = (blockIdx.x + 1 == gridDim.x) ? T - f0 * ST0 : nfr * ST0;
+    for (int i = threadIdx.x; i < own; i += 256) {
+      const double v = (double)(i < NS0 ? xs[i] : xb[f0 * ST0 + i]);
+      m[NMOM - 2] += v;
+      m[NMOM - 1] += v * v;
+    }
+  }
   for (int f = threadIdx.x; f < nfr; f += 256) {
     double xv[KS0];
 #pragma unroll
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restr
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 __global__ __launch_bounds__(256) void conv0_channel_stats_kernel(const double* __restrict__ partial, int nblk, const float* __restrict__ w,
-                                                                  int C, double* __restrict__ sums) {
+                                                                  int C, double* __restrict__ sums, int T, int T0, int fold_norm) {
   __shared__ double mom[NMOM];
   const int b = blockIdx.y;
   if (threadIdx.x < NMOM) {
@@ -361,6 +378,10 @@ __global__ __launch_bounds__(256) void conv0_channel_stats_kernel(const double* 
     s1 += wk[k] * mom[k];
 #pragma unroll
     for (int k2 = k; k2 < KS0; ++k2) s2 += (k2 == k ? 1.0 : 2.0) * wk[k] * wk[k2] * mom[idx++];
+  }
+  if (fold_norm) {  // raw waveform in: the normalisation's sigma^2 rescales GroupNorm's epsilon (see NMOM above)
+    const double mu = mom[NMOM - 2] / T, sig2 = fmax(mom[NMOM - 1] / T - mu * mu, 0.0) + 1e-7;
+    s2 += (double)T0 * 1e-5 * (sig2 - 1.0);
   }
   sums[((size_t)b * C + c) * 2] = s1;
   sums[((size_t)b * C + c) * 2 + 1] = s2 > 0.0 ? s2 : 0.0;
@@ -740,7 +761,7 @@ size_t k_conv0_stats_doubles(int B, int T0, int C) {
 
 template <typename OT>
 int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const float* beta, OT* out, double* stats,
-                      int B, int T, int T0, int C, int ksize, int stride, hipStream_t st) {
+                      int B, int T, int T0, int C, int ksize, int stride, hipStream_t st, bool raw_input) {
   SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
   SSAK_REQUIRE(T0 == (T - KS0) / ST0 + 1 && T0 > 0, "conv0: T0 mismatch");
@@ -750,6 +771,7 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
   double* sums = stats;
   double* partial = stats + (size_t)B * 2 * C;
   static const bool direct_stats = SSAK_DEV_ENV("SSAK_CONV0_DIRECT_STATS") != nullptr;  // development: the convolution-pass statistics
+  SSAK_REQUIRE(!(raw_input && direct_stats), "conv0: the folded normalisation needs the moment statistics");
   if (direct_stats) {
     conv0_kernel<OT, false, FR_STATS><<<dim3(nblk, B), 256, 0, st>>>(x, w, gamma, beta, out, partial, nullptr, T, T0, C);
     SSAK_LAUNCH_CHECK();
@@ -758,7 +780,7 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
   } else {  // 65 input moments per utterance, then the channels' sums in closed form (NMOM <= 2 C doubles per partial slot)
     conv0_moments_kernel<<<dim3(nblk, B), 256, 0, st>>>(x, T, T0, partial);
     SSAK_LAUNCH_CHECK();
-    conv0_channel_stats_kernel<<<dim3(ssak_cdiv(C, 256), B), 256, 0, st>>>(partial, nblk, w, C, sums);
+    conv0_channel_stats_kernel<<<dim3(ssak_cdiv(C, 256), B), 256, 0, st>>>(partial, nblk, w, C, sums, T, T0, raw_input ? 1 : 0);
     SSAK_LAUNCH_CHECK();
   }
   static const bool no_mfma = SSAK_DEV_ENV("SSAK_CONV0_VALU") != nullptr;  // development: the VALU apply pass
@@ -889,7 +911,7 @@ int k_conv0_gn_gelu_bwd_t(const float* x, const float* w, const float* gamma, co
 
 #define SSAK_INSTANTIATE_CONV_KERNELS(T)                                                                                       \
   template int k_conv0_gn_gelu_t<T>(const float*, const float*, const float*, const float*, T*, double*, int, int, int, int,   \
-                                    int, int, hipStream_t);                                                                    \
+                                    int, int, hipStream_t, bool);                                                              \
   template int k_conv0_bias_t<T>(const float*, const float*, const float*, T*, int, int, int, int, int, int, hipStream_t);     \
   template int k_conv_weight_rearrange_t<T>(const float*, T*, int, int, int, hipStream_t);                                     \
   template int k_posconv_prepare_t<T>(const float*, const float*, T*, T*, float*, int, int, int, hipStream_t);                 \
@@ -908,7 +930,17 @@ extern "C" int ssak_conv0_gn_gelu(const float* x, const float* w, const float* g
   SSAK_REQUIRE(T >= KS0, "conv0_gn_gelu: T=%d shorter than the kernel", T);
   const int T0 = (T - KS0) / ST0 + 1;
   SSAK_REQUIRE(workspace_bytes >= k_conv0_stats_doubles(B, T0, C) * sizeof(double), "conv0_gn_gelu: workspace too small");
-  return k_conv0_gn_gelu_t<bf16>(x, w, gamma, beta, (bf16*)out_bf16, (double*)workspace, B, T, T0, C, KS0, ST0, (hipStream_t)stream);
+  return k_conv0_gn_gelu_t<bf16>(x, w, gamma, beta, (bf16*)out_bf16, (double*)workspace, B, T, T0, C, KS0, ST0, (hipStream_t)stream, false);
+}
+// the same on RAW full-length waveforms: the feature extractor's zero-mean / unit-variance normalisation (a1) folded into the
+// GroupNorm statistics (conv_frontend.hip: NMOM) -- out == ssak_conv0_gn_gelu(ssak_wave_normalize(x)) to fp32 rounding
+extern "C" int ssak_conv0_gn_gelu_raw(const float* x, const float* w, const float* gamma, const float* beta, void* out_bf16, void* workspace,
+                                      size_t workspace_bytes, int B, int T, int C, void* stream) {
+  SSAK_REQUIRE(x && w && gamma && beta && out_bf16 && workspace, "conv0_gn_gelu_raw: null pointer");
+  SSAK_REQUIRE(T >= KS0, "conv0_gn_gelu_raw: T=%d shorter than the kernel", T);
+  const int T0 = (T - KS0) / ST0 + 1;
+  SSAK_REQUIRE(workspace_bytes >= k_conv0_stats_doubles(B, T0, C) * sizeof(double), "conv0_gn_gelu_raw: workspace too small");
+  return k_conv0_gn_gelu_t<bf16>(x, w, gamma, beta, (bf16*)out_bf16, (double*)workspace, B, T, T0, C, KS0, ST0, (hipStream_t)stream, true);
 }
 extern "C" size_t ssak_conv0_workspace_bytes(int B, int T, int C) {
   if (T < KS0) return 0;

@@ -113,7 +113,7 @@ int k_colsum(const bf16* X, long ld, int M, int N, float* out, hipStream_t st, f
 size_t k_conv0_stats_doubles(int B, int T0, int C);
 template <typename T>
 int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const float* beta, T* out, double* stats,
-                      int B, int Tn, int T0, int C, int ksize, int stride, hipStream_t st);
+                      int B, int Tn, int T0, int C, int ksize, int stride, hipStream_t st, bool raw_input = false);
 // dw [C][ksize] += sum over frames of d[b,t,c] * x[b, stride*t + k] (conv0 weight gradient of the layer-norm feature encoder,
 // Cin = 1); scratch >= k_conv0_wgrad_scratch_floats() floats; deterministic (per-workgroup partials, fixed-order sum)
 size_t k_conv0_wgrad_scratch_floats(int B, int C, int ksize);

@@ -123,6 +123,7 @@ struct ssak_w2v2 {
   hipEvent_t params_ready = nullptr, stall_begin = nullptr, stall_end = nullptr;
   // per-handle execution options (ssak_w2v2_set_option)
   int dynamic_tiles = 0;
+  int raw_input = 0;  // SSAK_W2V2_OPT_RAW_INPUT: input_values are raw full-length waveforms (group-norm feature encoder, frozen)
   int attn_bwd_mode = SSAK_ATTN_BWD_DEFAULT;
   int posconv_direct = 1;
   int fragment_weights = 0;
@@ -836,6 +837,9 @@ extern "C" int ssak_w2v2_set_option(ssak_w2v2* e, int option, int value) {
     e->fragment_weights = value ? 1 : 0;
   } else if (option == SSAK_W2V2_OPT_TRANSPOSED_WEIGHTS) {
     e->transposed_weights = value ? 1 : 0;
+  } else if (option == SSAK_W2V2_OPT_RAW_INPUT) {
+    SSAK_REQUIRE(!value || (e->cfg.arch == 0 && e->cfg.feat_extract_norm == 0), "w2v2_set_option: raw input is folded into the GroupNorm of the wav2vec2 group-norm feature encoder only");
+    e->raw_input = value ? 1 : 0;
   } else {
     ssak_set_error("w2v2_set_option: unknown option %d", option);
     return SSAK_ERR_INVALID;
@@ -1045,10 +1049,11 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
 
   // ---- a3: feature encoder (frozen: forward only)
   const bool ln_fe = c.feat_extract_norm == 1;
+  SSAK_REQUIRE(!(e->raw_input && p.fe_train), "w2v2_forward: raw input (normalisation folded into conv0's GroupNorm) needs the frozen feature encoder");
   if (!ln_fe) {
     TRY(k_conv0_gn_gelu_t<AT>(input_values, P + e->p_conv_w[0], P + e->p_cln_w[0], P + e->p_cln_b[0],
                         p.fe_train ? BF(p.act[0]) : BF(p.bufA), (double*)(ws + p.stats0), B, T, p.Tl[0], c.conv_dim[0],
-                        c.conv_kernel[0], c.conv_stride[0], st));
+                        c.conv_kernel[0], c.conv_stride[0], st, e->raw_input != 0));
   } else {
     // layer-norm variant (XLSR, modeling_wav2vec2.py:275-299): conv + bias -> LayerNorm over channels -> GELU
     // (--no_freeze keeps the pre-LayerNorm conv output and the statistics of every layer for the backward)

@@ -84,6 +84,7 @@ def _load():
         "ssak_gemm_uses_fragments": (i32, [C.POINTER(GemmDesc)]),
         "ssak_conv0_workspace_bytes": (sz, [i32, i32, i32]),
         "ssak_conv0_gn_gelu": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+        "ssak_conv0_gn_gelu_raw": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
         "ssak_prof_enable": (i32, [vp, i32]),
         "ssak_prof_enable_slots": (i32, [vp, C.POINTER(C.c_int32), i32]),
         "ssak_prof_collect": (i32, [vp, C.POINTER(ProfEntry), i32]),
@@ -382,15 +383,17 @@ def prof_collect():
     return [(arr[i].name.decode(), arr[i].launches, arr[i].total_ms, arr[i].total_flops, BOUNDS[arr[i].bound]) for i in range(n)]
 
 
-def conv0_gn_gelu(x: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
-    """x [B, T] fp32, w [C, 10], gamma / beta [C] -> [B, T0, C] bf16 (conv k=10 s=5 -> GroupNorm per channel -> GELU)."""
+def conv0_gn_gelu(x: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, raw: bool = False):
+    """x [B, T] fp32, w [C, 10], gamma / beta [C] -> [B, T0, C] bf16 (conv k=10 s=5 -> GroupNorm per channel -> GELU).  ``raw``:
+    x are RAW full-length waveforms, the zero-mean / unit-variance normalisation folded into the GroupNorm statistics."""
     B, T = x.shape
     C = w.shape[0]
     T0 = (T - 10) // 5 + 1
     out = torch.full((B, T0, C), float("nan"), dtype=torch.bfloat16, device=x.device)
     nb = lib.ssak_conv0_workspace_bytes(B, T, C)
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
-    check(lib.ssak_conv0_gn_gelu(ptr(x), ptr(w.contiguous()), ptr(gamma), ptr(beta), ptr(out), ptr(ws), nb, B, T, C, stream()))
+    fn = lib.ssak_conv0_gn_gelu_raw if raw else lib.ssak_conv0_gn_gelu
+    check(fn(ptr(x), ptr(w.contiguous()), ptr(gamma), ptr(beta), ptr(out), ptr(ws), nb, B, T, C, stream()))
     return out
 
 
@@ -407,6 +410,7 @@ def attention_fwd(qkv: torch.Tensor, B: int, F: int, nh: int, klens=None, drop_p
 
 ATTN_BWD_DEFAULT, ATTN_BWD_TWO_KERNEL = 0, 1
 W2V2_OPT_DYNAMIC_TILES, W2V2_OPT_ATTENTION_BWD, W2V2_OPT_POSCONV_DIRECT, W2V2_OPT_FRAGMENT_WEIGHTS, W2V2_OPT_TRANSPOSED_WEIGHTS = 1, 2, 3, 4, 5
+W2V2_OPT_RAW_INPUT = 6
 
 
 def attention_bwd(qkv, ctx, lse, dctx, B: int, F: int, nh: int, klens=None, drop_p=0.0, seed=0, stream_id=0,

@@ -117,6 +117,11 @@ class Wav2Vec2ForCTC:
             hip.check(n)
         return [(off[i], cnt[i]) for i in range(n)]
 
+    def can_fold_normalisation(self) -> bool:
+        """True when the waveform normalisation (a1) can ride in conv0's GroupNorm statistics instead of its own pass: the wav2vec2
+        group-norm feature encoder, frozen (the caller still has to pass full-length, unpadded utterances)."""
+        return getattr(self._c, "arch", 0) == 0 and self.config.feat_extract_norm == "group" and bool(self._c.freeze_feature_encoder)
+
     def announced_grad_ranges(self):
         """The (offset, count) sequence this model's backward announces (its own engine configuration, Whisper included)."""
         off, cnt = (C.c_long * 128)(), (C.c_long * 128)()
@@ -128,6 +133,7 @@ class Wav2Vec2ForCTC:
     def _finish_init(self, c, seed):
         config = self.config
         self._seed = seed
+        self._raw_input = False  # SSAK_W2V2_OPT_RAW_INPUT as last set by forward()
         self._c = c
         h = C.c_void_p()
         hip.check(hip.lib.ssak_w2v2_create(C.byref(c), C.byref(h)))
@@ -243,8 +249,8 @@ class Wav2Vec2ForCTC:
         return self._ws
 
     def __call__(self, input_values, attention_mask=None, labels=None, mask_time_indices=None, layer_keep=None,
-                 lengths=None, dropout_seed=None):
-        return self.forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths, dropout_seed)
+                 lengths=None, dropout_seed=None, **kw):
+        return self.forward(input_values, attention_mask, labels, mask_time_indices, layer_keep, lengths, dropout_seed, **kw)
 
     def _prelude(self, input_values, attention_mask, mask_time_indices, layer_keep, lengths, training, dropout_seed=None):
         """Everything before the engine call: device copies, workspace, the host-drawn SpecAugment spans / LayerDrop
@@ -300,9 +306,16 @@ class Wav2Vec2ForCTC:
 
     def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, mask_time_indices=None, layer_keep=None, lengths=None,
-                dropout_seed: Optional[int] = None):
+                dropout_seed: Optional[int] = None, raw_input: bool = False):
+        """``raw_input``: ``input_values`` are RAW full-length waveforms (no padding inside the batch); the feature extractor's
+        normalisation is folded into the first conv layer's GroupNorm (``can_fold_normalisation()``; SSAK_W2V2_OPT_RAW_INPUT)."""
         cfg = self.config
         training = self.training
+        if bool(raw_input) != self._raw_input:
+            if raw_input and not self.can_fold_normalisation():
+                raise ValueError("raw_input needs the group-norm feature encoder, frozen")
+            self.set_option(hip.W2V2_OPT_RAW_INPUT, int(bool(raw_input)))
+            self._raw_input = bool(raw_input)
         if labels is not None:
             labels = torch.as_tensor(labels)
             # the reference checks labels.max() on every call, which forces a device sync when the labels live on

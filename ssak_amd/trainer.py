@@ -171,6 +171,7 @@ class Trainer:
         self.normalize_on_device = normalize_on_device
         # group-norm ("base") models run without attention mask, layer-norm (XLSR) models with it
         self.use_mask = model.config.feat_extract_norm == "layer"
+        self._fold_norm = hasattr(model, "can_fold_normalisation") and model.can_fold_normalisation() and os.environ.get("SSAK_FOLD_NORM", "1") != "0"
         if self.dist and self.world > 1 and per_rank_seed:
             # independent replicas draw independent regularisers: dropout masks, SpecAugment spans and LayerDrop decisions
             # come from seed + rank (identical seeds would apply one mask pattern to every shard of the global batch)
@@ -333,8 +334,12 @@ class Trainer:
                 raise ValueError("train_step: empty batch")
             loss = self._empty_step()
         else:
-            x = hip.wave_normalize(waves, lengths) if raw else waves
-            out = m(x, lengths=lengths if self.use_mask else None, labels=labels)
+            # raw full-length utterances into the group-norm model: the normalisation (a1) rides in conv0's GroupNorm statistics,
+            # no pass of its own (model.can_fold_normalisation; ragged batches -- lengths given -- and the layer-norm topology
+            # keep ssak_wave_normalize)
+            fold = raw and lengths is None and self._fold_norm
+            x = waves if (fold or not raw) else hip.wave_normalize(waves, lengths)
+            out = m(x, lengths=lengths if self.use_mask else None, labels=labels, **({"raw_input": True} if fold else {}))
             m.backward(grad_scale=scale)  # with a process group: announces finished gradient ranges -> bucketed all-reduces overlap it
             loss = out.loss
         if self.opt_stream is None:

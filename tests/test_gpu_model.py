@@ -70,6 +70,60 @@ def test_tiny_forward_backward_vs_hf(mods, gold):
     assert torch.equal(out2.logits, out.logits)
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_raw_input_folds_the_normalisation_into_the_feature_encoder(mods, exact):
+    """SSAK_W2V2_OPT_RAW_INPUT: the group-norm model fed RAW full-length waveforms gives the logits, loss and gradients of the
+    same model fed ssak_wave_normalize(waveforms) (the normalisation rides in conv0's GroupNorm statistics), in the bf16 engine
+    and in the fp32-exact mode; the Trainer takes that path by itself for raw full-length batches and lands on the same update
+    as with the separate pass (SSAK_FOLD_NORM=0); the layer-norm topology and an unfrozen feature encoder refuse the option."""
+    import os
+    from ssak_amd import hip
+    from ssak_amd.trainer import AdamW, Trainer
+    Wav2Vec2Config, Wav2Vec2ForCTC, R = mods
+    oc = R.W2V2Config.tiny().deterministic()
+    rng = np.random.default_rng(7)
+    raw = torch.tensor((rng.standard_normal((3, 6007)) * 0.07 + 0.01).astype(np.float32)).cuda()
+    labels = torch.tensor(R.pad_labels([list(rng.integers(1, 32, 4)) for _ in range(3)]))
+    xn = hip.wave_normalize(raw, None)
+
+    def make():
+        m = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc), exact=exact).train()
+        m.load_state_dict(R.init_params(oc, 5))
+        return m
+    a, b = make(), make()
+    oa = a(xn, labels=labels)
+    ob = b(raw, labels=labels, raw_input=True)
+    tol = 2e-5 if exact else 1e-2
+    assert rel_l2(ob.logits.cpu().numpy(), oa.logits.cpu().numpy()) < tol
+    assert abs(ob.loss.item() - oa.loss.item()) < tol * abs(oa.loss.item())
+    a.backward()
+    b.backward()
+    ga, gb = a.grads[:a.num_trainable].cpu(), b.grads[:b.num_trainable].cpu()
+    assert float((gb - ga).norm() / ga.norm()) < (1e-4 if exact else 3e-2)
+    # the same handle goes back to normalised input (evaluation does)
+    oc2 = b(xn, labels=labels)
+    assert rel_l2(oc2.logits.cpu().numpy(), oa.logits.cpu().numpy()) < (1e-6 if exact else 1e-2)
+    # the trainer folds by itself
+    ta, tb = make(), make()
+    tr_b = Trainer(tb, AdamW(tb, lr=1e-3, warmup_steps=2, total_steps=100))
+    os.environ["SSAK_FOLD_NORM"] = "0"
+    try:
+        tr_a = Trainer(ta, AdamW(ta, lr=1e-3, warmup_steps=2, total_steps=100))
+    finally:
+        del os.environ["SSAK_FOLD_NORM"]
+    assert tr_b._fold_norm and not tr_a._fold_norm
+    for _ in range(3):
+        la, lb = tr_a.train_step(raw, None, labels.cuda()), tr_b.train_step(raw, None, labels.cuda())
+    assert abs(la.item() - lb.item()) < (1e-4 if exact else 2e-2) * abs(la.item())
+    # topologies without the fold
+    xl = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, R.W2V2Config.tiny(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True).deterministic()))
+    assert not xl.can_fold_normalisation()
+    with pytest.raises(ValueError):
+        xl(raw, raw_input=True)
+    nf = Wav2Vec2ForCTC(_cfg_from_oracle(Wav2Vec2Config, oc), freeze_feature_encoder=False)
+    assert not nf.can_fold_normalisation()
+
+
 def test_tiny_ragged_lengths_vs_oracle(mods):
     """Attention mask path (lengths): padded frames zeroed, padded keys masked, CTC input lengths shortened."""
     Wav2Vec2Config, Wav2Vec2ForCTC, R = mods

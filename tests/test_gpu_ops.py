@@ -333,6 +333,37 @@ def test_conv0_groupnorm_gelu_vs_fp64(hip, B, T, C):
     assert (err <= tol).all(), float((err - tol).max())
 
 
+@pytest.mark.parametrize("B,T,C,scale", [(2, 16000, 512, 0.1), (3, 4007, 512, 0.02), (2, 160000, 512, 0.3), (1, 649, 512, 3.0), (2, 3204, 64, 0.1)])
+def test_conv0_folds_the_waveform_normalisation(hip, B, T, C, scale):
+    """ssak_conv0_gn_gelu_raw on RAW full-length waveforms == ssak_conv0_gn_gelu on the zero-mean / unit-variance normalised ones (a1,
+    transformers feature_extraction_wav2vec2.py:78-97): conv0 is linear and bias-free, so the normalisation only rescales
+    GroupNorm's epsilon (1e-5 sigma^2), taken from two extra input moments -- the train step needs no normalisation pass.
+    Amplitudes from 0.02 to 3, a DC offset, lengths whose tail lies behind the last window (T mod 5 != 0); both apply forms
+    (matrix cores at C = 512, VALU at C = 64).  Bar: one bf16 ulp of the output (the two evaluations round differently in fp32)."""
+    g = torch.Generator().manual_seed(T + C)
+    x = (torch.randn(B, T, generator=g) * scale + 0.37 * scale).cuda()
+    w = (torch.randn(C, 10, generator=g) * 0.3).cuda()
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).cuda()
+    xn = hip.wave_normalize(x, None)
+    want = hip.conv0_gn_gelu(xn, w, gamma, beta).float()
+    got = hip.conv0_gn_gelu(x, w, gamma, beta, raw=True).float()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    tol = 2.0 ** -7 * want.abs() + 2e-4
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert float((got - want).norm() / want.norm()) < 2e-3
+    # and against fp64 on the normalised input, as test_conv0_groupnorm_gelu_vs_fp64 checks the two-pass form
+    xd = x.double().cpu()
+    xnd = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-7)
+    y = torch.nn.functional.conv1d(xnd[:, None, :], w.double().cpu()[:, None, :], stride=5)
+    y = (y - y.mean(2, keepdim=True)) / torch.sqrt(y.var(2, unbiased=False, keepdim=True) + 1e-5)
+    y = y * gamma.double().cpu()[None, :, None] + beta.double().cpu()[None, :, None]
+    ref = (0.5 * y * (1.0 + torch.erf(y / 2 ** 0.5))).transpose(1, 2)
+    e64 = (got.double().cpu() - ref).abs()
+    assert bool((e64 <= 2.0 ** -7 * ref.abs() + 3e-4).all()), float(e64.max())
+
+
 # ------------------------------------------------------------------ fused attention (head_dim 64)
 def _attn_ref(qkv, B, F, nh, klens=None):
     H = qkv.shape[1] // 3
