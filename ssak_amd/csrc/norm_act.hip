@@ -176,10 +176,24 @@ struct LnBwdParams {
 // PGELU: the forward applied GELU after the affine (p.beta non-null; XLSR feature-encoder conv layers) -- a template flag so
 // that the beta registers exist only in that instantiation; DROP: any dropout site active (the column multipliers stay in
 // registers for all of a wave's rows).
-template <typename T, int NCH, int VEC, bool PGELU, bool DROP>
+// SPEC >= 0: a SPECIALISED instantiation for the encoder's hot shape -- the row divides evenly over the lanes (no per-chunk
+// bounds branch) and which outputs / dropout sites exist is a compile-time bit set (1 dy, 2 pre-dropout, 4 sum-dropout,
+// 8 post-dropout, 16 second gradient operand g2, 32 residual-stream gradient g_res) instead of ~80 scalar branches inside the
+// row loop: the generic form (SPEC = -1) spent ~600 instructions per row and lane on 12 elements, this one about half.
+template <typename T, int NCH, int VEC, bool PGELU, bool DROP, int SPEC = -1>
 __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T> p) {
   using VecT = ChunkT<T, VEC>;
   __shared__ float red[3][ROW_THREADS / 64][NCH * VEC][64];  // [dgamma|dbeta|dy sum][wave][slot][lane]
+  constexpr bool S = SPEC >= 0;
+  const bool has_dy = S ? (SPEC & 1) != 0 : p.dy != nullptr;
+  const bool d_pre = S ? (SPEC & 2) != 0 : (DROP && p.pre_thresh != 0);
+  const bool d_mid = S ? (SPEC & 4) != 0 : (DROP && p.mid_thresh != 0);
+  const bool d_post = S ? (SPEC & 8) != 0 : (DROP && p.post_thresh != 0);
+  const bool has_g2 = S ? (SPEC & 16) != 0 : p.g2 != nullptr;
+  const bool has_gres = S ? (SPEC & 32) != 0 : p.g_res != nullptr;
+  // (the residual-stream gradient is prefetched with the row's other operands unless a second gradient operand already is: all
+  // four in flight per row cost the third wave per SIMD)
+  constexpr bool PF_GRES = S && (SPEC & 32) != 0 && (SPEC & 16) == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.C / VEC;
   const int wid = blockIdx.x * (ROW_THREADS / 64) + wave;
@@ -193,16 +207,16 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
       ag[i][k] = 0.f;
       ab[i][k] = 0.f;
       ay[i][k] = 0.f;
-      gm[i][k] = (ch < nch) ? p.gamma[ch * VEC + k] : 0.f;
+      gm[i][k] = (S || ch < nch) ? p.gamma[ch * VEC + k] : 0.f;
       if (PGELU) bt[i][k] = (ch < nch) ? p.beta[ch * VEC + k] : 0.f;
     }
-    if (DROP && ch < nch) load_colmul<VEC>(cm[i], ch * VEC);
+    if (DROP && (S || ch < nch)) load_colmul<VEC>(cm[i], ch * VEC);
   }
   const uint32_t thi_pre = p.pre_thresh << 16, thi_mid = p.mid_thresh << 16, thi_post = p.post_thresh << 16;
   // raw operands of the row a wave works on are fetched one row ahead: a wave owns ~8 rows and every row is a dependent
   // chain load -> two wave reductions -> store, so without the prefetch the kernel ran at HBM latency, not bandwidth
   const int rstep = gridDim.x * (ROW_THREADS / 64);
-  VecT ra[NCH], rb[NCH], rx[NCH];
+  VecT ra[NCH], rb[NCH], rx[NCH], re[NCH];
   float mean_n = 0.f, rstd_n = 0.f;
   auto fetch = [&](int row) {
     mean_n = p.mean[row];
@@ -210,11 +224,12 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
-      if (ch < nch) {
+      if (S || ch < nch) {
         const size_t o = (size_t)row * p.C + ch * VEC;
         ra[i] = *reinterpret_cast<const VecT*>(p.g1 + o);
-        if (p.g2) rb[i] = *reinterpret_cast<const VecT*>(p.g2 + o);
+        if (has_g2) rb[i] = *reinterpret_cast<const VecT*>(p.g2 + o);
         rx[i] = *reinterpret_cast<const VecT*>(p.r + o);
+        if (PF_GRES) re[i] = *reinterpret_cast<const VecT*>(p.g_res + o);
       }
     }
   };
@@ -223,18 +238,19 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
     const float mean = mean_n, rstd = rstd_n;
     uint32_t rk_pre = 1u, rk_mid = 1u, rk_post = 1u;  // this row's dropout keys (common.h), one hash per active site
     if (DROP) {
-      if (p.pre_thresh) rk_pre = drop_rowkey(p.seed, p.pre_stream, (uint64_t)row);
-      if (p.mid_thresh) rk_mid = drop_rowkey(p.seed, p.mid_stream, (uint64_t)row);
-      if (p.post_thresh) rk_post = drop_rowkey(p.seed, p.post_stream, (uint64_t)row);
+      if (d_pre) rk_pre = drop_rowkey(p.seed, p.pre_stream, (uint64_t)row);
+      if (d_mid) rk_mid = drop_rowkey(p.seed, p.mid_stream, (uint64_t)row);
+      if (d_post) rk_post = drop_rowkey(p.seed, p.post_stream, (uint64_t)row);
     }
     float dyv[NCH][VEC], xh[NCH][VEC];
     float s1 = 0.f, s2 = 0.f;
-    VecT ca[NCH], cb[NCH], cx[NCH];
+    VecT ca[NCH], cb[NCH], cx[NCH], ce[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       ca[i] = ra[i];
       cb[i] = rb[i];
       cx[i] = rx[i];
+      ce[i] = re[i];
     }
     if (row + rstep < p.M) fetch(row + rstep);
 #pragma unroll
@@ -245,10 +261,10 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
         dyv[i][k] = 0.f;
         xh[i][k] = 0.f;
       }
-      if (ch < nch) {
+      if (S || ch < nch) {
         float a[VEC], x[VEC];
         chunk_to_f(ca[i], a);
-        if (p.g2) {
+        if (has_g2) {
           float b2[VEC];
           chunk_to_f(cb[i], b2);
 #pragma unroll
@@ -257,9 +273,9 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
         chunk_to_f(cx[i], x);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          if (DROP && p.post_thresh) a[k] = drop_keep(rk_post, cm[i][k], thi_post) ? a[k] * p.post_scale : 0.f;
+          if (d_post) a[k] = drop_keep(rk_post, cm[DROP ? i : 0][k], thi_post) ? a[k] * p.post_scale : 0.f;
           xh[i][k] = (x[k] - mean) * rstd;
-          if (PGELU) a[k] *= gelu_grad_s<T>(fmaf(xh[i][k], gm[i][k], bt[i][k]));
+          if (PGELU) a[k] *= gelu_grad_s<T>(fmaf(xh[i][k], gm[i][k], bt[PGELU ? i : 0][k]));
           ag[i][k] += a[k] * xh[i][k];
           ab[i][k] += a[k];
           dyv[i][k] = a[k] * gm[i][k];
@@ -273,26 +289,27 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = lane + 64 * i;
-      if (ch < nch) {
+      if (S || ch < nch) {
         const size_t o = (size_t)row * p.C + ch * VEC;
         float d[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) d[k] = rstd * (dyv[i][k] - s1 - xh[i][k] * s2);
-        if (p.g_res) {
+        if (has_gres) {
           float e[VEC];
-          chunk_to_f(*reinterpret_cast<const VecT*>(p.g_res + o), e);
+          if (PF_GRES) chunk_to_f(ce[i], e);
+          else chunk_to_f(*reinterpret_cast<const VecT*>(p.g_res + o), e);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) d[k] += e[k];
         }
-        if (DROP && p.mid_thresh) {
+        if (d_mid) {
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) d[k] = drop_keep(rk_mid, cm[i][k], thi_mid) ? d[k] * p.mid_scale : 0.f;
+          for (int k = 0; k < VEC; ++k) d[k] = drop_keep(rk_mid, cm[DROP ? i : 0][k], thi_mid) ? d[k] * p.mid_scale : 0.f;
         }
         *reinterpret_cast<VecT*>(p.dr + o) = f_to_chunk<T, VEC>(d);
-        if (p.dy) {
+        if (has_dy) {
 #pragma unroll
           for (int k = 0; k < VEC; ++k) {
-            d[k] = (!(DROP && p.pre_thresh) || drop_keep(rk_pre, cm[i][k], thi_pre)) ? d[k] * p.pre_scale : 0.f;
+            d[k] = (!d_pre || drop_keep(rk_pre, cm[DROP ? i : 0][k], thi_pre)) ? d[k] * p.pre_scale : 0.f;
             ay[i][k] += d[k];  // fp32 values, before the rounding of the store
           }
           *reinterpret_cast<VecT*>(p.dy + o) = f_to_chunk<T, VEC>(d);
@@ -681,6 +698,32 @@ int k_layernorm_bwd_t(const T* g1, const T* g2, const T* r, const float* mean, c
     else if (drop) ln_bwd_kernel<T, N_, V_, false, true><<<grid, ROW_THREADS, 0, st>>>(p);                 \
     else ln_bwd_kernel<T, N_, V_, false, false><<<grid, ROW_THREADS, 0, st>>>(p);                          \
   } while (0)
+  // the encoder's hot shapes (H = 768: three chunks of 4 per lane; H = 1024: two chunks of 8), bf16 engine, no post-GELU: specialised
+  // instantiations by (dy, pre-, sum-, post-dropout, g2, g_res) -- every combination the engine's backward launches
+  if constexpr (std::is_same<T, bf16>::value) {
+    if (!post_gelu_beta && (C == 768 || C == 1024)) {
+      const int spec = (dy ? 1 : 0) | (p.pre_thresh ? 2 : 0) | (p.mid_thresh ? 4 : 0) | (p.post_thresh ? 8 : 0) | (g2 ? 16 : 0) | (g_res ? 32 : 0);
+      bool done = true;
+#define LN_BWD_SPEC(SP)                                                                                              \
+  case SP:                                                                                                           \
+    if (C == 768) ln_bwd_kernel<T, 3, 4, false, ((SP) & 14) != 0, SP><<<grid, ROW_THREADS, 0, st>>>(p);              \
+    else ln_bwd_kernel<T, 2, 8, false, ((SP) & 14) != 0, SP><<<grid, ROW_THREADS, 0, st>>>(p);                       \
+    break;
+      switch (spec) {
+        LN_BWD_SPEC(0) LN_BWD_SPEC(16) LN_BWD_SPEC(32) LN_BWD_SPEC(48)        // plain / g2 / g_res / both (no dy, no dropout)
+        LN_BWD_SPEC(1) LN_BWD_SPEC(17) LN_BWD_SPEC(33) LN_BWD_SPEC(49)        // + dy (hidden dropout off)
+        LN_BWD_SPEC(3) LN_BWD_SPEC(19) LN_BWD_SPEC(35) LN_BWD_SPEC(51)        // + dy with the hidden dropout
+        LN_BWD_SPEC(8) LN_BWD_SPEC(24)                                        // encoder-input dropout behind the LN (post)
+        LN_BWD_SPEC(36) LN_BWD_SPEC(52)                                       // encoder-input dropout on the sum (stable-LN)
+        default: done = false;
+      }
+#undef LN_BWD_SPEC
+      if (done) {
+        SSAK_LAUNCH_CHECK();
+        goto launched;
+      }
+    }
+  }
   if (C % 256 == 0 && C / 256 == 3 && (C / 8) % 64 != 0)  // (768: three chunks of 4 per lane, every lane busy)
     LN_BWD_LAUNCH(3, 4);
   else if (nch == 1)
@@ -691,6 +734,7 @@ int k_layernorm_bwd_t(const T* g1, const T* g2, const T* r, const float* mean, c
     LN_BWD_LAUNCH(3, 8);
 #undef LN_BWD_LAUNCH
   SSAK_LAUNCH_CHECK();
+launched:
   if (g_reduce_sink && g_reduce_sink->n + 3 <= ReduceSink::CAP) {  // second stage queued: one launch for many (kernels.h)
     g_reduce_sink->push(partial, 3L * C, grid, C, dgamma);
     g_reduce_sink->push(partial + C, 3L * C, grid, C, dbeta);
