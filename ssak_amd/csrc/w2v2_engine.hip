@@ -123,6 +123,7 @@ struct ssak_w2v2 {
   hipEvent_t params_ready = nullptr, stall_begin = nullptr, stall_end = nullptr;
   // per-handle execution options (ssak_w2v2_set_option)
   int dynamic_tiles = 0;
+  size_t xin[65] = {0};  // workspace offset of the INPUT of layer l (x[l]; a LayerDrop-skipped post-LN layer passes its input on: no copy)
   int raw_input = 0;  // SSAK_W2V2_OPT_RAW_INPUT: input_values are raw full-length waveforms (group-norm feature encoder, frozen)
   int attn_bwd_mode = SSAK_ATTN_BWD_DEFAULT;
   int posconv_direct = 1;
@@ -1136,6 +1137,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
     if (tr && e->transposed_weights && c.hidden_size % 256 == 0 && c.intermediate_size % 256 == 0) TRY(refresh_weight_transposes(e, layer_keep, st));
   }
   e->hres.assign(c.num_layers + 1, p.h1);
+  e->xin[0] = p.x[0];
   const float scale = 1.f / sqrtf((float)hd);
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerP& L = e->lp[l];
@@ -1147,17 +1149,20 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
     if (tr && layer_keep && !layer_keep[l]) {
       e->keep[l] = 0;
       if (!stable) {
-        // skipped layer: output = input (modeling_wav2vec2.py:701-712)
-        SSAK_HIP(hipMemcpyAsync(BF(p.x[l + 1]), BF(p.x[l]), (size_t)M * H * sizeof(AT), hipMemcpyDeviceToDevice, st));
+        // skipped layer: output = input (modeling_wav2vec2.py:701-712) -- the next layer reads this layer's input where it lies
+        // (it used to be a 24.5 MB device copy per dropped layer)
+        e->xin[l + 1] = e->xin[l];
       } else {
         // the residual stream passes through; the next LayerNorm still has to be applied to it
         TRY(k_layernorm_fwd_t<AT>(BF(e->hres[l]), nullptr, nxt_w, nxt_b, nullptr, BF(p.x[l + 1]), stl + 2 * M, stl + 3 * M, M, H,
                             c.layer_norm_eps, none, none, st));
         e->hres[l + 1] = e->hres[l];
+        e->xin[l + 1] = p.x[l + 1];
       }
       continue;
     }
-    const AT* x = BF(p.x[l]);
+    const AT* x = BF(e->xin[l]);
+    e->xin[l + 1] = p.x[l + 1];
     AT* qkv = BF(lb.qkv);
     TRY(GemmX<EXACT>(M, 3 * H, H).a(x, H).b(W + L.wqkv, H).bfrag(e->frag(l, 0)).c(qkv, 3 * H).with_bias(P + L.bqkv).run(st));
     if (p.fused_attn) {
@@ -1196,7 +1201,7 @@ static int forward_impl(ssak_w2v2* e, const float* input_values, const int32_t* 
     }
   }
   // ---- a8: final dropout + lm_head -> fp32 logits
-  const AT* xl = BF(p.x[c.num_layers]);
+  const AT* xl = BF(e->xin[c.num_layers]);
   if (hidden) {
     SSAK_REQUIRE(!EXACT, "w2v2_forward_hidden: the hidden-state interface is bf16 (not built for the fp32-exact mode)");
     SSAK_HIP(hipMemcpyAsync(hidden, xl, (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
@@ -1303,7 +1308,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       dlog = const_cast<float*>(dlogits);  // the CTC gradient is consumed in fp32 as it is
     else
       TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
-    const AT* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(p.x[c.num_layers]);
+    const AT* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(e->xin[c.num_layers]);
     TRY(GemmX<EXACT>(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
     TRY(k_colsum_t<AT>(dlog, V, M, V, Gd + e->p_lm_b, st, FP(p.lnpart), cs_floats));
   }
@@ -1490,7 +1495,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       TRY(GemmX<EXACT>(F, hd, F).a(BF(p.dSb), Fp, true).b(qkv, 3 * H, true).c(dqkv + H, 3 * H).alpha(scale)
               .batch(B, nh, sp1, sp2, sq1, hd, sq1, hd).run(st));  // dK = scale dS^T Q
     }
-    TRY(wq_push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(p.x[l]), H, true).c(Gd + L.wqkv, H, true), set));
+    TRY(wq_push(GemmX<EXACT>(3 * H, H, M).a(dqkv, 3 * H, true).b(BF(e->xin[l]), H, true).c(Gd + L.wqkv, H, true), set));
     if (!qkv_fused_floats) TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
     TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b_wt(EXACT ? nullptr : e->wt(l, 0), 3 * H, W + L.wqkv, H).bfrag(e->wt(l, 0) ? nullptr : e->frag(l, 3)).c(dX, H).run(st));
     wq.ann_off[wq.n_ann] = L.wqkv;
