@@ -150,17 +150,11 @@ __device__ __forceinline__ bf16x8 frag_cols_perm_d(const char* tile, int ci, int
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// (as vector conversions: element-by-element casts compiled to one v_cvt_pk_bf16_f32 PER ELEMENT plus a v_perm_b32 per pair --
+// 48 instructions per 32 score elements where 16 do)
 __device__ __forceinline__ bf16x8 pack_p(const f32x4& a, const f32x4& b) {
-  bf16x8 r;
-  r[0] = (bf16)a[0];
-  r[1] = (bf16)a[1];
-  r[2] = (bf16)a[2];
-  r[3] = (bf16)a[3];
-  r[4] = (bf16)b[0];
-  r[5] = (bf16)b[1];
-  r[6] = (bf16)b[2];
-  r[7] = (bf16)b[3];
-  return r;
+  const bf16x4 lo = __builtin_convertvector(a, bf16x4), hi = __builtin_convertvector(b, bf16x4);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 __device__ __forceinline__ bf16x8 load_row_frag(const bf16* base, long ld, int row, int nrows, int kk, int lane) {
@@ -217,7 +211,9 @@ __device__ __forceinline__ void bias_partial(float (&cs)[NS][4][4], char* smem, 
         cs[s][i][r] = v;
       }
   float* red = reinterpret_cast<float*>(smem);  // [set][wave][64 d]
-  __syncthreads();
+  // raw barriers with an LDS-only wait: __syncthreads() is also a fence, i.e. `s_waitcnt vmcnt(0)` -- every wave sat out the
+  // round trip of the output rows it had just stored (4 us per kernel: the bias sums cost 8 us per layer, measured standalone)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if ((lane & 15) == 0) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -225,7 +221,7 @@ __device__ __forceinline__ void bias_partial(float (&cs)[NS][4][4], char* smem, 
       for (int i = 0; i < 4; ++i)
         *reinterpret_cast<f32x4*>(red + (s * 4 + wave) * HD + 16 * i + 4 * (lane >> 4)) = (f32x4){cs[s][i][0], cs[s][i][1], cs[s][i][2], cs[s][i][3]};
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (wave < NS) {  // wave s adds up set s
     const float* rs = red + wave * 4 * HD;
     dst[wave * set_stride + lane] = (rs[lane] + rs[HD + lane]) + (rs[2 * HD + lane] + rs[3 * HD + lane]);
@@ -323,12 +319,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int qs = 0; qs < NQS; ++qs) {
       if (edge) {
-        const int klo = opaque_s(kl);
+        const int tl = opaque_s(kl) - k0 - 4 * g;  // keys 16 ks + r of this lane's column at or beyond it are padding
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (k0 + 16 * ks + 4 * g + r >= klo) s[qs][ks][r] = -INFINITY;
+            if (16 * ks + r >= tl) s[qs][ks][r] = -INFINITY;
       }
       float mx = max3_nc(s[qs][0][0], s[qs][0][1], s[qs][0][2]);
       mx = max3_nc(mx, s[qs][0][3], s[qs][1][0]);
@@ -511,14 +507,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
           }
         }
         if (edge) {  // keys beyond the key length: -inf before the exponent (only the tile that crosses it pays)
-          const int klo = opaque_s(kl);
+          const int tl = opaque_s(kl) - k0 - 4 * g;
 #pragma unroll
           for (int qs = 0; qs < NQS; ++qs)
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                if (k0 + 16 * (2 * t2 + kh) + 4 * g + r >= klo) s[qs][kh][r] = -INFINITY;
+                if (16 * (2 * t2 + kh) + r >= tl) s[qs][kh][r] = -INFINITY;
         }
         u32x4_t cm[2];  // multipliers of this lane's keys of this half (shared by the query sub-tiles)
         if (DROP) {
@@ -586,7 +582,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 //   S[q][key] = Q K^T (query on the accumulator row, key on the lane), dP[q][key] = dO V^T,
 //   Pd = P * mask/(1-p), dS = P * (dP * mask/(1-p) - delta[q]) * scale,
 //   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key].
-template <bool DROP, int NKS>
+// MASK: key-padding lengths are given (ragged batch).  Without them no key needs masking HERE: the key is on the lane, a key
+// beyond F only feeds its own dK / dV rows, which are not stored -- and the S accumulators start from the constant 0 instead of
+// a copy of a per-lane vector (4 v_mov per S tile, 32 per query tile and lane: a tenth of the loop's VALU).
+template <bool DROP, int NKS, bool MASK>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q dual image | dO dual image), then lse|delta|seed per stage
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -641,23 +640,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     char* s0 = smem + stage * 2 * TILE_BYTES;
     dma_tile(rs_qkv, s0, qcol, ld * 2, qt * KT, F, 2, wave, lane);
     dma_tile(rs_do, s0 + TILE_BYTES, qcol, (long)H * 2, qt * KT, F, 2, wave, lane);
+  };
+  // Per-query statistics of a tile (log-sum-exp, delta, dropout row key; threads 0..63 hold one query each) travel TWO tiles ahead
+  // in registers: loaded in front of a tile's LDS-DMA, written to LDS one iteration later.  Loaded behind the DMA and consumed at
+  // once (rounds 2-4) they made wave 0 wait `vmcnt(0)` for the tile it had just requested -- a memory round trip at the top of
+  // every iteration with nothing overlapped, and the other waves met it at the next barrier.
+  float st_l = -INFINITY, st_d = 0.f;  // RAW loaded values: any arithmetic on them here would wait for the loads on the spot
+  int st_q = 0;
+  auto load_stat = [&](int qt) {
     if (threadIdx.x < KT) {
-      const int q = qt * KT + threadIdx.x;
-      const long o = ((long)b * p.nh + h) * F + min(q, F - 1);
-      const float ls = q < F ? p.lse[o] : -INFINITY;
+      st_q = qt * KT + threadIdx.x;
+      const long o = ((long)b * p.nh + h) * F + min(st_q, F - 1);
+      st_l = p.lse[o];
+      st_d = p.delta[o];
+    }
+  };
+  auto write_stat = [&](int stage) {
+    if (threadIdx.x < KT) {
+      const float ls = st_q < F ? st_l : -INFINITY;
       // rows beyond F or without a valid key: +inf here makes P = exp2(.. - inf) = 0 without a select per element; the softmax
       // scale rides in the exponent (P' = P * scale: dS needs no multiply, dV is rescaled once at the end)
       stat[stage * 3 * KT + threadIdx.x] = ls > -INFINITY ? fmaf(ls, 1.4426950408889634f, -log2scale) : INFINITY;
-      stat[stage * 3 * KT + KT + threadIdx.x] = q < F ? p.delta[o] * inv_drop_scale : 0.f;
-      reinterpret_cast<uint32_t*>(stat)[stage * 3 * KT + 2 * KT + threadIdx.x] = drop_rowseed(p, b, h, q);
+      stat[stage * 3 * KT + KT + threadIdx.x] = st_q < F ? st_d * inv_drop_scale : 0.f;
+      reinterpret_cast<uint32_t*>(stat)[stage * 3 * KT + 2 * KT + threadIdx.x] = drop_rowseed(p, b, h, st_q);
     }
   };
+  load_stat(0);
+  write_stat(0);
+  if (nqt > 1) load_stat(1);
   issue(0, 0);
   for (int qt = 0; qt < nqt; ++qt) {
     const int cur = qt & 1;
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    if (qt + 1 < nqt) issue(qt + 1, cur ^ 1);
+    if (qt + 1 < nqt) {
+      write_stat(cur ^ 1);                 // tile qt + 1's statistics (in registers since the previous iteration)
+      if (qt + 2 < nqt) load_stat(qt + 2);  // ... and the next ones, ahead of the DMA in the memory queue
+      issue(qt + 1, cur ^ 1);
+    }
     const char* q_rows = smem + cur * 2 * TILE_BYTES;  // dual images: row reads and transposing reads from the same tile
     const char* q_tr = q_rows;
     const char* do_rows = q_rows + TILE_BYTES;
@@ -678,7 +698,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks) {
             // keys beyond the key length (a per-lane constant) start S at -3e38: exp2(-huge) = 0, no select per element
-            f32x4 a = sinit[ks], c = {0.f, 0.f, 0.f, 0.f};
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+            if (MASK) a = sinit[ks];
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks][0], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf[ks][1], a, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks][0], c, 0, 0, 0);
@@ -879,13 +900,17 @@ int k_attention_bwd(const bf16* qkv, const bf16* ctx, const float* lse, const in
   constexpr int dkv_lds = 2 * 2 * TILE_BYTES + 2 * 3 * KT * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
-    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
-    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
-    SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds));
+#define ATT_DKV_ATTR(D, N, K) SSAK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<D, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds))
+    ATT_DKV_ATTR(true, 1, true); ATT_DKV_ATTR(false, 1, true); ATT_DKV_ATTR(true, 2, true); ATT_DKV_ATTR(false, 2, true);
+    ATT_DKV_ATTR(true, 1, false); ATT_DKV_ATTR(false, 1, false); ATT_DKV_ATTR(true, 2, false); ATT_DKV_ATTR(false, 2, false);
+#undef ATT_DKV_ATTR
     attr_done = true;
   }
-#define ATT_LAUNCH_DKV(D, N) attn_bwd_dkv_kernel<D, N><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, dkv_lds, st>>>(p)
+#define ATT_LAUNCH_DKV(D, N)                                                                                        \
+  do {                                                                                                              \
+    if (klens) attn_bwd_dkv_kernel<D, N, true><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, dkv_lds, st>>>(p);        \
+    else attn_bwd_dkv_kernel<D, N, false><<<dim3(ssak_cdiv(F, 64 * N), nh, B), 256, dkv_lds, st>>>(p);             \
+  } while (0)
   if (p.thresh16) {
     if (nks == 1) ATT_LAUNCH_DKV(true, 1); else ATT_LAUNCH_DKV(true, 2);
   } else {

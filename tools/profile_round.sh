@@ -51,7 +51,9 @@ R = "${R}"
 a, b = json.load(open(f"gpurun_out/{R}_bench_b32.json")), json.load(open(f"gpurun_out/{R}_bench_b32_b.json"))
 # the committed line is the SECOND run (its roofline.traffic comes from this round's passes) with the cpu_baseline leg of the
 # first; both throughputs are listed (same build, same box, minutes apart) -- no picking
-best = dict(b, cpu_baseline=a.get("cpu_baseline"), secondary=a.get("secondary"), ingest=a.get("ingest"))
+best = dict(b, **{k: v for k, v in a.items() if k not in b})  # every side leg of the first run (cpu_baseline, secondary, ingest, online ...)
+if isinstance(best.get("online"), dict) and "value" in best["online"]:
+    best["online"]["resident_value_same_run"] = a["value"]  # vs_resident_batch was taken against the first run's own figure
 lm = [k for k in a["roofline"].get("kernels", []) if k.get("workload")]  # (the log-mel slot rides on the secondary workloads of the first run)
 best["roofline"]["kernels"] = best["roofline"].get("kernels", []) + lm
 best["runs"] = [{"value": a["value"], "ms_per_step": a["ms_per_step"]}, {"value": b["value"], "ms_per_step": b["ms_per_step"]}]
