@@ -213,7 +213,7 @@ __device__ __forceinline__ void bias_partial(float (&cs)[NS][4][4], char* smem, 
   float* red = reinterpret_cast<float*>(smem);  // [set][wave][64 d]
   // raw barriers with an LDS-only wait: __syncthreads() is also a fence, i.e. `s_waitcnt vmcnt(0)` -- every wave sat out the
   // round trip of the output rows it had just stored (4 us per kernel: the bias sums cost 8 us per layer, measured standalone)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  lds_barrier();
   if ((lane & 15) == 0) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -221,7 +221,7 @@ __device__ __forceinline__ void bias_partial(float (&cs)[NS][4][4], char* smem, 
       for (int i = 0; i < 4; ++i)
         *reinterpret_cast<f32x4*>(red + (s * 4 + wave) * HD + 16 * i + 4 * (lane >> 4)) = (f32x4){cs[s][i][0], cs[s][i][1], cs[s][i][2], cs[s][i][3]};
   }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  lds_barrier();
   if (wave < NS) {  // wave s adds up set s
     const float* rs = red + wave * 4 * HD;
     dst[wave * set_stride + lane] = (rs[lane] + rs[HD + lane]) + (rs[2 * HD + lane] + rs[3 * HD + lane]);

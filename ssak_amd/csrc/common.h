@@ -69,6 +69,10 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a memory fence: the compiler puts `s_waitcnt vmcnt(0)`
+// in front of it, so a wave with global stores (or prefetches) in flight sits out their round trip.  Where the barrier only
+// hands LDS contents from wave to wave, this is enough.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // block reductions for blockDim.x <= 1024 (<= 16 waves); `red` is >= 16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const LnBwdParams<T
       red[1][wave][i * VEC + k][lane] = ab[i][k];
       red[2][wave][i * VEC + k][lane] = ay[i][k];
     }
-  __syncthreads();
+  lds_barrier();  // (not __syncthreads(): the last rows' dr / dy stores are still in flight and nothing here reads them)
   for (int e = threadIdx.x; e < NCH * VEC * 64; e += ROW_THREADS) {
     const int slot = e >> 6, ln = e & 63;
     const int i = slot / VEC, k = slot % VEC;
