@@ -45,8 +45,8 @@ int ssak_wave_normalize(const float* in, const int32_t* lens, int B, int T, floa
  * wav [B, T] fp32 (lens [B] valid samples or NULL), padded / trimmed to n_samples (480000 = 30 s) -> mel
  * [B, 80, n_samples/160] fp32 (or NULL).  mel_cl_bf16 (or NULL): the same values as bf16 channels-last
  * [B, cl_rows, 80] written from row cl_lead (what the Whisper encoder's first conv reads; pad rows untouched).
- * tables: ssak_logmel_table_floats() floats filled once by ssak_logmel_init_tables (Hann-weighted DFT matrix + Slaney
- * mel filters, computed in double on the host). */
+ * tables: ssak_logmel_table_floats() floats, 16-byte aligned, filled once by ssak_logmel_init_tables (the FFT's twiddles, the
+ * periodic Hann window and the Slaney mel filters, computed in double on the host). */
 size_t ssak_logmel_table_floats(void);
 int ssak_logmel_init_tables(float* tables /*device*/);
 size_t ssak_logmel_workspace_bytes(int B, int n_samples);
