@@ -144,6 +144,109 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const LnFwdParams<T
   }
 }
 
+// The encoder's hot shapes (C = 768: three chunks of 4 per lane, every lane busy; C = 1024: two chunks of 8), SPECIALISED like
+// ln_bwd_kernel: which operands, outputs and dropout sites exist is a compile-time bit set (1 branch y, 2 residual, 4 pre-,
+// 8 sum-, 16 post-dropout, 32 r_out), a wave strides over rows and keeps gamma, beta and the dropout column multipliers in
+// registers for all of them (the one-row-per-wave form above reads them again for every row: 144 of its 336 bytes of loads per
+// lane and row at C = 768), and the next row's operands are fetched while this row's two wave reductions run.
+template <typename T, int NCH, int VEC, int SPEC>
+__global__ __launch_bounds__(ROW_THREADS) void ln_fwd_rows_kernel(const LnFwdParams<T> p) {
+  using VecT = ChunkT<T, VEC>;
+  constexpr bool HAS_Y = (SPEC & 1) != 0, HAS_RES = (SPEC & 2) != 0, D_PRE = (SPEC & 4) != 0, D_MID = (SPEC & 8) != 0,
+                 D_POST = (SPEC & 16) != 0, HAS_ROUT = (SPEC & 32) != 0, DROP = (SPEC & 28) != 0;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * (ROW_THREADS / 64) + (threadIdx.x >> 6);
+  const int rstep = gridDim.x * (ROW_THREADS / 64);
+  float gm[NCH][VEC], bt[NCH][VEC];
+  uint32_t cm[DROP ? NCH : 1][VEC];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (lane + 64 * i) * VEC;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) gm[i][k] = p.gamma[c0 + k], bt[i][k] = p.beta[c0 + k];
+    if (DROP) load_colmul<VEC>(cm[i], c0);
+  }
+  const uint32_t thi_pre = p.pre_thresh << 16, thi_mid = p.mid_thresh << 16, thi_post = p.post_thresh << 16;
+  const float inv_c = 1.f / (float)p.C;
+  VecT ny[NCH], nr[NCH];
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const size_t o = (size_t)row * p.C + (lane + 64 * i) * VEC;
+      if (HAS_Y) ny[i] = *reinterpret_cast<const VecT*>(p.y + o);
+      if (HAS_RES) nr[i] = *reinterpret_cast<const VecT*>(p.res + o);
+    }
+  };
+  if (wid < p.M) fetch(wid);
+  for (int row = wid; row < p.M; row += rstep) {
+    VecT cy[NCH], cr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) cy[i] = ny[i], cr[i] = nr[i];
+    if (row + rstep < p.M) fetch(row + rstep);
+    const uint32_t rk_pre = D_PRE ? drop_rowkey(p.seed, p.pre_stream, (uint64_t)row) : 1u;
+    const uint32_t rk_mid = D_MID ? drop_rowkey(p.seed, p.mid_stream, (uint64_t)row) : 1u;
+    const uint32_t rk_post = D_POST ? drop_rowkey(p.seed, p.post_stream, (uint64_t)row) : 1u;
+    float v[NCH][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const size_t o = (size_t)row * p.C + (lane + 64 * i) * VEC;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[i][k] = 0.f;
+      if (HAS_Y) {
+        chunk_to_f(cy[i], v[i]);
+        if (D_PRE) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) v[i][k] = drop_keep(rk_pre, cm[DROP ? i : 0][k], thi_pre) ? v[i][k] * p.pre_scale : 0.f;
+        }
+      }
+      if (HAS_RES) {
+        float r[VEC];
+        chunk_to_f(cr[i], r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[i][k] += r[k];
+      }
+      if (D_MID) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[i][k] = drop_keep(rk_mid, cm[DROP ? i : 0][k], thi_mid) ? v[i][k] * p.mid_scale : 0.f;
+      }
+      if (HAS_ROUT) {
+        // round through the storage type so that forward and backward see the same LN input
+        const VecT q = f_to_chunk<T, VEC>(v[i]);
+        *reinterpret_cast<VecT*>(p.r_out + o) = q;
+        chunk_to_f(q, v[i]);
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) s += v[i][k];
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float d = v[i][k] - mean;
+        q2 += d * d;
+      }
+    const float rstd = rsqrtf(wave_sum(q2) * inv_c + p.eps);
+    if (lane == 0 && p.mean) {
+      p.mean[row] = mean;
+      p.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const size_t o = (size_t)row * p.C + (lane + 64 * i) * VEC;
+      float w[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        w[k] = (v[i][k] - mean) * rstd * gm[i][k] + bt[i][k];
+        if (D_POST) w[k] = drop_keep(rk_post, cm[DROP ? i : 0][k], thi_post) ? w[k] * p.post_scale : 0.f;
+      }
+      *reinterpret_cast<VecT*>(p.out + o) = f_to_chunk<T, VEC>(w);
+    }
+  }
+}
+
 template <typename T>
 struct LnBwdParams {
   const T* g1;        // [M,C] grad wrt (post-dropout) LN output
@@ -665,6 +768,32 @@ int k_layernorm_fwd_t(const T* y, const T* res, const float* gamma, const float*
   const int grid = ssak_cdiv(M, ROW_THREADS / 64);
   const int nch = ssak_cdiv(C / 8, 64);
   ProfScope prof_scope(PROF_LN_FWD, (double)M * C * 2.0 * ((y != nullptr) + (res != nullptr) + (r_out != nullptr) + (out != nullptr)), st);
+  // the encoder's hot shapes, bf16 engine, LN output wanted, no post-GELU: specialised multi-row instantiations by (y, res, pre-,
+  // sum-, post-dropout, r_out) -- the combinations the engine's forward launches
+  if constexpr (std::is_same<T, bf16>::value) {
+    if (out && !post_gelu && (C == 768 || C == 1024)) {
+      const int spec = (y ? 1 : 0) | (res ? 2 : 0) | (p.pre_thresh ? 4 : 0) | (p.mid_thresh ? 8 : 0) | (p.post_thresh ? 16 : 0) | (r_out ? 32 : 0);
+      const int rgrid = std::min(LN_FWD_BLOCKS, grid);
+      bool done = true;
+#define LN_FWD_SPEC(SP)                                                                          \
+  case SP:                                                                                       \
+    if (C == 768) ln_fwd_rows_kernel<T, 3, 4, SP><<<rgrid, ROW_THREADS, 0, st>>>(p);             \
+    else ln_fwd_rows_kernel<T, 2, 8, SP><<<rgrid, ROW_THREADS, 0, st>>>(p);                      \
+    break;
+      switch (spec) {
+        LN_FWD_SPEC(1) LN_FWD_SPEC(2)                      // a plain LayerNorm of one operand
+        LN_FWD_SPEC(35) LN_FWD_SPEC(39)                    // r = res + [drop] y, LN(r): the encoder layers' two LayerNorms
+        LN_FWD_SPEC(17) LN_FWD_SPEC(18)                    // encoder-input dropout behind the LN
+        LN_FWD_SPEC(43) LN_FWD_SPEC(47) LN_FWD_SPEC(42)    // stable-LN: dropout on the sum
+        default: done = false;
+      }
+#undef LN_FWD_SPEC
+      if (done) {
+        SSAK_LAUNCH_CHECK();
+        return SSAK_OK;
+      }
+    }
+  }
   if (nch == 1)
     ln_fwd_kernel<T, 1><<<grid, ROW_THREADS, 0, st>>>(p);
   else if (nch == 2)

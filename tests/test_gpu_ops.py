@@ -308,6 +308,24 @@ def test_logmel_batch_ragged_and_properties(hip):
     assert (c[:, 0, :] == 9.0).all() and (c[:, 3001:, :] == 9.0).all()       # pad rows untouched
 
 
+@pytest.mark.parametrize("n_samples", [480, 1120, 1280, 7680, 24160])
+def test_logmel_window_sizes_around_the_wave_and_workgroup_shapes(hip, n_samples):
+    """The kernel gives a wave 8 frames and a workgroup 48: windows of 3, 7, 8, 48 and 151 frames (fewer than a wave's, exactly a
+    wave's, exactly a workgroup's, a ragged last workgroup), reflect padding longer than the signal's interior, lengths that end
+    inside the first frame -- all against the float64 oracle at the golden's tolerance."""
+    from oracle import logmel_ref
+    rng = np.random.default_rng(n_samples)
+    B = 3
+    t = np.arange(n_samples + 300) / 16000.0
+    x = (0.3 * np.sin(2 * np.pi * 523.0 * t)[None, :] + rng.standard_normal((B, n_samples + 300)) * 0.02).astype(np.float32)
+    lens = np.array([n_samples + 300, max(1, n_samples // 3), 5], np.int32)
+    mel = hip.logmel_whisper(_dev(x), _dev(lens), n_samples=n_samples).cpu().numpy()
+    assert mel.shape == (B, 80, n_samples // 160)
+    for b in range(B):
+        ref = logmel_ref.log_mel(x[b, :lens[b]], n_samples=n_samples)
+        assert np.abs(mel[b] - ref).max() < 2e-4, (b, np.abs(mel[b] - ref).max())
+
+
 # ------------------------------------------------------------------ conv0 + GroupNorm + GELU (a3)
 @pytest.mark.parametrize("B,T,C", [(2, 16000, 512), (3, 4007, 512), (1, 645, 512), (2, 3200, 64)])
 def test_conv0_groupnorm_gelu_vs_fp64(hip, B, T, C):
