@@ -344,12 +344,38 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restr
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Sum every moment over the wave's 64 lanes.  One butterfly per moment is 67 x 6 exchanges of a double (two ds_bpermute
+  // each: 804 per wave, and that, not the arithmetic, was the kernel -- 64 us per launch).  Instead the lanes split the LIST at
+  // every step: of c live entries a lane keeps the lower or the upper half (by the step's lane bit), sends the other half to
+  // its partner and adds what the partner sent -- 34 + 17 + 9 + 5 + 3 + 2 = 70 exchanges, after which lane L holds two complete
+  // sums, those of moments j + 2 b1 + 3 b2 + 5 b4 + 9 b8 + 17 b16 + 34 b32 (b = L's bits), j = 0, 1.
+  {
+    constexpr int CNT[7] = {NMOM, 34, 17, 9, 5, 3, 2};
+    static_assert(NMOM == 67, "the halving schedule below is written for 67 moments");
 #pragma unroll
-  for (int i = 0; i < NMOM; ++i) {
-    double v = m[i];
+    for (int s = 0; s < 6; ++s) {
+      const int off = 32 >> s, c = CNT[s], h = CNT[s + 1];
+      const bool up = (lane & off) != 0;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) red[wave][i] = v;
+      for (int i = 0; i < h; ++i) {
+        const double lo = m[i], hi = (i + h < c) ? m[i + h] : 0.0;
+        const double keep = up ? hi : lo, send = up ? lo : hi;
+        m[i] = keep + __shfl_xor(send, off);
+      }
+    }
+    // the moments this lane's m[0] and m[1] belong to; valid if every level's index is inside its list
+    bool ok0 = true, ok1 = true;
+    int i0 = 0, i1 = 1;
+#pragma unroll
+    for (int s = 5; s >= 0; --s) {
+      const int add = (lane & (32 >> s)) ? CNT[s + 1] : 0;
+      i0 += add;
+      i1 += add;
+      ok0 = ok0 && i0 < CNT[s];
+      ok1 = ok1 && i1 < CNT[s];
+    }
+    if (ok0) red[wave][i0] = m[0];
+    if (ok1) red[wave][i1] = m[1];
   }
   __syncthreads();
   if (threadIdx.x < NMOM)
