@@ -99,7 +99,7 @@ void register_classes() {
       {"softmax fwd / bwd (unfused attention fallback)", SSAK_BOUND_HBM},
       {"posconv_direct_kernel (grouped positional convolution forward / input gradient)", SSAK_BOUND_MFMA},
       {"posconv_wgrad_kernel + posconv_wgrad_sum_kernel (grouped positional convolution weight gradient)", SSAK_BOUND_MFMA},
-      {"stft_mel_kernel + logmel_finalize_kernel (Whisper log-mel features)", SSAK_BOUND_HBM},
+      {"stft_fft_mel_kernel + logmel_finalize_kernel (Whisper log-mel features)", SSAK_BOUND_HBM},
   };
   if (g_nslots == 0)
     for (int i = 0; i < PROF_CLASS_SLOTS; ++i) register_locked(kClasses[i].name, kClasses[i].bound);
