@@ -53,6 +53,18 @@ struct AttnParams {
 };
 
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+// max over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48), the result in all of them: two VALU swaps
+// (v_permlane16_swap / v_permlane32_swap of the value with a copy of itself leave {r0 r0 r2 r2 | r1 r1 r3 r3} and
+// {lo lo | hi hi}) instead of two ds_bpermute round trips through the LDS crossbar in the softmax's dependent chain
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ float max_over_lane_groups(float v) {
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  u32x2_t t = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  const float m = fmaxf(__builtin_bit_cast(float, t[0]), __builtin_bit_cast(float, t[1]));
+  const unsigned c = __builtin_bit_cast(unsigned, m);
+  t = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+  return fmaxf(__builtin_bit_cast(float, t[0]), __builtin_bit_cast(float, t[1]));
+}
 // max of three without the canonicalising v_max x, x that fmaxf puts in front of every MFMA result in IEEE mode (the scores
 // are never NaN): 8 instructions for 16 values instead of 31
 __device__ __forceinline__ float max3_nc(float a, float b, float c) {
@@ -336,8 +348,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         else
           mx = fmaxf(mx, s[qs][ks][3]);
       }
-      mx = fmaxf(mx, shfl_xor_f(mx, 16));
-      mx = fmaxf(mx, shfl_xor_f(mx, 32));
+      mx = max_over_lane_groups(mx);
       // key 0 is never masked (kl >= 1 whenever a tile is processed), so the running maximum is finite from the first tile on
       const float m_new = fmaxf(m_run[qs], mx);
       const float mc = m_new * c2;
@@ -359,10 +370,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
           s[qs][ks][r2 + 1] = e[1];
         }
       }
-      float rs = rs2[0] + rs2[1];
-      rs += shfl_xor_f(rs, 16);
-      rs += shfl_xor_f(rs, 32);
-      l_run[qs] = l_run[qs] * alpha + rs;
+      // (the row sum stays a per-lane partial over this lane's keys -- alpha is the same in the four lanes of a query -- and is
+      // added up across them once, in the epilogue)
+      l_run[qs] = l_run[qs] * alpha + (rs2[0] + rs2[1]);
       m_run[qs] = m_new;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {  // the maximum moves in the first tiles only: skip 16 multiplies otherwise
 #pragma unroll
@@ -385,10 +395,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
   for (int qs = 0; qs < NQS; ++qs) {
     const int q = qrow[qs];
+    float lsum = l_run[qs];
+    lsum += shfl_xor_f(lsum, 16);
+    lsum += shfl_xor_f(lsum, 32);
     if (q >= F) continue;
-    const float inv = l_run[qs] > 0.f ? p.drop_scale / l_run[qs] : 0.f;
+    const float inv = lsum > 0.f ? p.drop_scale / lsum : 0.f;
     if (g == 0 && p.lse)  // natural-log units of the SCALED scores, as the backward and the reference's logsumexp use them
-      p.lse[((long)b * p.nh + h) * F + q] = l_run[qs] > 0.f ? m_run[qs] * p.scale + __logf(l_run[qs]) : -INFINITY;
+      p.lse[((long)b * p.nh + h) * F + q] = lsum > 0.f ? m_run[qs] * p.scale + __logf(lsum) : -INFINITY;
     bf16* dst = p.ctx + ((long)b * F + q) * H + h * HD + 4 * g;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
