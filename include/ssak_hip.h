@@ -85,6 +85,11 @@ int ssak_ctc_greedy_decode(const float* logits, const int32_t* in_lens, int B, i
  * ssak_resample_plan / _table (host): reduced rates, filter half-width and taps; table [new_r][taps] fp32 computed in
  *   double like torchaudio's kernel.  ssak_resample_sinc: in [B, Tin] (in_lens [B] or NULL) -> out [B, Tout] with
  *   out_lens[b] = ceil(new_r * len / orig_r) valid samples (0 beyond); table on the device. */
+/* ssak_read_ranges (host): n byte ranges (path, file offset, length) read with pread by `threads` native threads into dst[i] (the
+ *   caller's slices of a pinned staging buffer).  SSAK_ERR_INVALID with the path in ssak_last_error() for a file that cannot be
+ *   opened or ends inside its range. */
+int ssak_read_ranges(const char* const* paths, const int64_t* file_offsets, const int64_t* nbytes, void* const* dst, int n,
+                     int threads);
 int ssak_pcm_to_mono_f32(const void* raw, const int64_t* byte_offsets, const int32_t* nframes, int B, int channels, int sample_width,
                          int Tmax, float* out, void* stream);
 int ssak_resample_plan(int orig_sr, int new_sr, int* orig_r, int* new_r, int* width, int* taps);

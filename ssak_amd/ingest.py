@@ -2,7 +2,7 @@
 (``ssak/utils/dataset.py:630-645`` -> ``ssak/utils/audio.py:24-154``) with everything after the file read on the GPU.
 
 The host only finds the PCM byte range of each segment (``offset = int(start * sr)``, audio.py:85-92; the WAV header is parsed
-once per file) and reader threads ``preadv`` it straight into one pinned staging buffer; one asynchronous H2D copy later the device converts to mono fp32
+once per file) and native reader threads (``ssak_read_ranges``) ``pread`` it straight into one pinned staging buffer; one asynchronous H2D copy later the device converts to mono fp32
 (``ssak_pcm_to_mono_f32``), converts the sample rate (``ssak_resample_sinc`` = torchaudio's windowed-sinc resampler) and
 normalises (``ssak_wave_normalize``, a1).  ``BatchPrefetcher`` reads the next batches on a background thread while the
 current step runs, which is what the reference's 6 dataloader workers are for (wav2vec_train.py:360).
@@ -15,7 +15,6 @@ import os
 import queue
 import struct
 import threading
-from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -123,27 +122,6 @@ def read_pcm_segment(path: str, start: Optional[float] = None, end: Optional[flo
     return raw, info.sample_rate, info.channels, info.sample_width, len(raw) // (info.channels * info.sample_width)
 
 
-def _read_into(jobs):
-    """One reader-thread task: a share of a batch's segments, each straight into its slice of the pinned staging buffer
-    (os.preadv releases the GIL; no intermediate bytes object, no numpy copy).  A task per reader, not per file: the executor's
-    per-task hand-off costs as much as reading a cached 320 KB file."""
-    for path, off, view in jobs:
-        fd = os.open(path, os.O_RDONLY)
-        try:
-            got, want = 0, len(view)
-            while got < want:
-                n = os.preadv(fd, [view[got:]], off + got)
-                if n <= 0:
-                    raise RuntimeError(f"{path}: short read ({got} of {want} bytes)")
-                got += n
-        finally:
-            os.close(fd)
-
-
-def _infos(paths):
-    return [wav_info(p) for p in paths]
-
-
 class DeviceIngest:
     """Turns lists of (path, start, end) into normalised fp32 batches on the device."""
 
@@ -153,7 +131,6 @@ class DeviceIngest:
         self.sample_rate, self.device, self.normalize = sample_rate, torch.device(device), normalize
         n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         self.readers = max(1, min(8, n_cpu) if readers is None else int(readers))
-        self._pool = ThreadPoolExecutor(max_workers=self.readers, thread_name_prefix="ssak-ingest")
         self._tables = {}
         self._stream = None  # the device part's own stream (to_device_async)
         # ring of reusable pinned staging buffers: pinning a fresh buffer per batch costs milliseconds (and the caching host
@@ -185,12 +162,7 @@ class DeviceIngest:
         to the same buffer, so that the batch's ONE H2D copy carries them too (a ``labels.to(device)`` from pageable memory on
         the compute stream blocks the host until the previous step has drained)."""
         paths = [p for p, _, _ in items]
-        if all(p in _WAV_CACHE for p in paths):
-            infos = [_WAV_CACHE[p] for p in paths]
-        else:  # first visit: the headers in parallel too (one small read per file)
-            k = self.readers
-            infos = [i for part in self._pool.map(_infos, [paths[j::k] for j in range(k)]) for i in part]
-            infos = [_WAV_CACHE[p] for p in paths]
+        infos = [_WAV_CACHE.get(p) or wav_info(p) for p in paths]  # (first visit: ~10 us per header, cheaper here than a hand-off)
         ranges = [segment_range(i, s, e) for i, (_, s, e) in zip(infos, items)]
         sizes = [cnt * i.channels * i.sample_width for i, (_, cnt) in zip(infos, ranges)]
         audio = sum(sizes)
@@ -199,17 +171,23 @@ class DeviceIngest:
         total = audio if lab is None else lab_off + lab.nbytes
         slot = self._staging(total)
         pinned = slot[0]
-        mv = memoryview(pinned.numpy())
         if lab is not None:
             pinned.numpy()[lab_off:lab_off + lab.nbytes] = lab.reshape(-1).view(np.uint8)
-        offs, pos, jobs = [], 0, []
-        for (path, _, _), (foff, _), nbytes in zip(items, ranges, sizes):
+        offs, pos = [], 0
+        for nbytes in sizes:
             offs.append(pos)
-            if nbytes:
-                jobs.append((path, foff, mv[pos:pos + nbytes]))
             pos += nbytes
-        k = min(self.readers, max(1, len(jobs)))
-        list(self._pool.map(_read_into, [jobs[j::k] for j in range(k)]))  # (list: re-raises a reader's exception here)
+        # the reads: native threads pread the ranges straight into their slices of the pinned buffer (ssak_read_ranges; the
+        # interpreter lock is released for the call)
+        n, base = len(items), pinned.data_ptr()
+        c_paths = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        c_foff = (C.c_int64 * n)(*[foff for foff, _ in ranges])
+        c_size = (C.c_int64 * n)(*sizes)
+        c_dst = (C.c_void_p * n)(*[base + o for o in offs])
+        try:
+            hip.check(hip.lib.ssak_read_ranges(c_paths, c_foff, c_size, c_dst, n, self.readers))
+        except ValueError as err:  # an unreadable or truncated file: what the reference's loader raises (audio.py:49-55)
+            raise RuntimeError(str(err)) from None
         meta = [(i.sample_rate, i.channels, i.sample_width, cnt) for i, (_, cnt) in zip(infos, ranges)]
         return (pinned[:max(total, 1)], slot), offs, meta, (None if lab is None else (lab_off, lab.shape))
 

@@ -266,7 +266,7 @@ def online_steps(B=32, steps=20, warmup=5, n_files=4096, device="cuda:0", keep_d
         shutil.rmtree(d, ignore_errors=True)
     del model, trainer
     return {"path": f"Kaldi folder of {n_files} x 10 s PCM16 WAV files -> load_kaldi -> length-grouped batches of {B} -> BatchPrefetcher "
-                    f"({ingest.readers} reader threads, preadv into a pinned ring, one H2D copy per batch) -> device decode + normalise -> "
+                    f"({ingest.readers} native reader threads (ssak_read_ranges: pread into a pinned ring), one H2D copy per batch) -> device decode + normalise -> "
                     "the headline train step (the loop of `ssak_amd.train --online`)",
             "value": round(n / dt, 2), "unit": "utterances/sec", "steps": len(plan) - warmup, "warmup": warmup, "ms_per_step": round(dt / (len(plan) - warmup) * 1e3, 3),
             "batch": B, "folder_written_in_s": round(t_gen, 1), "final_loss": round(float(loss.item()), 4)}
@@ -305,6 +305,6 @@ def ingest_rate(N=1024, sr=16000, nch=1, B=32):
         os.unlink(p)
     os.rmdir(d)
     return {"path": "Kaldi-style wav.scp entries -> PCM16 WAV read -> device decode / mono / resample -> ssak_wave_normalize -> batches of "
-                    f"{B} (ssak_amd/ingest.py: {readers} reader threads preadv into a pinned ring, prefetch depth 3)",
+                    f"{B} (ssak_amd/ingest.py: {readers} native reader threads pread into a pinned ring (ssak_read_ranges), prefetch depth 3)",
             "utterances_per_sec": round(N / dt, 1), "files": N, "reader_threads": readers,
             "source": f"{sr} Hz x {nch} ch, 10 s"}
