@@ -8,6 +8,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -53,7 +54,10 @@ extern "C" int ssak_read_ranges(const char* const* paths, const int64_t* file_of
   } else {
     std::vector<std::thread> pool;
     pool.reserve(T - 1);
-    for (int t = 1; t < T; ++t) pool.emplace_back(work);
+    try {
+      for (int t = 1; t < T; ++t) pool.emplace_back(work);
+    } catch (...) {  // no more threads to be had: the ones that started (and this one) take all the ranges
+    }
     work();
     for (auto& th : pool) th.join();
   }

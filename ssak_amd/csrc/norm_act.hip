@@ -771,7 +771,7 @@ int k_layernorm_fwd_t(const T* y, const T* res, const float* gamma, const float*
   // the encoder's hot shapes, bf16 engine, LN output wanted, no post-GELU: specialised multi-row instantiations by (y, res, pre-,
   // sum-, post-dropout, r_out) -- the combinations the engine's forward launches
   if constexpr (std::is_same<T, bf16>::value) {
-    if (out && !post_gelu && (C == 768 || C == 1024)) {
+    if (out && gamma && beta && !post_gelu && (C == 768 || C == 1024)) {
       const int spec = (y ? 1 : 0) | (res ? 2 : 0) | (p.pre_thresh ? 4 : 0) | (p.mid_thresh ? 8 : 0) | (p.post_thresh ? 16 : 0) | (r_out ? 32 : 0);
       const int rgrid = std::min(LN_FWD_BLOCKS, grid);
       bool done = true;
