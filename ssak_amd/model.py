@@ -156,6 +156,7 @@ class Wav2Vec2ForCTC:
         self._ws_key = None
         self.train_forwards = 0
         self.kept_layers = 0
+        self.last_layer_keep = None
         self.reseed(seed)
         self._last = None
         self._pinned_mask = {}
@@ -295,6 +296,7 @@ class Wav2Vec2ForCTC:
         if layer_keep is not None:
             keep_arr = (C.c_uint8 * cfg.num_hidden_layers)(*[int(bool(k)) for k in layer_keep])
         if training:  # LayerDrop bookkeeping (benchmarks price the step by the layers that actually ran)
+            self.last_layer_keep = None if layer_keep is None else [bool(k) for k in layer_keep]  # (AdamW(skip_unused_layers=True) reads it)
             self.train_forwards += 1
             self.kept_layers += cfg.num_hidden_layers if layer_keep is None else int(sum(bool(k) for k in layer_keep))
         self._step_seed = (int(self._step_seed) * 6364136223846793005 + 1442695040888963407) % (1 << 64)

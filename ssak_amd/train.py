@@ -119,6 +119,10 @@ def build_parser():
     p.add_argument("--batch_audio", type=float, default=None,
                    help="(extension, not a flag of the reference) seconds of PADDED audio per step: length-grouped batches of a constant "
                         "padded length instead of a constant count (many short utterances or few long ones per step)")
+    p.add_argument("--skip_unused_layers", default=False, action="store_true",
+                   help="(extension, not a flag of the reference) leave the weights and AdamW state of an encoder layer that LayerDrop "
+                        "skipped in a step untouched (torch >= 2.0 zero_grad(set_to_none=True) semantics on one GPU); default: the skipped "
+                        "layer takes the step with a zero gradient")
     return p
 
 
@@ -204,8 +208,8 @@ def main(argv=None):
     script = os.path.abspath(__file__)
     # (the folder names are the reference's, built from ITS options in declaration order: the extension --batch_audio is not one
     # of them and only adds a suffix when it is used)
-    named = {k: v for k, v in vars(args).items() if k != "batch_audio"}
-    out_dir = os.path.join(args.output_dir, train_folder_name(named, script) + ("" if args.batch_audio is None else f"_ba-{args.batch_audio:g}"))
+    named = {k: v for k, v in vars(args).items() if k not in ("batch_audio", "skip_unused_layers")}
+    out_dir = os.path.join(args.output_dir, train_folder_name(named, script) + ("" if args.batch_audio is None else f"_ba-{args.batch_audio:g}") + ("_skipunused" if args.skip_unused_layers else ""))
     untrained_dir = os.path.join(args.output_dir, train_folder_name(named, script, untrained=True))
     model, tok = load_pretrained(args.base_model, device=dev, freeze_feature_encoder=not args.no_freeze,
                                  attention_dropout=args.attention_dropout,
@@ -231,7 +235,8 @@ def main(argv=None):
         steps_per_epoch = max(1, len(length_grouped_batches(train_len, args.batch_size, np.random.RandomState(args.seed),
                                                             frame_budget=args.batch_audio * 16000)))
         total = round(args.num_epochs * steps_per_epoch)
-    opt = AdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay, warmup_steps=500, total_steps=max(total, 1))
+    opt = AdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay, warmup_steps=500, total_steps=max(total, 1),
+                skip_unused_layers=args.skip_unused_layers)
     trainer = Trainer(model, opt)
     trainer.broadcast_parameters()
     state = {"log_history": [], "global_step": 0, "max_steps": total}

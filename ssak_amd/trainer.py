@@ -62,7 +62,14 @@ class AdamW:
     two weight-decay groups (matrices decayed, biases / LayerNorm affines not)."""
 
     def __init__(self, model: Wav2Vec2ForCTC, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 max_grad_norm=1.0, warmup_steps=500, total_steps=100000):
+                 max_grad_norm=1.0, warmup_steps=500, total_steps=100000, skip_unused_layers: bool = False):
+        """``skip_unused_layers``: what ``torch.optim.AdamW`` does under torch >= 2.0 defaults for an encoder layer LayerDrop skipped
+        in this step (its ``.grad`` is None): weights, both moments and the layer's own step count (bias correction) stay as they
+        are.  Off (the default): the skipped layer takes the step with a zero gradient, as under ``zero_grad(set_to_none=False)`` and
+        under DistributedDataParallel whenever another rank ran the layer."""
+        self.skip_unused_layers = bool(skip_unused_layers)
+        self._segments = None      # [(offset, count, layer or -1, decays)] covering [0, n): built on first use
+        self.layer_steps = None    # optimizer steps each encoder layer has taken (skip_unused_layers)
         self.model = model
         self.n = model.num_trainable
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -90,8 +97,29 @@ class AdamW:
         hip.check(fn(hip.ptr(m.grads[offset:]), count, hip.ptr(self.gnorm_sq), hip.ptr(self._sumsq_ws),
                      self._sumsq_ws.numel() * 4, hip.stream()))
 
-    def step(self, grad_scale: float = 1.0, norm_done: bool = False):
-        """Clip + update on the CURRENT stream.  ``norm_done``: gnorm_sq already holds the sum of squares (bucket partials)."""
+    def _layer_segments(self):
+        """[(offset, count, encoder layer or -1, decays)] covering the trainable range, adjacent parameters of one layer and
+        decay group merged."""
+        if self._segments is None:
+            import re
+            m = self.model
+            items = sorted((off, n, name) for name, (off, n, _) in m.layout.items() if off < m.num_trainable)
+            segs = []
+            for off, n, name in items:
+                mt = re.search(r"\.layers\.(\d+)\.", name)
+                layer = int(mt.group(1)) if mt and ".encoder." in name else -1
+                d = hf_decays(name, m.config)
+                if segs and segs[-1][2] == layer and segs[-1][3] == d and segs[-1][0] + segs[-1][1] == off:
+                    segs[-1] = (segs[-1][0], segs[-1][1] + n, layer, d)
+                else:
+                    segs.append((off, n, layer, d))
+            self._segments = segs
+            self.layer_steps = [0] * (1 + max([s[2] for s in segs] + [-1]))
+        return self._segments
+
+    def step(self, grad_scale: float = 1.0, norm_done: bool = False, layer_keep=None):
+        """Clip + update on the CURRENT stream.  ``norm_done``: gnorm_sq already holds the sum of squares (bucket partials).
+        ``layer_keep``: this step's LayerDrop decisions (read only with ``skip_unused_layers``)."""
         m = self.model
         lr = self.current_lr()
         self.step_count += 1
@@ -99,11 +127,22 @@ class AdamW:
             st = hip.stream()
             if not norm_done:
                 self.add_sumsq(0, self.n, first=True)
-            for off, cnt, wd in self._update_ranges():
+            if self.skip_unused_layers:
+                # one launch per (layer, decay group) segment: a skipped layer is left alone, a kept one is bias-corrected by
+                # ITS step count (torch keeps `step` per parameter)
+                segs = self._layer_segments()
+                keep = [True] * len(self.layer_steps) if layer_keep is None else [bool(k) for k in layer_keep]
+                for l, k in enumerate(keep):
+                    self.layer_steps[l] += int(k)
+                ranges = [(off, cnt, self.weight_decay if d else 0.0, self.step_count if layer < 0 else self.layer_steps[layer])
+                          for off, cnt, layer, d in segs if layer < 0 or keep[layer]]
+            else:
+                ranges = [(off, cnt, wd, self.step_count) for off, cnt, wd in self._update_ranges()]
+            for off, cnt, wd, stepno in ranges:
                 hip.check(hip.lib.ssak_adamw_step(hip.ptr(m.params[off:]), hip.ptr(m.grads[off:]), hip.ptr(self.exp_avg[off:]),
                                                   hip.ptr(self.exp_avg_sq[off:]), hip.ptr(m.shadow[off:]), cnt,
                                                   hip.ptr(self.gnorm_sq), self.max_grad_norm, grad_scale, lr, self.betas[0],
-                                                  self.betas[1], self.eps, wd, self.step_count, st))
+                                                  self.betas[1], self.eps, wd, stepno, st))
         m.sync_weights(full=False)  # the weight-normed positional-conv layouts follow the updated (g, v)
 
     def grad_norm(self, grad_scale: float = 1.0) -> float:
@@ -112,13 +151,19 @@ class AdamW:
 
     def state_dict(self):
         self.model.wait_params()
-        return {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.step_count}
+        sd = {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.step_count}
+        if self.skip_unused_layers and self.layer_steps is not None:
+            sd["layer_steps"] = list(self.layer_steps)
+        return sd
 
     def load_state_dict(self, sd):
         self.model.wait_params()
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+        if self.skip_unused_layers:
+            self._layer_segments()
+            self.layer_steps = list(sd.get("layer_steps", [self.step_count] * len(self.layer_steps)))
 
 
 class _EventWork:
@@ -313,7 +358,8 @@ class Trainer:
         if compute_stream is not None:
             # everything of the backward (without a process group: the gradients themselves) precedes the update
             torch.cuda.current_stream().wait_stream(compute_stream)
-        self.opt.step(grad_scale=1.0 / self.world, norm_done=have_norm)
+        # (per-layer skipping follows ONE process's LayerDrop decisions: under a process group a layer another rank ran has a gradient)
+        self.opt.step(grad_scale=1.0 / self.world, norm_done=have_norm, layer_keep=self.model.last_layer_keep if self.world == 1 else None)
 
     def train_step(self, waves: torch.Tensor, lengths, labels: torch.Tensor, raw: bool = True, global_count: int | None = None):
         """waves [B,T] fp32 on the device (raw samples when ``raw``: normalised here, a1), lengths [B] or None,

@@ -66,6 +66,59 @@ def test_matched_loss_50_steps_vs_fp32_oracle():
     assert rel < 2e-2
 
 
+@pytest.mark.parametrize("skip", [True, False])
+def test_optimizer_step_of_layerdrop_skipped_layers(skip):
+    """A layer LayerDrop skips has no gradient.  ``AdamW(skip_unused_layers=True)`` = torch >= 2.0 defaults (``.grad`` is None: the
+    layer's weights, moments and per-parameter step count are left alone); the default = a zero gradient that takes the step
+    (``zero_grad(set_to_none=False)`` / DistributedDataParallel).  Both against the fp32 oracle + ``torch.optim.AdamW`` over eight
+    steps with explicit decisions, compared on the weights of a layer that is skipped in some steps."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer, linear_warmup_lr
+    oc = R.W2V2Config.tiny(num_hidden_layers=3).deterministic()
+    p0 = R.init_params(oc, 21)
+    rng = np.random.default_rng(5)
+    x = R.zero_mean_unit_var_norm([rng.standard_normal(8000).astype(np.float32) for _ in range(4)])
+    labels = R.pad_labels([list(rng.integers(1, 32, n)) for n in (6, 4, 7, 5)])
+    keeps = [[1, 1, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1], [1, 0, 0], [1, 1, 1], [1, 0, 1], [1, 1, 1]]
+    lr, warm = 1e-3, 2
+    names = R.trainable_names(oc)
+    q = {n: (t.clone().requires_grad_(n in names)) for n, t in p0.items()}
+    opt = torch.optim.AdamW([q[n] for n in names], lr=lr, weight_decay=0.0)
+    for s, keep in enumerate(keeps):
+        for g in opt.param_groups:
+            g["lr"] = linear_warmup_lr(lr, s, warm, 1000)
+        loss, _ = R.forward(q, oc, torch.tensor(x), None, torch.tensor(labels), layer_keep=keep)
+        opt.zero_grad(set_to_none=skip)
+        loss.backward()
+        if not skip:  # (the first time a layer is skipped before it ever had a gradient, torch has nothing to zero)
+            for n in names:
+                if q[n].grad is None:
+                    q[n].grad = torch.zeros_like(q[n])
+        torch.nn.utils.clip_grad_norm_([q[n] for n in names if q[n].grad is not None], 1.0)
+        opt.step()
+    model = Wav2Vec2ForCTC(_cfg(Wav2Vec2Config, oc), exact=True).train()  # fp32-exact engine: the two semantics differ by ~40 %
+    model.load_state_dict(p0)                                             # of layer 1's movement, the engines by ~1e-3
+    opt2 = AdamW(model, lr=lr, warmup_steps=warm, total_steps=1000, max_grad_norm=1.0, skip_unused_layers=skip)
+    xd, ld = torch.tensor(x).cuda(), torch.tensor(labels).cuda()
+    for keep in keeps:
+        model(xd, labels=ld, layer_keep=keep)
+        model.backward()
+        opt2.step(layer_keep=model.last_layer_keep)
+    sd = model.state_dict()
+    worst, which = 0.0, None
+    for n in names:
+        if ".encoder.layers." not in n or not n.endswith(".weight") or p0[n].dim() != 2:
+            continue
+        a, b = sd[n].float().cpu(), q[n].detach()
+        d = float((a - b).norm() / (b - p0[n]).norm())
+        if d > worst:
+            worst, which = d, n
+    print("skip" if skip else "zero-gradient", "semantics: worst (engine - torch) / (torch's movement) over the layers' matrices", worst, which)
+    assert worst < 3e-2, (worst, which)
+
+
 def test_vocab_not_multiple_of_8():
     """A 29-symbol tokenizer: the head is padded to 32 inert classes; logits / loss / head gradient match the oracle."""
     from oracle import w2v2_ref as R
