@@ -614,8 +614,10 @@ __global__ __launch_bounds__(1024) void posconv_colnorm_finalize_kernel(const fl
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + cx;
   float s = 0.f;
-  if (k < K)
-    for (int b = ry; b < nblk; b += 16) s += partial[(size_t)b * K + k];
+  if (k < K) {
+#pragma unroll 8
+    for (int b = ry; b < nblk; b += 16) s += partial[(size_t)b * K + k];  // (eight loads in flight: two workgroups do all of it)
+  }
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && k < K) {
