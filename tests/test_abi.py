@@ -28,6 +28,40 @@ def test_binding_rejects_without_gpu_compute():
     assert rc == h.SSAK_ERR_INVALID and b"null" in h.lib.ssak_last_error()
 
 
+def test_read_ranges_reads_and_reports(tmp_path):
+    """ssak_read_ranges (host: the file reads of an ingest batch by native threads): bytes land where asked for any thread count,
+    empty ranges are skipped, a missing file and a range past the end of a file are SSAK_ERR_INVALID with the path in the message."""
+    import numpy as np
+    import ssak_amd.hip as h
+    rng = np.random.default_rng(0)
+    blobs, paths = [], []
+    for i in range(11):
+        b = rng.integers(0, 256, 1000 + 37 * i, dtype=np.uint8)
+        p = tmp_path / f"f{i}.bin"
+        p.write_bytes(b.tobytes())
+        blobs.append(b)
+        paths.append(os.fsencode(str(p)))
+    n = len(paths)
+    off = [7 * i for i in range(n)]
+    size = [len(blobs[i]) - off[i] - (i % 3) for i in range(n)]
+    size[4] = 0
+    pos = np.cumsum([0] + size[:-1])
+    for threads in (1, 3, 8, 64):
+        buf = np.full(sum(size) + 16, 0xEE, dtype=np.uint8)
+        args = ((ctypes.c_char_p * n)(*paths), (ctypes.c_int64 * n)(*off), (ctypes.c_int64 * n)(*size),
+                (ctypes.c_void_p * n)(*[buf.ctypes.data + int(q) for q in pos]))
+        assert h.lib.ssak_read_ranges(*args, n, threads) == h.SSAK_OK
+        for i in range(n):
+            assert (buf[pos[i]:pos[i] + size[i]] == blobs[i][off[i]:off[i] + size[i]]).all(), (threads, i)
+        assert (buf[sum(size):] == 0xEE).all()
+    buf = np.zeros(64, dtype=np.uint8)
+    one = lambda path, o, s: h.lib.ssak_read_ranges((ctypes.c_char_p * 1)(path), (ctypes.c_int64 * 1)(o), (ctypes.c_int64 * 1)(s),
+                                                    (ctypes.c_void_p * 1)(buf.ctypes.data), 1, 4)
+    assert one(os.fsencode(str(tmp_path / "nope.bin")), 0, 8) == h.SSAK_ERR_INVALID and b"nope.bin" in h.lib.ssak_last_error()
+    assert one(paths[0], 990, 64) == h.SSAK_ERR_INVALID and b"short read" in h.lib.ssak_last_error()
+    assert h.lib.ssak_read_ranges(None, None, None, None, 0, 4) == h.SSAK_OK
+
+
 def test_base_gradient_buckets_cover_the_trainable_range():
     """The gradient ranges the backward announces for the data-parallel exchange, from the configuration alone
     (ssak_w2v2_grad_ranges: host arithmetic, no GPU): for wav2vec2-base with the frozen feature encoder they are disjoint,
