@@ -69,6 +69,22 @@ def test_logmel(gold):
     assert np.abs(m[:, :40] - z["mel_head"]).max() < 1e-4
 
 
+def test_logmel_fp32_fft_route_is_within_the_bar(gold):
+    """The device kernel's route (fp32, 200-point complex Stockham FFT 5 x 5 x 8 + real-input split) restated in numpy: its distance
+    from the float64 oracle on the golden wave and on the weak-bin case that rules out 16-bit operand splits (a full-scale tone over
+    noise at 1e-3 of its amplitude) -- the bar on the device is 2e-4."""
+    from oracle import logmel_fft_ref
+    z = gold("logmel.npz")
+    w = z["wave"]
+    assert np.abs(logmel_fft_ref.log_mel_fp32_fft(w) - logmel_ref.log_mel(w)).max() < 2e-5
+    rng = np.random.default_rng(0)
+    t = np.arange(160000) / 16000.0
+    tone = (0.5 * np.sin(2 * np.pi * 440.0 * t) + 0.001 * rng.standard_normal(t.size)).astype(np.float32)
+    assert np.abs(logmel_fft_ref.log_mel_fp32_fft(tone, 160000) - logmel_ref.log_mel(tone, 160000)).max() < 1.5e-4
+    zf = logmel_fft_ref.stockham_fft200((rng.standard_normal((3, 200)) + 1j * rng.standard_normal((3, 200))).astype(np.complex64))
+    assert zf.shape == (3, 200)
+
+
 def test_logmel_bonjour(gold):
     import wave
     z = gold("logmel.npz")
