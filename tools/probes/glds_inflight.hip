@@ -64,7 +64,8 @@ double run(const char* src, size_t region, size_t wg_stride, int n, int grid, un
   return (double)grid * n * 4 * 1024 / (ms * 1e-3) / 1e9;  // GB/s
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool one = argc > 1;  // any argument: the 64 KiB row only (for a counter run: rocprofv3 --pmc FETCH_SIZE)
   const int grid = 256;
   const size_t total = 2ull << 30;
   char* buf;
@@ -82,6 +83,10 @@ int main() {
     const double h4 = run<D>(buf, 24u << 20, 24u << 20, 6144, grid, sink, 4, 6u << 20);   /* 4 sharers, 6 MiB apart */          \
     printf("      4 sharers 256 KiB apart %8.1f (%5.1f per CU)   6 MiB apart (a quarter of the region) %8.1f (%5.1f per CU)\n", g4, g4 / grid, h4, h4 / grid); \
     printf("%4d  HBM %8.1f GB/s (%5.1f per CU)   L2 %8.1f (%5.1f)   4 sharers in lockstep %8.1f (%5.1f per CU; HBM side %6.1f)   8 sharers %8.1f (%5.1f; HBM side %6.1f)\n", 4 * D, hbm, hbm / grid, l2, l2 / grid, s4, s4 / grid, s4 / 4, s8, s8 / grid, s8 / 8); \
+  }
+  if (one) {
+    ROW(16)
+    return 0;
   }
   ROW(4) ROW(8) ROW(12) ROW(16) ROW(20) ROW(24) ROW(32) ROW(36)
   return 0;
