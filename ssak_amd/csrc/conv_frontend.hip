@@ -47,11 +47,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
   if (APPLY) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const double s1 = sums[((size_t)b * C + q * 4 + j) * 2], s2 = sums[((size_t)b * C + q * 4 + j) * 2 + 1];
-      const double m = s1 / T0;
-      const double var = fmax(s2 / T0 - m * m, 0.0);
-      mu[j] = (float)m;
-      rs[j] = (float)(1.0 / sqrt(var + 1e-5));
+      mu[j] = (float)sums[((size_t)b * C + q * 4 + j) * 2];  // (mean, 1 / sqrt(var + eps)) per (utterance, channel)
+      rs[j] = (float)sums[((size_t)b * C + q * 4 + j) * 2 + 1];
       ga[j] = gamma[q * 4 + j];
       be[j] = beta[q * 4 + j];
     }
@@ -181,10 +178,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     xs[i] = (sidx < T) ? xb[sidx] : 0.f;
   }
   for (int c = threadIdx.x; c < C; c += 256) {
-    const double s1 = sums[((size_t)b * C + c) * 2], s2 = sums[((size_t)b * C + c) * 2 + 1];
-    const double m = s1 / T0;
-    const double var = fmax(s2 / T0 - m * m, 0.0);
-    const float mu = (float)m, rs = (float)(1.0 / sqrt(var + 1e-5));
+    const float mu = (float)sums[((size_t)b * C + c) * 2], rs = (float)sums[((size_t)b * C + c) * 2 + 1];
     const float a = rs * gamma[c];
     ab[0][c] = a;
     ab[1][c] = beta[c] - mu * a;
@@ -297,13 +291,13 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 //   sum_t y[c,t]   = sum_k w[c,k] S[k],              S[k]    = sum_t x[5t+k]
 //   sum_t y[c,t]^2 = sum_{k,k'} w[c,k] w[c,k'] R[k,k'],  R[k,k'] = sum_t x[5t+k] x[5t+k']
 // i.e. 65 moments of the input per utterance (fp64) instead of a 512-channel convolution pass: the statistics pass drops
-// from 144 us to a few us.  Same output format as before (sums[b][c] = (sum y, sum y^2)), fixed summation order.
+// from 144 us to a few us.  Output sums[b][c] = (mean_t y, 1 / sqrt(var_t y + eps)), fixed summation order.
 // Two more moments, sum x and sum x^2 over ALL samples of the utterance (slots NMOM - 2, NMOM - 1), fold the feature extractor's
 // zero-mean / unit-variance normalisation (a1: x_n = (x - mu) / sqrt(var + 1e-7), transformers feature_extraction_wav2vec2.py:
 // 78-97) into this GroupNorm for full-length utterances: conv0 is linear and bias-free, so conv(x_n) = (conv(x) - mu W_c) / sigma,
 // and GroupNorm over time is invariant under a per-channel shift and scale except for its epsilon:
 //     GN(conv(x_n)) = (y - mean_t y) / sqrt(var_t y + 1e-5 sigma^2),      y = conv(x) on the RAW waveform.
-// conv0_channel_stats_kernel adds 1e-5 (sigma^2 - 1) to the channel variances (through sum y^2) and the apply pass runs on raw
+// conv0_channel_stats_kernel uses 1e-5 sigma^2 as the epsilon of rstd = 1 / sqrt(var_t y + eps) and the apply pass runs on raw
 // samples unchanged: the train step needs no normalisation pass at all (it was two launches and two passes over the waveform).
 constexpr int NMOM = KS0 + KS0 * (KS0 + 1) / 2 + 2;
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ x, int T, int T0, double* __restrict__ partial) {
@@ -405,22 +399,31 @@ __global__ __launch_bounds__(256) void conv0_channel_stats_kernel(const double* 
 #pragma unroll
     for (int k2 = k; k2 < KS0; ++k2) s2 += (k2 == k ? 1.0 : 2.0) * wk[k] * wk[k2] * mom[idx++];
   }
+  double eps = 1e-5;
   if (fold_norm) {  // raw waveform in: the normalisation's sigma^2 rescales GroupNorm's epsilon (see NMOM above)
     const double mu = mom[NMOM - 2] / T, sig2 = fmax(mom[NMOM - 1] / T - mu * mu, 0.0) + 1e-7;
-    s2 += (double)T0 * 1e-5 * (sig2 - 1.0);
+    eps *= sig2;
   }
-  sums[((size_t)b * C + c) * 2] = s1;
-  sums[((size_t)b * C + c) * 2 + 1] = s2 > 0.0 ? s2 : 0.0;
+  // the epsilon stays OUTSIDE the clamp: a near-dead channel of quiet audio has var_y far below 1e-5 and 1e-5 sigma^2 is then
+  // the whole denominator (adding it to sum y^2 instead lost it to the clamp at 0)
+  const double m = s1 / T0;
+  sums[((size_t)b * C + c) * 2] = m;
+  sums[((size_t)b * C + c) * 2 + 1] = 1.0 / sqrt(fmax(s2 / T0 - m * m, 0.0) + eps);
 }
 
-__global__ void conv0_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C, double* __restrict__ sums) {
-  // grid (ceil(2C/256), B): sums[b][c][2] = sum over the nblk workgroup partials, fixed order
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * C) return;
+__global__ void conv0_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C, int T0, double* __restrict__ sums) {
+  // grid (ceil(C/256), B): sums[b][c] = (mean, 1 / sqrt(var + 1e-5)) from the nblk workgroup partials (sum y, sum y^2), fixed order
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
   const int b = blockIdx.y;
-  double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += partial[((size_t)b * nblk + k) * 2 * C + e];
-  sums[(size_t)b * 2 * C + e] = s;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    s1 += partial[(((size_t)b * nblk + k) * C + c) * 2];
+    s2 += partial[(((size_t)b * nblk + k) * C + c) * 2 + 1];
+  }
+  const double m = s1 / T0;
+  sums[((size_t)b * C + c) * 2] = m;
+  sums[((size_t)b * C + c) * 2 + 1] = 1.0 / sqrt(fmax(s2 / T0 - m * m, 0.0) + 1e-5);
 }
 
 // ---- feature-encoder backward (--no_freeze, ssak/train/transformers/wav2vec_train.py:326-327 off) -------------------
@@ -488,10 +491,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     const int c = q * 4 + j;
 #pragma unroll
     for (int k = 0; k < KS0; ++k) wr[j][k] = w[c * KS0 + k];
-    const double s1 = sums[((size_t)b * C + c) * 2], s2 = sums[((size_t)b * C + c) * 2 + 1];
-    const double m = s1 / T0;
-    mu[j] = (float)m;
-    rs[j] = (float)(1.0 / sqrt(fmax(s2 / T0 - m * m, 0.0) + 1e-5));
+    mu[j] = (float)sums[((size_t)b * C + c) * 2];
+    rs[j] = (float)sums[((size_t)b * C + c) * 2 + 1];
     ga[j] = gamma[c];
     be[j] = beta[c];
     m1[j] = PASS == 1 ? (float)(gsums[((size_t)b * C + c) * 2] / T0) : 0.f;
@@ -783,7 +784,7 @@ int k_conv0_wgrad_t(const DT* d, const float* x, float* dw, float* scratch, int 
 }
 
 size_t k_conv0_stats_doubles(int B, int T0, int C) {
-  // [B][2C] ordered sums | per-workgroup partials: 2C (convolution-pass statistics) or NMOM (input moments) doubles each
+  // [B][C] (mean, rstd) | per-workgroup partials: 2C (convolution-pass statistics) or NMOM (input moments) doubles each
   return (size_t)B * 2 * C + (size_t)B * ssak_cdiv(T0, FR_STATS) * std::max(2 * C, NMOM);
 }
 
@@ -793,7 +794,7 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
   SSAK_REQUIRE(ksize == KS0 && stride == ST0, "conv0: only kernel 10 / stride 5 is built (got %d/%d)", ksize, stride);
   SSAK_REQUIRE((C & 3) == 0 && C <= 1024 && 256 % (C / 4) == 0, "conv0: C=%d must divide into 256 threads as quads", C);
   SSAK_REQUIRE(T0 == (T - KS0) / ST0 + 1 && T0 > 0, "conv0: T0 mismatch");
-  // stats layout: [B][2C] ordered sums | [B][nblk][2C] per-workgroup partials   (k_conv0_stats_doubles(B, T0, C) doubles)
+  // stats layout: [B][C] (mean, rstd) | [B][nblk][2C] per-workgroup partials   (k_conv0_stats_doubles(B, T0, C) doubles)
   const int nblk = ssak_cdiv(T0, FR_STATS);
   ProfScope prof_scope(PROF_CONV0, (double)B * ((double)T * 4.0 + (double)T0 * C * sizeof(OT)), st);  // waveform in, channels-last out
   double* sums = stats;
@@ -803,7 +804,7 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
   if (direct_stats) {
     conv0_kernel<OT, false, FR_STATS><<<dim3(nblk, B), 256, 0, st>>>(x, w, gamma, beta, out, partial, nullptr, T, T0, C);
     SSAK_LAUNCH_CHECK();
-    conv0_stats_finalize_kernel<<<dim3(ssak_cdiv(2 * C, 256), B), 256, 0, st>>>(partial, nblk, C, sums);
+    conv0_stats_finalize_kernel<<<dim3(ssak_cdiv(C, 256), B), 256, 0, st>>>(partial, nblk, C, T0, sums);
     SSAK_LAUNCH_CHECK();
   } else {  // 65 input moments per utterance, then the channels' sums in closed form (NMOM <= 2 C doubles per partial slot)
     conv0_moments_kernel<<<dim3(nblk, B), 256, 0, st>>>(x, T, T0, partial);

@@ -118,7 +118,12 @@ def build_parser():
     # extensions (not flags of the reference; declared last and left out of the output-folder name unless used)
     p.add_argument("--batch_audio", type=float, default=None,
                    help="(extension, not a flag of the reference) seconds of PADDED audio per step: length-grouped batches of a constant "
-                        "padded length instead of a constant count (many short utterances or few long ones per step)")
+                        "padded length instead of a constant count (many short utterances or few long ones per step).  The number of "
+                        "steps per epoch then depends on each epoch's shuffle: the LR-schedule horizon and --num_epochs use the step "
+                        "count of ONE seeded plan (an approximation), the logged `epoch` counts utterances actually consumed")
+    p.add_argument("--batch_audio_max_utts", type=int, default=None,
+                   help="(extension) with --batch_audio: most utterances in one step (default 8 x --batch_size); bounds the workspace "
+                        "a step of many short utterances asks for")
     p.add_argument("--skip_unused_layers", default=False, action="store_true",
                    help="(extension, not a flag of the reference) leave the weights and AdamW state of an encoder layer that LayerDrop "
                         "skipped in a step untouched (torch >= 2.0 zero_grad(set_to_none=True) semantics on one GPU); default: the skipped "
@@ -208,7 +213,7 @@ def main(argv=None):
     script = os.path.abspath(__file__)
     # (the folder names are the reference's, built from ITS options in declaration order: the extension --batch_audio is not one
     # of them and only adds a suffix when it is used)
-    named = {k: v for k, v in vars(args).items() if k not in ("batch_audio", "skip_unused_layers")}
+    named = {k: v for k, v in vars(args).items() if k not in ("batch_audio", "batch_audio_max_utts", "skip_unused_layers")}
     out_dir = os.path.join(args.output_dir, train_folder_name(named, script) + ("" if args.batch_audio is None else f"_ba-{args.batch_audio:g}") + ("_skipunused" if args.skip_unused_layers else ""))
     untrained_dir = os.path.join(args.output_dir, train_folder_name(named, script, untrained=True))
     model, tok = load_pretrained(args.base_model, device=dev, freeze_feature_encoder=not args.no_freeze,
@@ -233,7 +238,7 @@ def main(argv=None):
     total = round(args.num_epochs * len(tl) / args.batch_size)
     if args.batch_audio is not None:  # constant padded length per step: the step count of an epoch follows from the plan
         steps_per_epoch = max(1, len(length_grouped_batches(train_len, args.batch_size, np.random.RandomState(args.seed),
-                                                            frame_budget=args.batch_audio * 16000)))
+                                                            frame_budget=args.batch_audio * 16000, max_batch=args.batch_audio_max_utts)))
         total = round(args.num_epochs * steps_per_epoch)
     opt = AdamW(model, lr=args.learning_rate, weight_decay=args.weight_decay, warmup_steps=500, total_steps=max(total, 1),
                 skip_unused_layers=args.skip_unused_layers)
@@ -308,16 +313,19 @@ def main(argv=None):
         resume_step = int(state["global_step"])
         if rank == 0:
             print(f"resuming from {last} (step {resume_step} of {total})")
+    seen_utts = 0
     while step < total:
         # (global batch, this rank's contiguous shard of it): shards may differ by one utterance on the short last batch and
         # may be empty; the trainer weights by utterance count
         plan = [(idx, shard_batch(idx, rank, world) if world > 1 else idx) for idx in length_grouped_batches(train_len, args.batch_size, rng,
-                                                                frame_budget=None if args.batch_audio is None else args.batch_audio * 16000)]
+                                                                frame_budget=None if args.batch_audio is None else args.batch_audio * 16000,
+                                                                max_batch=args.batch_audio_max_utts)]
         plan = [gm for gm in plan if gm[0]][:total - step]
         if not plan:
             raise RuntimeError("empty batch plan: no training utterances")
         if step < resume_step:  # batches the checkpointed run already consumed
             skip = min(len(plan), resume_step - step)
+            seen_utts += sum(len(w) for w, _ in plan[:skip])
             plan, step = plan[skip:], step + skip
             if not plan:
                 continue
@@ -339,12 +347,17 @@ def main(argv=None):
                 else:
                     x, lens = next(feed)
                     lab = pad_labels([tl[i] for i in mine])
-                    loss = trainer.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(lens).to(dev),
+                    # an un-padded batch (every utterance as long as the batch) carries no length information: lengths=None lets the
+                    # trainer fold the normalisation into conv0 (an all-ones mask and no mask are the same computation)
+                    full = bool((lens == x.shape[1]).all())
+                    loss = trainer.train_step(torch.from_numpy(x).to(dev), None if full else torch.from_numpy(lens).to(dev),
                                               torch.from_numpy(lab).to(dev), global_count=gc)
             run_loss.append(loss)
             step += 1
+            seen_utts += len(whole)
             if step % args.eval_steps == 0 or step == total:
-                entry = {"epoch": step / steps_per_epoch, "step": step, "learning_rate": opt.current_lr(),
+                # (frame-budget batches: an epoch is len(tl) utterances consumed, whatever the number of steps that took)
+                entry = {"epoch": step / steps_per_epoch if args.batch_audio is None else seen_utts / max(1, len(tl)), "step": step, "learning_rate": opt.current_lr(),
                          "loss": float(torch.stack(run_loss).mean().item())}
                 run_loss = []
                 ck = os.path.join(out_dir, f"checkpoint-{step}")

@@ -361,9 +361,14 @@ class Trainer:
         # (per-layer skipping follows ONE process's LayerDrop decisions: under a process group a layer another rank ran has a gradient)
         self.opt.step(grad_scale=1.0 / self.world, norm_done=have_norm, layer_keep=self.model.last_layer_keep if self.world == 1 else None)
 
-    def train_step(self, waves: torch.Tensor, lengths, labels: torch.Tensor, raw: bool = True, global_count: int | None = None):
+    def train_step(self, waves: torch.Tensor, lengths, labels: torch.Tensor, raw: bool = True, global_count: int | None = None,
+                   fold_norm: bool | None = None):
         """waves [B,T] fp32 on the device (raw samples when ``raw``: normalised here, a1), lengths [B] or None,
         labels [B,L] (-100 padding).  Returns the (local) loss tensor; no host synchronisation.
+
+        ``fold_norm``: None = the trainer's default (SSAK_FOLD_NORM, on when the model allows it); False = keep the separate
+        ssak_wave_normalize pass for this call.  The fold applies only to un-padded batches (``lengths`` None: every utterance
+        fills the batch's T) of the group-norm topology with a frozen feature encoder; everything else normalises in its own pass.
 
         ``global_count`` (data parallel): utterances of the GLOBAL batch when the ranks' shards differ in size (the short last
         batch of an epoch, data.shard_batch).  The CTC loss is a mean over utterances, so rank r's gradient enters the sum
@@ -383,7 +388,7 @@ class Trainer:
             # raw full-length utterances into the group-norm model: the normalisation (a1) rides in conv0's GroupNorm statistics,
             # no pass of its own (model.can_fold_normalisation; ragged batches -- lengths given -- and the layer-norm topology
             # keep ssak_wave_normalize)
-            fold = raw and lengths is None and self._fold_norm
+            fold = raw and lengths is None and self._fold_norm and fold_norm is not False
             x = waves if (fold or not raw) else hip.wave_normalize(waves, lengths)
             out = m(x, lengths=lengths if self.use_mask else None, labels=labels, **({"raw_input": True} if fold else {}))
             m.backward(grad_scale=scale)  # with a process group: announces finished gradient ranges -> bucketed all-reduces overlap it

@@ -382,6 +382,33 @@ def test_conv0_folds_the_waveform_normalisation(hip, B, T, C, scale):
     assert bool((e64 <= 2.0 ** -7 * ref.abs() + 3e-4).all()), float(e64.max())
 
 
+@pytest.mark.parametrize("B,T,C,amp", [(2, 16000, 512, 0.02), (2, 8003, 512, 0.005), (1, 160000, 512, 0.01), (2, 3204, 64, 0.02)])
+def test_conv0_fold_keeps_the_epsilon_for_quiet_audio_and_weak_channels(hip, B, T, C, amp):
+    """The folded form's epsilon is 1e-5 sigma^2 (sigma^2 << 1 for raw audio).  Channels whose filter is weak (|w| down to 1e-3: a
+    pretrained conv0 has near-dead filters) have var_t(conv(x_n)) far below 1e-5 / sigma^2, where the epsilon IS the denominator:
+    it must not be lost to the variance clamp.  fp64 reference on the normalised input; the two-pass form must agree as well."""
+    g = torch.Generator().manual_seed(T + C + 1)
+    x = (torch.randn(B, T, generator=g) * amp + 0.5 * amp).cuda()
+    wscale = torch.logspace(-3, 0, C)[torch.randperm(C, generator=g)]
+    w = (torch.randn(C, 10, generator=g) * 0.3 * wscale[:, None]).cuda()
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).cuda()
+    got = hip.conv0_gn_gelu(x, w, gamma, beta, raw=True).float()
+    two_pass = hip.conv0_gn_gelu(hip.wave_normalize(x, None), w, gamma, beta).float()
+    xd = x.double().cpu()
+    xnd = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-7)
+    y = torch.nn.functional.conv1d(xnd[:, None, :], w.double().cpu()[:, None, :], stride=5)
+    var = y.var(2, unbiased=False, keepdim=True)
+    assert float(var.min()) < 1e-5 < float(var.max()), "the case must have channels on both sides of the epsilon"
+    y = (y - y.mean(2, keepdim=True)) / torch.sqrt(var + 1e-5)
+    y = y * gamma.double().cpu()[None, :, None] + beta.double().cpu()[None, :, None]
+    ref = (0.5 * y * (1.0 + torch.erf(y / 2 ** 0.5))).transpose(1, 2)
+    for name, out in (("folded", got), ("two-pass", two_pass)):
+        assert torch.isfinite(out).all()
+        e64 = (out.double().cpu() - ref).abs()
+        assert bool((e64 <= 2.0 ** -7 * ref.abs() + 3e-4).all()), (name, float(e64.max()))
+
+
 # ------------------------------------------------------------------ fused attention (head_dim 64)
 def _attn_ref(qkv, B, F, nh, klens=None):
     H = qkv.shape[1] // 3

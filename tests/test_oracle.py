@@ -163,7 +163,8 @@ ALIGN_CASES = ["tiny", "base", "blank5", "garbage", "flat", "tight", "infeasible
 
 @pytest.mark.parametrize("name", ALIGN_CASES)
 def test_align_oracle_vs_torch_golden(gold, name):
-    """Bit-exact against the trellis / path the reference's torch ops give (oracle/gen_golden_align.py)."""
+    """Bit-exact against the trellis / path of the reference's OWN get_trellis / backtrack (oracle/gen_golden_align.py imports
+    /root/reference/ssak/utils/align_transcriptions.py and writes align.npz from them: row f1 is pinned)."""
     from oracle import align_ref
     z = gold("align.npz")
     em, tok, blank = z[f"{name}_emission"], z[f"{name}_tokens"].tolist(), int(z[f"{name}_blank"])
@@ -206,6 +207,25 @@ def test_align_path_properties_and_segments(gold):
     assert all(a.end == b.start for a, b in zip(segs, segs[1:]))
     words = align_ref.merge_words(segs)
     assert "".join(w.label for w in words) == transcript.replace(" ", "")
+
+
+@pytest.mark.parametrize("name", [c for c in ALIGN_CASES if c != "infeasible"])
+def test_align_segments_vs_reference_merge(gold, gold_json, name):
+    """merge_repeats / merge_words: the oracle's and the product's host mirrors (ssak_amd/align.py) against the segments the
+    reference's own functions produced from the golden paths (align_segments.json, written by oracle/gen_golden_align.py from
+    the imported ssak/utils/align_transcriptions.py:141-175)."""
+    from oracle import align_ref
+    from ssak_amd import align as prod
+    z = gold("align.npz")
+    want = gold_json("align_segments.json")["cases"][name]
+    for mod in (align_ref, prod):
+        path = [mod.Point(int(a), int(b), float(c)) for a, b, c in zip(z[f"{name}_path_token"], z[f"{name}_path_time"], z[f"{name}_path_score"])]
+        segs = mod.merge_repeats(want["transcript"], path)
+        assert [[s.label, s.start, s.end] for s in segs] == [w[:3] for w in want["segments"]]
+        assert np.allclose([s.score for s in segs], [w[3] for w in want["segments"]], rtol=1e-12, atol=0)
+        words = mod.merge_words(segs)
+        assert [[s.label, s.start, s.end] for s in words] == [w[:3] for w in want["words"]]
+        assert np.allclose([s.score for s in words], [w[3] for w in want["words"]], rtol=1e-12, atol=0)
 
 
 # ------------------------------------------------------------------ evaluation metric (SURVEY.md 8f-3)
