@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (Whisper-small, XLSR-large bucketed, ingest)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the per-GPU batch sweep (8, 16) and the un-folded normalisation run after the timed region")
     ap.add_argument("--long-steps", type=int, default=100, help="extra untimed-by-the-driver run after the timed region (0 = skip)")
     args = ap.parse_args()
     build = build_stamp()  # before anything touches the GPU: it spawns git (no child processes under a profiler's preload later)
@@ -373,6 +374,37 @@ def main():
         long_run = {"steps": args.long_steps, "value": round(B * world * args.long_steps / dl, 2), "ms_per_step": round(dl / args.long_steps * 1e3, 3),
                     "note": "same step, run after the timed region, no event markers"}
 
+    # "per-GPU batch B in {8, 16, 32}; report best" -- the other batch sizes through the same model / trainer,
+    # a short timed run each (the reference's default is --batch_size 8, wav2vec_train.py:158); the headline stays the --batch line
+    sweep = []
+    if world == 1 and not args.no_sweep and not args.no_secondary:  # (profiler passes run --no-secondary: only the headline's launches)
+        for Bs in (8, 16):
+            if Bs == B:
+                continue
+            kl1, fw1 = model.kept_layers, model.train_forwards
+            w_s, l_s = waves[:Bs].contiguous(), labels[:Bs].contiguous()
+            for _ in range(3):
+                trainer.train_step(w_s, None, l_s)
+            sync()
+            n_s = 30
+            ts = time.perf_counter()
+            for _ in range(n_s):
+                trainer.train_step(w_s, None, l_s)
+            sync()
+            ds = time.perf_counter() - ts
+            kept_s = (model.kept_layers - kl1) / max(1, model.train_forwards - fw1)
+            tf_s = gf_per_utt(kept_s) * 1e9 * Bs * n_s / ds / 1e12
+            sweep.append({"per_gpu_batch": Bs, "value": round(Bs * n_s / ds, 2), "ms_per_step": round(ds / n_s * 1e3, 3), "steps": n_s,
+                          "whole_step_tflops": round(tf_s, 1), "whole_step_frac": round(tf_s / PEAK_BF16_TFLOPS, 4)})
+        # and the un-folded step (ssak_wave_normalize as its own pass, what a padded batch takes) beside the folded headline
+        for _ in range(2):
+            trainer.train_step(waves, None, labels, fold_norm=False)
+        sync()
+        ts = time.perf_counter()
+        for _ in range(20):
+            trainer.train_step(waves, None, labels, fold_norm=False)
+        sync()
+        unfolded_ms = (time.perf_counter() - ts) / 20 * 1e3
     if rank == 0:
         utts = B * world * args.steps
         value = utts / dt
@@ -480,6 +512,17 @@ def main():
                                "bucket_bytes": [c * (2 if trainer.grad_exchange_dtype == "bf16" else 4) for _, c in trainer.bucket_log],
                                "payload_bytes_per_step": sum(c for _, c in trainer.bucket_log) * (2 if trainer.grad_exchange_dtype == "bf16" else 4)}
         out["long_run"] = long_run
+        if sweep:
+            tf_h = gf_per_utt(kept_avg) * 1e9 * B * args.steps / dt / 1e12
+            rows = sorted(sweep + [{"per_gpu_batch": B, "value": round(value, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "steps": args.steps,
+                                    "whole_step_tflops": round(tf_h, 1), "whole_step_frac": round(tf_h / PEAK_BF16_TFLOPS, 4)}], key=lambda r: r["per_gpu_batch"])
+            out["headline_sweep"] = {"rows": rows, "best_per_gpu_batch": max(rows, key=lambda r: r["value"])["per_gpu_batch"],
+                                     "note": f"SURVEY.md 8d: B in {{8, 16, 32}}, report best; `value` is the B = {B} line (the timed region), the others are "
+                                             "30-step runs of the same model right after it"}
+            out["normalisation"] = {"folded_ms_per_step": round(dt / args.steps * 1e3, 3), "own_pass_ms_per_step": round(unfolded_ms, 3),
+                                    "note": "the headline batch is un-padded (every utterance fills T), so ssak_amd.train and this bench fold the waveform "
+                                            "normalisation (a1) into conv0's GroupNorm statistics; padded / ragged batches and the layer-norm topology run "
+                                            "ssak_wave_normalize as a pass of its own (second figure, 20 steps)"}
         if world == 1 and not args.no_secondary:
             # BASELINE.json configs[3] / configs[4] and the ingest path on the same clock as the headline (their models are built after
             # the headline's timed region; its buffers are released first)
@@ -488,7 +531,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import side_benches
             sec = []
-            for fn, kw in ((side_benches.whisper_sweep, dict()), (side_benches.xlsr_sweep, dict())):
+            # secondary[0..1]: BASELINE configs[3] / [4]; [2]: the ssak/infer path; [3]: forced alignment (f1); [4]: evaluation metric (f3)
+            for fn, kw in ((side_benches.whisper_sweep, dict()), (side_benches.xlsr_sweep, dict()), (side_benches.infer_line, dict()),
+                           (side_benches.align_line, dict()), (side_benches.wer_line, dict())):
                 try:
                     sec.append(fn(**kw))
                 except Exception as e:  # a secondary line must not take the headline down with it

@@ -85,11 +85,14 @@ int ssak_ctc_greedy_decode(const float* logits, const int32_t* in_lens, int B, i
  * ssak_resample_plan / _table (host): reduced rates, filter half-width and taps; table [new_r][taps] fp32 computed in
  *   double like torchaudio's kernel.  ssak_resample_sinc: in [B, Tin] (in_lens [B] or NULL) -> out [B, Tout] with
  *   out_lens[b] = ceil(new_r * len / orig_r) valid samples (0 beyond); table on the device. */
-/* ssak_read_ranges (host): n byte ranges (path, file offset, length) read with pread by `threads` native threads into dst[i] (the
+/* ssak_read_ranges (host): n byte ranges (path, file offset, length) read with pread by `threads` native threads (a process-wide pool that outlives the call) into dst[i] (the
  *   caller's slices of a pinned staging buffer).  SSAK_ERR_INVALID with the path in ssak_last_error() for a file that cannot be
  *   opened or ends inside its range. */
 int ssak_read_ranges(const char* const* paths, const int64_t* file_offsets, const int64_t* nbytes, void* const* dst, int n,
                      int threads);
+/* ssak_drop_file_cache (host, measurement aid): fdatasync + posix_fadvise(DONTNEED) on each file, so that the next read comes from the
+ *   storage device (bench.py's cold-cache ingest figure); returns the number of files it could not open / advise. */
+int ssak_drop_file_cache(const char* const* paths, int n);
 int ssak_pcm_to_mono_f32(const void* raw, const int64_t* byte_offsets, const int32_t* nframes, int B, int channels, int sample_width,
                          int Tmax, float* out, void* stream);
 int ssak_resample_plan(int orig_sr, int new_sr, int* orig_r, int* new_r, int* width, int* taps);
@@ -191,11 +194,9 @@ typedef struct {
                  read.  Both must describe the same matrix: results are bit-identical either way.  Not with B batch strides. */
   int plan_tile; /* 0 (default): the library's cost model picks kernel, tile height and split.  256 / 192 / 128: run the product
                  on the persistent 256-column-tile kernels with this tile height whenever it qualifies for them (M, N >= 256,
-                 whole 16-byte chunks) -- for tests and tuning; results do not depend on it beyond the summation order.
-                 SSAK_PLAN_TILE_CORESIDENT: the 128-row-tile kernel that runs two workgroups per CU (K-contiguous operands,
-                 K % 64 == 0, N % 256 == 0, bf16 out; otherwise the 256-row persistent kernels). */
+                 whole 16-byte chunks) -- for tests and tuning; results do not depend on it beyond the summation order.  (Round 5's
+                 value 129, a co-resident 128-row-tile kernel that never won a shape, is gone: tools/probes/gemm_c4.hip.txt.) */
 } ssak_gemm_desc;
-#define SSAK_PLAN_TILE_CORESIDENT 129
 /* Fragment-ordered copy of a B operand ([N, K] K-contiguous, or [K, N] with b_kmajor; ldb as in the descriptor):
  * out[(cb * nkt + kt)][j][kk][lane][8] = B(n = 64 cb + 16 j + (lane & 15), k = 64 kt + 32 kk + 8 (lane >> 4) + e), zeros
  * beyond N / K, cb < 4 * ceil(N / 256), nkt = ceil(K / 64): the 8 KB one wave column needs for one 64-deep K tile are

@@ -132,6 +132,60 @@ def quality_report(p: float, rows: int = 4096, cols: int = 3072, seed: int = 123
             "row_count_var": float(cnt_r.var() / (cols * v)), "col_count_var": float(cnt_c.var() / (rows * v))}
 
 
+def inverse_mod_2_32(a) -> np.ndarray:
+    """Multiplicative inverses of odd 32-bit values mod 2^32 (Newton iteration: the number of correct bits doubles per step)."""
+    a = np.asarray(a, dtype=np.uint64)
+    x = a.copy()  # correct to 3 bits for odd a
+    for _ in range(5):
+        x = (x * ((np.uint64(2) - ((a * x) & _M32)) & _M32)) & _M32
+    return x
+
+
+def smallest_key_ratio_pairs(seed: int, site: int, rows: int, top: int = 1000):
+    """The rank-one weakness made concrete: two rows' words differ by ONE factor for every column, word_i = r word_j with
+    r = rowkey_i * rowkey_j^-1 (mod 2^32).  Returns the `top` ordered row pairs (i, j) with the smallest |r| (r read as a signed 32-bit
+    number) as arrays (r_signed, i, j), ascending in |r|: the pairs whose masks are closest to being functions of each other."""
+    rk = rowkey(seed, site, np.arange(rows, dtype=np.uint64))
+    iv = inverse_mod_2_32(rk)
+    two32 = np.uint64(1) << np.uint64(32)
+    out_m, out_r, out_i, out_j = [], [], [], []
+    step = 512
+    for s in range(0, rows, step):
+        r = (rk[s:s + step, None] * iv[None, :]) & _M32
+        mag = np.minimum(r, two32 - r)
+        ii = np.arange(s, min(rows, s + step))
+        mag[ii - s, ii] = two32  # (a row with itself)
+        flat = mag.ravel()
+        k = min(top, flat.size)
+        idx = np.argpartition(flat, k - 1)[:k]
+        out_m.append(flat[idx])
+        out_r.append(r.ravel()[idx])
+        out_i.append(idx // rows + s)
+        out_j.append(idx % rows)
+    m, r, i, j = (np.concatenate(v) for v in (out_m, out_r, out_i, out_j))
+    o = np.argsort(m, kind="stable")[:top]
+    r = r[o].astype(np.int64)
+    r = np.where(r >= (1 << 31), r - (1 << 32), r)
+    return r, i[o], j[o]
+
+
+def keep_agreement(seed: int, site: int, rows_i, rows_j, cols: int, p: float) -> np.ndarray:
+    """Fraction of the `cols` columns on which rows_i[k] and rows_j[k] of the site have the same keep bit."""
+    cm = colmul(np.arange(cols, dtype=np.uint64))[None, :]
+    t = np.uint64(thresh16(p) << 16)
+    ki = ((rowkey(seed, site, np.asarray(rows_i, dtype=np.uint64))[:, None] * cm) & _M32) >= t
+    kj = ((rowkey(seed, site, np.asarray(rows_j, dtype=np.uint64))[:, None] * cm) & _M32) >= t
+    return (ki == kj).mean(1)
+
+
+def ratio_agreement_expected(r: int, p: float) -> float:
+    """Keep-bit agreement of two rows whose words satisfy word_i = r word_j (mod 2^32), r a small odd integer with |r| p < 1, word_j
+    uniform: for r > 0 both drop when word_j < thresh / r (probability p / r), for r < 0 never; independence would give p^2."""
+    pe = thresh16(p) / 65536.0
+    joint_drop = pe / r if r > 0 else 0.0
+    return 1.0 - 2.0 * pe + 2.0 * joint_drop
+
+
 def step_seed_sequence(seed: int, n: int):
     """The per-forward dropout seeds ``ssak_amd.model.Wav2Vec2ForCTC`` derives from its constructor seed: state 0 from
     ``np.random.SeedSequence(seed)``, then one 64-bit LCG step per forward (the value after the step is the one used)."""

@@ -297,12 +297,14 @@ constexpr uint32_t drop_colmul_host(uint32_t col) {
   h ^= h >> 16;
   return h | 1u;
 }
-struct DropColmulTable {
+// (read through 16-byte vector loads in gemm_common.h and norm_act.hip's load_colmul: the alignment is part of the type)
+struct alignas(16) DropColmulTable {
   uint32_t v[DROP_TABLE_N];
   constexpr DropColmulTable() : v() {
     for (int i = 0; i < DROP_TABLE_N; ++i) v[i] = drop_colmul_host((uint32_t)i);
   }
 };
+static_assert(alignof(DropColmulTable) >= 16, "g_drop_colmul is read as uint4");
 #define SSAK_DEFINE_DROP_TABLE static __device__ const DropColmulTable g_drop_colmul = DropColmulTable();
 // keep test on a word; thi = thresh16 << 16 (thresh16 = round(p * 65536): the realised drop probability is thresh16 / 65536)
 __device__ __forceinline__ bool drop_keep(uint32_t rowkey, uint32_t colmul, uint32_t thi) { return rowkey * colmul >= thi; }

@@ -754,7 +754,7 @@ GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
   const bool p8_layout_ok = (d->epilogue != SSAK_EPI_GELU_SAVE_GRAD || (!d->a_kmajor && !d->b_kmajor)) &&
                             (d->epilogue != SSAK_EPI_MUL_AUX || !d->a_kmajor);
   const bool p8_ok = dma && d->M >= 256 && d->N >= 256 && g_env_p8 != 0 && p8_layout_ok;
-  if (p8_ok && (d->plan_tile == 256 || d->plan_tile == 192 || d->plan_tile == 128 || d->plan_tile == SSAK_PLAN_TILE_CORESIDENT))
+  if (p8_ok && (d->plan_tile == 256 || d->plan_tile == 192 || d->plan_tile == 128))
     return GemmPlan{true, d->plan_tile, s_lo, 0.0};  // caller's choice
   GemmPlan best_def{false, 0, s_lo, 1e30}, best_p8{true, 256, s_lo, 1e30};
   for (int s = s_lo; s <= s_hi; ++s) {
@@ -783,19 +783,7 @@ GemmPlan plan_gemm(const ssak_gemm_desc* d, bool dma, size_t workspace_bytes) {
 // (tools/probes/p8_loop.hip, profiles/r03_gemm_bdirect_probe*.log): 192-row tiles (the N = 768 products) gain 3-25 %, 256-row
 // tiles gain for deep K and narrow N (K = 3072, N = 768: +15 %) and LOSE for wide outputs (N = 3072: -5..-9 %, the weight no
 // longer fits the XCD's L2 next to the activations and every wave row fetches it again) and for the conv stack.
-// Products that go to the co-resident kernel by default (set from same-box measurements: tools/bench_gemm_tiles.py, bench.py A/B).
-bool c4_pays(const ssak_gemm_desc* d) {
-  static const int mode = [] {
-    const char* e = SSAK_DEV_ENV("SSAK_GEMM_C4");  // development switch: 0 = never, 1 = wherever it applies
-    return e ? atoi(e) : -1;
-  }();
-  if (mode == 0) return false;
-  if (mode == 1) return true;
-  return false;
-}
-
 bool fragments_pay(const ssak_gemm_desc* d, const GemmPlan& plan) {
-  if (plan.bm == SSAK_PLAN_TILE_CORESIDENT) return false;
   if (!plan.p8 || plan.split != 1 || d->a_kmajor || d->out_f32 || d->accumulate || d->colsum || d->drop_p > 0.f) return false;
   if (d->sb1 || d->sb2 || d->lda < d->K) return false;  // one weight for every batch; no Toeplitz A (conv stack)
   if (d->epilogue != SSAK_EPI_NONE) return false;
@@ -929,22 +917,10 @@ extern "C" int ssak_gemm_bf16(const ssak_gemm_desc* d, const void* A, const void
     return nb && nb[0] == '1';
   }();
   const long big_tiles = (long)ssak_cdiv(d->M, 256) * ssak_cdiv(d->N, 128) * p.nz * split;
-  // the co-resident four-wave kernel (gemm_c4.hip: 128-row tiles, two workgroups per CU) when the caller asks for it or the
-  // product is one of the epilogue-heavy shapes it was built for
-  bool use_c4 = false;
-  if (plan.p8 && split == 1) {
-    p.tiles_m = ssak_cdiv(d->M, 128);
-    p.tiles_n = ssak_cdiv(d->N, 256);
-    p.kperm_p = p.kperm_n2 = 0;
-    use_c4 = (plan.bm == SSAK_PLAN_TILE_CORESIDENT || (d->plan_tile == 0 && c4_pays(d))) && ssak_gemm_c4_supports(&p, d->a_kmajor, d->b_kmajor) &&
-             !(d->lda < d->K);  // (no Toeplitz A: the conv stack keeps its K-tile order on gemm_p4.hip)
-  }
-  const int p8_bm = use_c4 ? 128 : plan.bm == SSAK_PLAN_TILE_CORESIDENT ? 256 : plan.bm;
+  const int p8_bm = plan.bm;
   if (colsum_fused) p.colsum = (float*)workspace;
   p.kperm_p = p.kperm_n2 = 0;
-  if (use_c4) {
-    rc = ssak_gemm_c4_launch(&p, st);
-  } else if (plan.p8) {
+  if (plan.p8) {
     p.tiles_m = ssak_cdiv(d->M, p8_bm);
     p.tiles_n = ssak_cdiv(d->N, 256);
     // Toeplitz A (conv as GEMM, rows overlap: lda < K): visit the K tiles so that the two reads of the same bytes -- tap t + s of

@@ -467,7 +467,13 @@ int dispatch_p4(const GemmParams& p, int b_km, hipStream_t st) {
   const bool no_extras = !p.drop_thresh && !p.colsum;
   if (no_extras && p.epilogue == SSAK_EPI_NONE && !p.out_f32 && !p.accumulate) return launch_p4<NI, P8_EPI_PLAIN_BF16>(p, st);
   if (no_extras && p.epilogue == SSAK_EPI_GELU && !p.aux_out && !p.out_f32) return launch_p4<NI, P8_EPI_GELU_ONLY>(p, st);
-  return launch_p4<NI, -1>(p, st);
+  if constexpr (NI == 8) {
+    // the general epilogue form on a 256-row tile needs scratch inside the K loop (ssak_gemm_p4_supports never plans it: not built)
+    ssak_set_error("gemm_p4: the general epilogue form is built for 128- and 192-row tiles");
+    return SSAK_ERR_INVALID;
+  } else {
+    return launch_p4<NI, -1>(p, st);
+  }
 }
 
 }  // namespace

@@ -197,9 +197,6 @@ int ssak_gemm_ticket_slot(hipStream_t st, int** out);
 // gemm_p4.hip: the same tiles with four waves and a hand-scheduled main loop (K-contiguous operands, K % 64 == 0, N % 256 == 0)
 bool ssak_gemm_p4_supports(const void* params, int bm, int a_km, int b_km);
 int ssak_gemm_p4_launch(const void* params, int bm, int b_km, hipStream_t st);
-// gemm_c4.hip: 128 x 256 tiles, two co-resident four-wave workgroups per CU (the epilogue-heavy K-contiguous products)
-bool ssak_gemm_c4_supports(const void* params, int a_km, int b_km);
-int ssak_gemm_c4_launch(const void* params, hipStream_t st);
 // B-direct form: params->B = the fragment-ordered copy (k_gemm_fragment_b_batched), params->ext_b its bytes
 int ssak_gemm_p8bd_launch(const void* params, int bm, hipStream_t st);
 size_t k_gemm_fragment_b_bytes(int N, int K);

@@ -65,6 +65,7 @@ def _load():
         "ssak_ctc_loss_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]),
         "ssak_ctc_greedy_decode": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "ssak_read_ranges": (i32, [vp, vp, vp, vp, i32, i32]),
+        "ssak_drop_file_cache": (i32, [vp, i32]),
         "ssak_pcm_to_mono_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
         "ssak_resample_plan": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "ssak_resample_table": (i32, [i32, i32, vp]),

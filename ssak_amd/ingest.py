@@ -25,10 +25,11 @@ from . import hip
 
 class WavInfo:
     """Where the PCM samples of a RIFF / WAVE file sit: parsed once per path (RIFF chunk walk), cached."""
-    __slots__ = ("sample_rate", "channels", "sample_width", "data_offset", "frames")
+    __slots__ = ("sample_rate", "channels", "sample_width", "data_offset", "frames", "sig")
 
     def __init__(self, sample_rate, channels, sample_width, data_offset, frames):
         self.sample_rate, self.channels, self.sample_width, self.data_offset, self.frames = sample_rate, channels, sample_width, data_offset, frames
+        self.sig = None  # (st_mtime_ns, st_size) of the file the header was read from: a rewritten file is parsed again
 
 
 _WAV_CACHE: dict = {}
@@ -40,7 +41,12 @@ def wav_info(path: str) -> WavInfo:
     it (sample rate, channels, frames: ssak/utils/audio.py:64-92).  RuntimeError for anything else, as audio.py:49-55 raises."""
     info = _WAV_CACHE.get(path)
     if info is not None:
-        return info
+        try:  # one stat (~1 us) per visit: a file rewritten between epochs must not keep its old frame count / data offset
+            st0 = os.stat(path)
+            if info.sig == (st0.st_mtime_ns, st0.st_size):
+                return info
+        except OSError:
+            pass  # gone or unreadable: the open below raises the reference's error
     # one open, one 4 KiB read (the fmt and data chunk headers of nearly every file), one fstat: the header walk costs as much as
     # reading a cached 320 KB file when it takes a buffered open, three seeks and four reads
     try:
@@ -96,9 +102,16 @@ def wav_info(path: str) -> WavInfo:
         raise RuntimeError(f"Could not read {path} as PCM WAV (sox/ffmpeg decoding is not built): {err}") from err
     finally:
         os.close(fd)
+    info.sig = (st.st_mtime_ns, st.st_size)
     with _WAV_LOCK:
         _WAV_CACHE[path] = info
     return info
+
+
+def clear_wav_cache() -> None:
+    """Forget every parsed header (tests; a caller that knows its folder changed)."""
+    with _WAV_LOCK:
+        _WAV_CACHE.clear()
 
 
 def segment_range(info: WavInfo, start: Optional[float], end: Optional[float]) -> Tuple[int, int]:
@@ -162,7 +175,7 @@ class DeviceIngest:
         to the same buffer, so that the batch's ONE H2D copy carries them too (a ``labels.to(device)`` from pageable memory on
         the compute stream blocks the host until the previous step has drained)."""
         paths = [p for p, _, _ in items]
-        infos = [_WAV_CACHE.get(p) or wav_info(p) for p in paths]  # (first visit: ~10 us per header, cheaper here than a hand-off)
+        infos = [wav_info(p) for p in paths]  # (first visit: ~10 us per header, later ones one stat: cheaper here than a hand-off)
         ranges = [segment_range(i, s, e) for i, (_, s, e) in zip(infos, items)]
         sizes = [cnt * i.channels * i.sample_width for i, (_, cnt) in zip(infos, ranges)]
         audio = sum(sizes)
@@ -278,16 +291,22 @@ class BatchPrefetcher:
         ahead = None
         while True:
             item = self.q.get()
-            if isinstance(item, BaseException):
-                raise item
-            nxt = None if item is None else self.ingest.to_device_async(item)
+            err = item if isinstance(item, BaseException) else None
+            nxt = None
+            if err is None and item is not None:
+                try:
+                    nxt = self.ingest.to_device_async(item)
+                except BaseException as e:  # noqa: BLE001 -- re-raised below, after the batch already in flight was handed out
+                    err = e
             if ahead is not None:
                 out, ev = ahead
                 cur = torch.cuda.current_stream(self.ingest.device)
                 cur.wait_event(ev)
                 for t in out:
                     t.record_stream(cur)  # (allocated on the ingest's stream, consumed on the caller's)
-                yield out
+                yield out  # (batch k is complete whatever happened to batch k + 1: the consumer runs its step before the error)
+            if err is not None:
+                raise err
             if item is None:
                 return
             ahead = nxt

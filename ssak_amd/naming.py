@@ -44,7 +44,7 @@ def _compact(value) -> str:
 # options that do not enter the name: without influence on the result, or handled by a suffix / the data hash
 _NOT_NAMED = frozenset(("verbose", "disable_first_eval", "output_dir", "gpus", "eval_steps", "num_epochs", "data_augment_noise",
                         "data_augment_rir", "train", "valid", "debug", "online", "no_freeze", "data_augment",
-                        "batch_audio", "skip_unused_layers"))  # (the last two: this build's extensions, never part of the reference's name)
+                        "batch_audio", "batch_audio_max_utts", "skip_unused_layers"))  # (the last three: this build's extensions, never part of the reference's name)
 _N_DATA_OPTIONS = 8  # train, valid, debug, gpus, online, max_duration, min_duration, base_model: not learning hyper-parameters
 
 

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -60,6 +61,68 @@ def test_read_ranges_reads_and_reports(tmp_path):
     assert one(os.fsencode(str(tmp_path / "nope.bin")), 0, 8) == h.SSAK_ERR_INVALID and b"nope.bin" in h.lib.ssak_last_error()
     assert one(paths[0], 990, 64) == h.SSAK_ERR_INVALID and b"short read" in h.lib.ssak_last_error()
     assert h.lib.ssak_read_ranges(None, None, None, None, 0, 4) == h.SSAK_OK
+
+
+def test_read_ranges_pool_is_reused_and_takes_concurrent_callers(tmp_path):
+    """The reader threads are a process-wide pool that outlives a call: hundreds of calls with changing thread counts, from several
+    Python threads at once (two ingests take turns), and in a forked child (which starts over with an empty pool) all read the
+    right bytes; ssak_drop_file_cache leaves the files readable."""
+    import threading
+
+    import numpy as np
+    import ssak_amd.hip as h
+    rng = np.random.default_rng(1)
+    blobs, paths = [], []
+    for i in range(24):
+        b = rng.integers(0, 256, 5000 + 11 * i, dtype=np.uint8)
+        p = tmp_path / f"g{i}.bin"
+        p.write_bytes(b.tobytes())
+        blobs.append(b)
+        paths.append(os.fsencode(str(p)))
+
+    def once(threads, sel):
+        n = len(sel)
+        size = [len(blobs[i]) for i in sel]
+        pos = np.cumsum([0] + size[:-1])
+        buf = np.zeros(sum(size), dtype=np.uint8)
+        rc = h.lib.ssak_read_ranges((ctypes.c_char_p * n)(*[paths[i] for i in sel]), (ctypes.c_int64 * n)(*([0] * n)), (ctypes.c_int64 * n)(*size),
+                                    (ctypes.c_void_p * n)(*[buf.ctypes.data + int(q) for q in pos]), n, threads)
+        return rc == h.SSAK_OK and all((buf[pos[k]:pos[k] + size[k]] == blobs[i]).all() for k, i in enumerate(sel))
+
+    ok = []
+
+    def caller(seed):
+        r = np.random.default_rng(seed)
+        for _ in range(100):
+            sel = r.choice(24, int(r.integers(1, 24)), replace=False).tolist()
+            ok.append(once(int(r.integers(1, 17)), sel))
+
+    ts = [threading.Thread(target=caller, args=(s,)) for s in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(ok) == 400 and all(ok)
+    n = len(paths)
+    assert h.lib.ssak_drop_file_cache((ctypes.c_char_p * n)(*paths), n) == 0
+    assert once(8, list(range(24)))
+    pid = os.fork()
+    if pid == 0:  # the child has none of the pool's threads
+        os._exit(0 if once(8, list(range(24))) and once(3, [5, 6, 7]) else 1)
+    assert os.waitpid(pid, 0)[1] == 0
+
+
+def test_no_scratch_inside_the_matrix_loops():
+    """Register spills where they would hurt.  The persistent GEMMs carry a few spilled registers in their per-tile prologue /
+    epilogue blocks (harmless, outside the K loop); one more live value in the loop and `-Rpass-analysis` would look the same.
+    tools/loop_scratch.py disassembles the device code of the BUILT library and finds, per gemm_p4 / gemm_p8 / attention
+    instantiation, the innermost loops that contain MFMAs: none of them may hold a scratch instruction."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import loop_scratch
+    rows = loop_scratch.check()
+    assert len(rows) >= 40 and all(nl >= 1 for _, _, _, nl in rows), "expected every hot instantiation with its K loop"
+    bad = [(n, inside) for n, _, inside, _ in rows if inside]
+    assert not bad, f"scratch instructions inside K loops: {bad}"
 
 
 def test_base_gradient_buckets_cover_the_trainable_range():

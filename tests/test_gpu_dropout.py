@@ -266,3 +266,65 @@ def test_base_regularisers_on_vs_patched_hf(gold, exact):
             worst = (n, e)
     print("   full tensors vs the CPU oracle: worst", worst)
     assert worst[1] < (5e-3 if exact else 6e-2)
+
+
+@pytest.mark.parametrize("strength", ["script", "strong"])
+def test_regularised_training_dynamics(strength):
+    """The contract of the dropout masks is statistical, so test the statistic that matters: TRAINING with the engine's own masks
+    (one-multiply counter hash, rank-one words) behaves like training with torch's generator.  Tiny config, regularisers ON (the
+    train script's rates, wav2vec_train.py:161-165 -- and a stronger setting where the masks carry more of the noise), 200 optimizer
+    steps from the same init on the same batch, 5 seeds each: the engine (bf16 kernels, its masks, its SpecAugment / LayerDrop
+    draws) against the CPU oracle (eager torch fp32, torch's dropout generator, the same host draws from another seed).  Per
+    20-step window the two 5-seed mean losses differ by less than 3 standard errors of the seeds' spread plus the 2 % the bf16
+    matched-loss bar allows -- a generator whose masks were correlated enough to change the regularisation would shift the curve."""
+    from oracle import w2v2_ref as R
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.trainer import AdamW, Trainer, linear_warmup_lr
+    import dataclasses
+    kw = {} if strength == "script" else dict(attention_dropout=0.3, hidden_dropout=0.2, activation_dropout=0.3, final_dropout=0.2)
+    oc = R.W2V2Config.tiny(**kw)
+    d = dataclasses.asdict(oc)
+    d.pop("initializer_range")
+    p0 = R.init_params(oc, 13)
+    rng = np.random.default_rng(0)
+    x = R.zero_mean_unit_var_norm([rng.standard_normal(8000).astype(np.float32) for _ in range(4)])
+    labels = R.pad_labels([list(rng.integers(1, 32, n)) for n in (6, 4, 7, 5)])
+    steps, lr, warm, seeds, win = 200, 1e-3, 5, 5, 20
+    F = 24  # frames of 8000 samples
+    names = R.trainable_names(oc)
+    ref = np.zeros((seeds, steps))
+    for s in range(seeds):
+        torch.manual_seed(1000 + s)
+        rs = np.random.RandomState(2000 + s)
+        q = {n: (t.clone().requires_grad_(n in names)) for n, t in p0.items()}
+        opt = torch.optim.AdamW([q[n] for n in names], lr=lr, weight_decay=0.0)
+        for k in range(steps):
+            for g in opt.param_groups:
+                g["lr"] = linear_warmup_lr(lr, k, warm, 1000)
+            mask = torch.tensor(R.compute_mask_indices((4, F), oc.mask_time_prob, oc.mask_time_length, None, oc.mask_time_min_masks, rng=rs))
+            keep = rs.rand(oc.num_hidden_layers) >= oc.layerdrop
+            loss, logits = R.forward(q, oc, torch.tensor(x), None, torch.tensor(labels), train=True, mask_time_indices=mask, layer_keep=keep)
+            assert logits.shape[1] == F
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([q[n] for n in names], 1.0)
+            opt.step()
+            ref[s, k] = loss.item()
+    got = np.zeros((seeds, steps))
+    xd, ld = torch.tensor(x).cuda(), torch.tensor(labels).cuda()
+    for s in range(seeds):
+        model = Wav2Vec2ForCTC(Wav2Vec2Config(**d), seed=3000 + s).train()
+        model.load_state_dict(p0)
+        tr = Trainer(model, AdamW(model, lr=lr, warmup_steps=warm, total_steps=1000, max_grad_norm=1.0))
+        losses = [tr.train_step(xd, None, ld, raw=False) for _ in range(steps)]
+        got[s] = torch.stack(losses).reshape(-1).cpu().numpy()
+    assert ref[:, -win:].mean() < 0.8 * ref[:, :win].mean() and got[:, -win:].mean() < 0.8 * got[:, :win].mean()  # both learn
+    worst = 0.0
+    for w in range(steps // win):
+        a, b = got[:, w * win:(w + 1) * win].mean(1), ref[:, w * win:(w + 1) * win].mean(1)  # per-seed window means
+        se = np.sqrt(a.var(ddof=1) / seeds + b.var(ddof=1) / seeds)
+        tol = 3.0 * se + 0.02 * abs(b.mean())
+        worst = max(worst, abs(a.mean() - b.mean()) / tol)
+        assert abs(a.mean() - b.mean()) < tol, (strength, w, float(a.mean()), float(b.mean()), float(se))
+    print(f"dynamics ({strength}): engine last-window mean {got[:, -win:].mean():.4f}, oracle {ref[:, -win:].mean():.4f}, worst window at {worst:.2f} of its bar")

@@ -100,3 +100,37 @@ def test_ingest_prefetcher_carries_labels_and_runs_one_batch_ahead(tmp_path):
     for (w, l, y), (ww, wl), lab in zip(got, want, labels):
         assert torch.equal(w, ww) and torch.equal(l, wl)
         assert y.dtype == torch.int64 and np.array_equal(y.cpu().numpy(), lab)
+
+
+def test_ingest_prefetcher_hands_out_the_batch_in_flight_before_a_later_error(tmp_path):
+    """A bad file in batch k + 1 must not swallow batch k (whose H2D copy is already issued): the consumer gets batch k, runs its
+    step, and sees the error at the next fetch -- under data parallelism every rank then stops at the same collective."""
+    from ssak_amd.ingest import BatchPrefetcher, DeviceIngest
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(4):
+        p = str(tmp_path / f"x{i}.wav")
+        _write(p, _signal(rng, 16000 + 100 * i, 16000), 16000)
+        paths.append((p, None, None))
+    batches = [paths[:2], paths[2:], [(str(tmp_path / "missing.wav"), None, None)], paths[:2]]
+    seen = []
+    with pytest.raises(RuntimeError):
+        for w, l in BatchPrefetcher(DeviceIngest(16000), batches, depth=2):
+            seen.append(l.cpu().tolist())
+    assert seen == [[16000, 16100], [16200, 16300]]
+
+
+def test_wav_header_cache_follows_a_rewritten_file(tmp_path):
+    """The header cache is keyed on (mtime, size): a file rewritten between epochs is parsed again."""
+    from ssak_amd.ingest import DeviceIngest, clear_wav_cache, wav_info
+    rng = np.random.default_rng(4)
+    p = str(tmp_path / "r.wav")
+    _write(p, _signal(rng, 16000, 16000), 16000)
+    assert wav_info(p).frames == 16000
+    _write(p, _signal(rng, 12345, 16000), 16000)
+    os.utime(p, ns=(1, 1))  # (even with a coarse clock the size differs; this also covers an mtime going backwards)
+    assert wav_info(p).frames == 12345
+    w, l = DeviceIngest(16000, normalize=False).load_batch([(p, None, None)])
+    assert l.cpu().tolist() == [12345]
+    clear_wav_cache()
+    assert wav_info(p).frames == 12345

@@ -342,6 +342,54 @@ def test_dropout_mask_generator_quality(p):
     assert abs(q["row_count_var"] - 1) < 0.06 and abs(q["col_count_var"] - 1) < 0.06, q
 
 
+@pytest.mark.parametrize("site_kind,cols,p", [("hid1", 768, 0.05), ("act", 3072, 0.05), ("attn", 499, 0.1)])
+def test_dropout_masks_of_the_closest_row_pairs(site_kind, cols, p):
+    """Where the one-multiply generator is weakest: two rows' words differ by ONE fixed odd factor r = rowkey_i / rowkey_j (mod 2^32)
+    for every column, so a pair with a tiny |r| has masks that are functions of each other.  Over the 15 968 rows of a base site
+    (B = 32 x 499 frames; for the attention site the first 15 968 (utterance, head, query) rows) and two of the engine's real step
+    seeds, the 1 000 ordered row pairs with the smallest |r| are enumerated (oracle/dropout_hash.py smallest_key_ratio_pairs):
+      * every pair with |r| > 7 agrees on its keep bits like independent rows, within 4 sigma (binomial over the site's columns);
+      * the handful with |r| <= 7 follow the closed form of the structure (agreement 1 - 2p + 2p/r for r > 0, 1 - 2p for r < 0 --
+        r = +1, identical masks, needs two row hashes that differ in bit 0 only) within 4 sigma, and there are at most 8 such pairs of
+        1.3e8: at most 16 rows of 15 968 share part of their mask with another row.
+    The training-dynamics comparison against torch's generator is tests/test_gpu_dropout.py::test_regularised_training_dynamics."""
+    from oracle import dropout_hash as DH
+    rows = 15968
+    pe = DH.thresh16(p) / 65536.0
+    q = pe * pe + (1 - pe) ** 2
+    sig = np.sqrt(q * (1 - q) / cols)
+    for layer, seed in zip((3, 7), DH.step_seed_sequence(69, 2)):
+        site = {"hid1": DH.ds_hid1, "act": DH.ds_act, "attn": DH.ds_attn}[site_kind](layer)
+        r, i, j = DH.smallest_key_ratio_pairs(seed, site, rows, top=1000)
+        assert len(r) == 1000 and (np.abs(r[:-1]) <= np.abs(r[1:])).all() and (r % 2 != 0).all()
+        agree = DH.keep_agreement(seed, site, i, j, cols, p)
+        far = np.abs(r) > 7
+        z = (agree[far] - q) / sig
+        assert np.abs(z).max() < 4.0, (site_kind, hex(seed), float(np.abs(z).max()), int(r[far][np.argmax(np.abs(z))]))
+        near = ~far
+        assert near.sum() <= 8, (site_kind, hex(seed), r[near].tolist())
+        for rr, a in zip(r[near], agree[near]):
+            want = DH.ratio_agreement_expected(int(rr), p)
+            assert abs(a - want) < 4.0 * np.sqrt(max(want * (1 - want), 1e-4) / cols), (site_kind, hex(seed), int(rr), float(a), want)
+
+
+def test_dropout_ratio_structure_closed_form():
+    """The closed form used above, on constructed keys: words w and r w (mod 2^32) for uniform w agree on their keep bits with
+    probability 1 - 2p + 2p/r (r = 3, 5, 7), 1 - 2p (r < 0); from |r| ~ 1/p on the excess over independence is below 2 p^2."""
+    from oracle import dropout_hash as DH
+    rng = np.random.default_rng(5)
+    w = rng.integers(0, 1 << 32, 2_000_000, dtype=np.uint64)
+    for p in (0.05, 0.1):
+        t = np.uint64(DH.thresh16(p) << 16)
+        pe = DH.thresh16(p) / 65536.0
+        for r in (3, 5, 7, -1, -3, 21, 101):
+            w2 = (w * np.uint64(r % (1 << 32))) & np.uint64(0xFFFFFFFF)
+            a = float(((w >= t) == (w2 >= t)).mean())
+            if abs(r) * pe < 1:
+                assert abs(a - DH.ratio_agreement_expected(r, p)) < 1e-3, (p, r, a)
+            assert a - (pe * pe + (1 - pe) ** 2) < 2 * pe / abs(r) + 1e-3
+
+
 KNOWN_COLMUL = [4102127511, 2960243731, 3929676619, 1507823451]
 KNOWN_ROWKEY = [2898601965, 3335941947, 1865774827]
 KNOWN_MASK = [[1, 1, 1, 1, 0, 1, 1, 0], [1, 0, 0, 1, 0, 1, 1, 1], [1, 1, 1, 1, 0, 1, 0, 1], [1, 1, 1, 1, 1, 1, 0, 0], [1, 1, 0, 0, 1, 1, 0, 1]]

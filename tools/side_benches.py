@@ -296,6 +296,29 @@ def ingest_rate(N=1024, sr=16000, nch=1, B=32):
     for w, l in BatchPrefetcher(ing, batches[:2]):
         pass
     torch.cuda.synchronize()
+    # cold pass first: the files were written a moment ago and sit in the page cache -- fdatasync + posix_fadvise(DONTNEED) on each
+    # (ssak_drop_file_cache) sends the next read to the storage device.  (On a memory-backed file system the advice is a no-op and the
+    # two figures coincide: `fs_type` says what /tmp is.)
+    import ctypes
+    from ssak_amd import hip
+    from ssak_amd.ingest import clear_wav_cache
+    c_paths = (ctypes.c_char_p * N)(*[os.fsencode(p) for p, _, _ in items])
+    not_dropped = hip.lib.ssak_drop_file_cache(c_paths, N)
+    clear_wav_cache()
+    t0 = time.perf_counter()
+    for w, l in BatchPrefetcher(ing, batches, depth=3):
+        pass
+    torch.cuda.synchronize()
+    dt_cold = time.perf_counter() - t0
+    fs_type = "?"
+    try:
+        best = ""
+        for line in open("/proc/mounts"):
+            f = line.split()
+            if d.startswith(f[1]) and len(f[1]) > len(best):
+                best, fs_type = f[1], f[2]
+    except OSError:
+        pass
     t0 = time.perf_counter()
     for w, l in BatchPrefetcher(ing, batches, depth=3):
         pass
@@ -307,4 +330,222 @@ def ingest_rate(N=1024, sr=16000, nch=1, B=32):
     return {"path": "Kaldi-style wav.scp entries -> PCM16 WAV read -> device decode / mono / resample -> ssak_wave_normalize -> batches of "
                     f"{B} (ssak_amd/ingest.py: {readers} native reader threads pread into a pinned ring (ssak_read_ranges), prefetch depth 3)",
             "utterances_per_sec": round(N / dt, 1), "files": N, "reader_threads": readers,
+            "warm": {"utterances_per_sec": round(N / dt, 1), "mb_per_sec": round(N * 10 * sr * nch * 2 / dt / 1e6, 1), "what": "second pass: page-cache reads"},
+            "cold": {"utterances_per_sec": round(N / dt_cold, 1), "mb_per_sec": round(N * 10 * sr * nch * 2 / dt_cold / 1e6, 1),
+                     "what": "first pass after fdatasync + posix_fadvise(DONTNEED) on every file (ssak_drop_file_cache) and with the header cache "
+                             "cleared: reads come from the storage device", "files_not_dropped": int(not_dropped), "fs_type": fs_type},
             "source": f"{sr} Hz x {nch} ch, 10 s"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The ssak/infer entry point and the f-rows (forced alignment, evaluation metric) on the driver's clock: secondary[2..4].
+GF_FORWARD_PER_UTT = 148.16  # Wav2Vec2-base forward, 10 s utterance
+
+
+def _cpu_cores():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.host_cores()
+
+
+def infer_line(B=32, steps=20, warmup=3, device="cuda:0", cpu_batch=4, cpu_steps=3):
+    """The `ssak/infer` hot path (ssak/infer/transformers_infer.py:190-269: processor -> model(...).logits -> argmax / batch_decode,
+    :84-85) at B x 10 s: ssak_wave_normalize -> Wav2Vec2-base eval forward -> ssak_ctc_greedy_decode, inputs resident in HBM.
+    Beside it the CPU restatement's eval-mode forward (oracle/w2v2_ref.py, eager torch fp32 on all host cores) + argmax + collapse
+    on a bounded sample."""
+    from ssak_amd import hip
+    from ssak_amd.config import Wav2Vec2Config
+    from ssak_amd.model import Wav2Vec2ForCTC
+    from ssak_amd.synth import synth_batch
+    cfg = Wav2Vec2Config()
+    model = Wav2Vec2ForCTC(cfg, device=device, seed=69).eval()
+    model.load_state_dict(_w2v2_state(model))
+    waves_np = synth_batch(B, 160000, seed=1)[0]
+    waves = torch.tensor(waves_np).to(device)
+
+    def step():
+        x = hip.wave_normalize(waves, None)
+        out = model(x)
+        return hip.ctc_greedy_decode(out.logits.contiguous(), None, cfg.pad_token_id)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ids, n = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # latency of ONE utterance (the reference's `compute_logits(model, audio)` for a single file, ssak/infer/general.py:76-97)
+    one = waves[:1].contiguous()
+    for _ in range(3):
+        hip.ctc_greedy_decode(model(hip.wave_normalize(one, None)).logits.contiguous(), None, cfg.pad_token_id)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        hip.ctc_greedy_decode(model(hip.wave_normalize(one, None)).logits.contiguous(), None, cfg.pad_token_id)
+    torch.cuda.synchronize()
+    lat = (time.perf_counter() - t1) / 10
+    tf = GF_FORWARD_PER_UTT * B / dt / 1e3
+    out = {"workload": "ssak/infer path: ssak_wave_normalize -> Wav2Vec2-base eval forward (bf16) -> ssak_ctc_greedy_decode, "
+                       f"B = {B} x 10 s utterances resident in HBM (transformers_infer.py:190-269, :84-85)",
+           "value": round(B / dt, 1), "unit": "utterances/sec", "batch": B, "steps": steps, "ms_per_batch": round(dt * 1e3, 3),
+           "real_time_factor": round(dt / (10.0 * B), 7), "audio_sec_per_sec": round(10.0 * B / dt, 1),
+           "single_utterance_latency_ms": round(lat * 1e3, 3),
+           "whole_forward_tflops": round(tf, 1), "whole_forward_frac": round(tf / PEAK_BF16_TFLOPS, 4),
+           "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                        "algorithmic_gflop_per_utt": GF_FORWARD_PER_UTT}}
+    del model
+    torch.cuda.empty_cache()
+    try:
+        from oracle import w2v2_ref as R
+        cores = _cpu_cores()
+        torch.set_num_threads(cores)
+        oc = R.W2V2Config.base()
+        p = R.init_params(oc, 69)
+        x = torch.tensor(R.zero_mean_unit_var_norm(list(waves_np[:cpu_batch])))
+        ts = []
+        with torch.no_grad():
+            for k in range(1 + cpu_steps):
+                t2 = time.perf_counter()
+                _, logits = R.forward(p, oc, x, None, None, train=False)
+                pred = logits.argmax(-1).numpy()
+                for row in pred:  # greedy collapse: repeats merged, blanks dropped (batch_decode's group_tokens)
+                    keep = np.concatenate([[True], row[1:] != row[:-1]]) & (row != oc.pad_token_id)
+                    row[keep]
+                ts.append(time.perf_counter() - t2)
+        med = sorted(ts[1:])[len(ts[1:]) // 2]
+        out["cpu_baseline"] = {"value": round(cpu_batch / med, 3), "unit": "utterances/sec", "cores": cores, "kind": "port",
+                               "sample": f"1 warm-up + {cpu_steps} eval forwards of oracle/w2v2_ref.py (eager torch fp32) + argmax + collapse, "
+                                         f"B = {cpu_batch} x 10 s, median {med:.2f} s"}
+    except Exception as e:  # the baseline leg must not take the line down
+        out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def align_line(n=32, F=1500, L=300, V=32, reps=20, device="cuda:0", cpu_utts=2):
+    """Forced alignment (ssak/utils/align_transcriptions.py:27-123 called per utterance from :294-402):
+    ssak_ctc_forced_align_batch on n x (F frames, L tokens), emissions and tokens resident in HBM, HIP events on the launch stream.
+    Beside it the reference's host loop (a Python loop of torch CPU ops over the frames + the backtrack walk), timed on a few
+    utterances of the same batch."""
+    from ssak_amd import hip
+    g = torch.Generator().manual_seed(F + L)
+    em = torch.log_softmax(torch.randn(n, F, V, generator=g) * 2.0, -1)
+    tok = torch.randint(1, V, (n, L), generator=g, dtype=torch.int32)
+    em_d, tok_d = em.to(device), tok.to(device)
+    fl = torch.full((n,), F, dtype=torch.int32, device=device)
+    tl = torch.full((n,), L, dtype=torch.int32, device=device)
+    path_token = torch.empty((n, F), dtype=torch.int32, device=device)
+    path_logp = torch.empty((n, F), dtype=torch.float32, device=device)
+    info = torch.empty((n, 2), dtype=torch.int32, device=device)
+    ws = torch.empty(hip.lib.ssak_ctc_align_batch_workspace_bytes(n, F, L), dtype=torch.uint8, device=device)
+
+    def launch():
+        hip.check(hip.lib.ssak_ctc_forced_align_batch(hip.ptr(em_d), hip.ptr(fl), hip.ptr(tok_d), hip.ptr(tl), n, F, V, L, 0, None, None,
+                                                      hip.ptr(path_token), hip.ptr(path_logp), hip.ptr(info), hip.ptr(ws), ws.numel(), hip.stream()))
+
+    with torch.cuda.device(device):
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    cnt = info.cpu().numpy()[:, 0]
+    algo_bytes = n * (F * V * 4 + L * 4 + F * 8)  # emissions in, tokens in, path (token, log-prob) out
+    out = {"workload": f"ssak_ctc_forced_align_batch: {n} utterances x ({F} frames, {L} tokens, V = {V}), Viterbi trellis + backtrack in "
+                       "one launch, one workgroup per utterance (align_transcriptions.py:27-123)",
+           "value": round(n / (us * 1e-6), 1), "unit": "utterances/sec", "us_per_launch": round(us, 1), "us_per_utterance": round(us / n, 2),
+           "us_per_frame": round(us / F, 4), "aligned": int((cnt >= 0).sum()), "utterances": n,
+           "roofline": {"bound": "latency", "note": "F sequential lattice steps per utterance; one workgroup (one CU) per utterance",
+                        "achieved": round(n / (us * 1e-6) / min(n, 256), 1), "unit": "utterances/s/CU", "peak": None, "frac": None,
+                        "cus_busy": min(n, 256), "cus": 256, "hbm_gbs": round(algo_bytes / (us * 1e-6) / 1e9, 2),
+                        "algorithmic_mb_per_launch": round(algo_bytes / 1e6, 2)},
+           "timed_with": "HIP events on the launch stream around the launches"}
+    try:
+        from oracle import align_ref
+        from oracle.gen_golden_align import backtrack_torch, trellis_torch
+        torch.set_num_threads(_cpu_cores())
+        ts, same = [], True
+        pt_h, info_h = path_token.cpu().numpy(), info.cpu().numpy()
+        for i in range(cpu_utts):
+            t0 = time.perf_counter()
+            tr = trellis_torch(em[i], tok[i].tolist(), 0)
+            path = backtrack_torch(tr, em[i], tok[i].tolist(), 0)
+            ts.append(time.perf_counter() - t0)
+            c, first = int(info_h[i, 0]), int(info_h[i, 1])
+            same = same and path is not None and c == len(path) and first == path[0][1] and [p[0] for p in path] == pt_h[i, first:first + c].tolist()
+        med = sorted(ts)[len(ts) // 2]
+        out["cpu_baseline"] = {"value": round(1.0 / med, 3), "unit": "utterances/sec", "cores": _cpu_cores(), "kind": "port",
+                               "ms_per_utterance": round(med * 1e3, 1), "device_path_identical": bool(same),
+                               "sample": f"{cpu_utts} utterances of the same batch through the reference's per-frame loop of torch CPU ops "
+                                         "(get_trellis + backtrack as oracle/gen_golden_align.py restates them; that file pins them to the "
+                                         "reference's own functions bit for bit)"}
+        del align_ref
+    except Exception as e:
+        out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def wer_line(B=32, F=499, reps=50, device="cuda:0"):
+    """Evaluation metric on the device (compute_metrics of wav2vec_train.py:107-125 pulls the logits to the host,
+    argmaxes in numpy and scores strings): ssak_ctc_greedy_decode + ssak_ctc_wer on an eval batch of logits resident in HBM; only
+    two integers per utterance would cross to the host.  The CPU restatement (oracle/wer_ref.py) on the same batch beside it."""
+    from ssak_amd import hip
+    from ssak_amd.metrics import token_classes
+    from ssak_amd.synth import VOCAB, synth_text, text_to_ids
+    rng = np.random.default_rng(7)
+    V = len(VOCAB)
+    refs = [text_to_ids(synth_text(rng, 60, 120)) for _ in range(B)]
+    Lm = max(len(r) for r in refs)
+    labels = np.full((B, Lm), -100, np.int64)
+    logits = rng.standard_normal((B, F, V)).astype(np.float32)
+    for b, r in enumerate(refs):
+        labels[b, :len(r)] = r
+        hyp = list(r)
+        for k in rng.choice(len(hyp), max(1, len(hyp) // 10), replace=False):  # ~10 % character errors
+            hyp[k] = int(rng.integers(5, V))
+        pos = np.sort(rng.choice(F // 2, len(hyp), replace=False)) * 2  # (a blank frame between any two emitted tokens)
+        logits[b, :, 0] += 6.0
+        logits[b, pos, 0] -= 6.0
+        logits[b, pos, hyp] += 8.0
+    lg, lab = torch.tensor(logits).to(device), torch.tensor(labels).to(device)
+    cls = token_classes(VOCAB).to(device)
+
+    def step():
+        ids, n = hip.ctc_greedy_decode(lg, None, 0)
+        return hip.ctc_wer(ids, n, lab, cls)
+
+    with torch.cuda.device(device):
+        for _ in range(3):
+            step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            edits, nref = step()
+        e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    e_h, r_h = edits.cpu().numpy(), nref.cpu().numpy()
+    algo_bytes = B * (F * V * 4 + Lm * 4 + 8)
+    out = {"workload": f"ssak_ctc_greedy_decode + ssak_ctc_wer on an eval batch: {B} x [{F}, {V}] fp32 logits in HBM, {Lm}-token references "
+                       "(compute_metrics, wav2vec_train.py:107-125)",
+           "value": round(B / (us * 1e-6), 1), "unit": "utterances/sec", "us_per_batch": round(us, 1), "wer": round(float(e_h.sum()) / max(1, int(r_h.sum())), 4),
+           "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (us * 1e-6) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(algo_bytes / (us * 1e-6) / 1e9 / 8000.0, 5), "algorithmic_mb_per_batch": round(algo_bytes / 1e6, 2),
+                        "note": "two launches of a few microseconds on a 2 MB batch: launch-latency-bound, not bandwidth-bound"},
+           "timed_with": "HIP events on the launch stream around (decode, wer) pairs"}
+    try:
+        from oracle import wer_ref
+        t0 = time.perf_counter()
+        ce, cr, cw = wer_ref.compute_metrics(logits.argmax(-1), labels, VOCAB, 0)
+        dc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(B / dc, 1), "unit": "utterances/sec", "cores": 1, "kind": "port", "ms_per_batch": round(dc * 1e3, 2),
+                               "counts_identical": bool(np.array_equal(ce, e_h) and np.array_equal(cr, r_h)),
+                               "sample": "the same batch through oracle/wer_ref.py (numpy argmax + the reference's string pipeline + word-level edit distance)"}
+    except Exception as e:
+        out["cpu_baseline"] = {"error": repr(e)}
+    return out
