@@ -396,15 +396,23 @@ def main():
             tf_s = gf_per_utt(kept_s) * 1e9 * Bs * n_s / ds / 1e12
             sweep.append({"per_gpu_batch": Bs, "value": round(Bs * n_s / ds, 2), "ms_per_step": round(ds / n_s * 1e3, 3), "steps": n_s,
                           "whole_step_tflops": round(tf_s, 1), "whole_step_frac": round(tf_s / PEAK_BF16_TFLOPS, 4)})
-        # and the un-folded step (ssak_wave_normalize as its own pass, what a padded batch takes) beside the folded headline
+        # and the un-folded step (ssak_wave_normalize as its own pass, what a padded batch takes) beside the folded one: alternating
+        # blocks of ten steps on the same clock state (the boxes drift by a per cent over a second; a single pair of runs read as noise)
+        t_fold = t_own = 0.0
         for _ in range(2):
             trainer.train_step(waves, None, labels, fold_norm=False)
-        sync()
-        ts = time.perf_counter()
-        for _ in range(20):
-            trainer.train_step(waves, None, labels, fold_norm=False)
-        sync()
-        unfolded_ms = (time.perf_counter() - ts) / 20 * 1e3
+        for _ in range(3):
+            for own in (False, True):
+                sync()
+                ts = time.perf_counter()
+                for _ in range(10):
+                    trainer.train_step(waves, None, labels, fold_norm=False if own else None)
+                sync()
+                if own:
+                    t_own += time.perf_counter() - ts
+                else:
+                    t_fold += time.perf_counter() - ts
+        folded_ms, unfolded_ms = t_fold / 30 * 1e3, t_own / 30 * 1e3
     if rank == 0:
         utts = B * world * args.steps
         value = utts / dt
@@ -519,10 +527,10 @@ def main():
             out["headline_sweep"] = {"rows": rows, "best_per_gpu_batch": max(rows, key=lambda r: r["value"])["per_gpu_batch"],
                                      "note": f"SURVEY.md 8d: B in {{8, 16, 32}}, report best; `value` is the B = {B} line (the timed region), the others are "
                                              "30-step runs of the same model right after it"}
-            out["normalisation"] = {"folded_ms_per_step": round(dt / args.steps * 1e3, 3), "own_pass_ms_per_step": round(unfolded_ms, 3),
+            out["normalisation"] = {"folded_ms_per_step": round(folded_ms, 3), "own_pass_ms_per_step": round(unfolded_ms, 3),
                                     "note": "the headline batch is un-padded (every utterance fills T), so ssak_amd.train and this bench fold the waveform "
                                             "normalisation (a1) into conv0's GroupNorm statistics; padded / ragged batches and the layer-norm topology run "
-                                            "ssak_wave_normalize as a pass of its own (second figure, 20 steps)"}
+                                            "ssak_wave_normalize as a pass of its own (both figures: three alternating blocks of ten steps each, after the timed region)"}
         if world == 1 and not args.no_secondary:
             # BASELINE.json configs[3] / configs[4] and the ingest path on the same clock as the headline (their models are built after
             # the headline's timed region; its buffers are released first)

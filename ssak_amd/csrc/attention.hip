@@ -60,10 +60,20 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 __device__ __forceinline__ float max_over_lane_groups(float v) {
   const unsigned b = __builtin_bit_cast(unsigned, v);
   u32x2_t t = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-  const float m = fmaxf(__builtin_bit_cast(float, t[0]), __builtin_bit_cast(float, t[1]));
+  float m;  // (asm: no canonicalising v_max x, x in front)
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(__builtin_bit_cast(float, t[0])), "v"(__builtin_bit_cast(float, t[1])));
   const unsigned c = __builtin_bit_cast(unsigned, m);
   t = __builtin_amdgcn_permlane32_swap(c, c, false, false);
-  return fmaxf(__builtin_bit_cast(float, t[0]), __builtin_bit_cast(float, t[1]));
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(float, t[0])), "v"(__builtin_bit_cast(float, t[1])));
+  return r;
+}
+// max of two without the canonicalising v_max x, x that fmaxf puts in front of values it cannot prove canonical (MFMA results,
+// lane swaps): the scores are never NaN
+__device__ __forceinline__ float max2_nc(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
 }
 // max of three without the canonicalising v_max x, x that fmaxf puts in front of every MFMA result in IEEE mode (the scores
 // are never NaN): 8 instructions for 16 values instead of 31
@@ -346,11 +356,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         if (ks < 3)
           mx = max3_nc(mx, s[qs][ks][3], s[qs][ks + 1][0]);
         else
-          mx = fmaxf(mx, s[qs][ks][3]);
+          mx = max2_nc(mx, s[qs][ks][3]);
       }
       mx = max_over_lane_groups(mx);
       // key 0 is never masked (kl >= 1 whenever a tile is processed), so the running maximum is finite from the first tile on
-      const float m_new = fmaxf(m_run[qs], mx);
+      const float m_new = max2_nc(m_run[qs], mx);
       const float mc = m_new * c2;
       const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qs], c2, -mc));  // first tile: exp2(-inf) = 0 on a zero accumulator
       f32x2 rs2 = {0.f, 0.f};  // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): the pair's two exponent arguments and the row sum

@@ -1321,11 +1321,14 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   AT* gB = nullptr;
   if (dhidden)
     SSAK_HIP(hipMemcpyAsync(gA, dhidden, (size_t)M * H * sizeof(bf16), hipMemcpyDeviceToDevice, st));
-  else
-    TRY(GemmX<EXACT>(M, H, V).a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H).run(st));
-  if (dlogits && c.final_dropout > 0.f)  // replay the final-dropout mask with the kernel that applied it in the forward
-    TRY(k_layernorm_fwd_t<AT>(gA, nullptr, nullptr, nullptr, gA, nullptr, nullptr, nullptr, M, H, 0.f, DS(c.final_dropout, DS_FINAL),
-                        none, st));
+  else {
+    // dx = (dlogits W) * mask / (1 - p): the final-dropout mask is replayed in this product's epilogue ((row, column) of the [M, H]
+    // output = the site's indices; through round 5 a pass of its own over gA, 14 us per step)
+    GemmX<EXACT> g(M, H, V);
+    g.a(dlog, V).b(W + e->p_lm_w, H, true).c(gA, H);
+    if (c.final_dropout > 0.f) g.drop(c.final_dropout, DS_FINAL, seed);
+    TRY(g.run(st));
+  }
   // ---- encoder layers, last to first.  gA (+gB) = gradient w.r.t. x[l+1], the layer output (post-LN) or the
   // normalised input of the next layer (stable-LN); Gres = gradient of the residual stream (stable-LN only).
   const bool stable = whisper || c.do_stable_layer_norm != 0;
