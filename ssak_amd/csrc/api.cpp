@@ -18,7 +18,7 @@ void ssak_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int ssak_version(void) { return 500; }  // round 5: one dropout-mask definition (row key x column multiplier), ssak_debug_dropout_mask(rows, cols)
+extern "C" int ssak_version(void) { return 510; }  // round 6: ssak_drop_file_cache, plan_tile 129 gone, conv0 statistics as (mean, rstd) (INTEGRATION.md "ABI 510")
 extern "C" const char* ssak_last_error(void) { return g_err; }
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around launches, on the launch's own stream ----

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(256) void conv0_bias_kernel(const float* __restrict
 #define C0M_HALF_SWAP 1  // (0: the round-2 store tile, for A/B builds)
 #endif
 constexpr int C0M_FR = 128;
+#ifndef C0M_SUB
+#define C0M_SUB 4  // blocks of C0M_FR frames per workgroup
+#endif
 constexpr int C0M_NS = (C0M_FR - 1) * ST0 + KS0;  // 645 input samples
 typedef __attribute__((ext_vector_type(2))) float c0_f32x2;
 
@@ -171,12 +174,18 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
   __shared__ __attribute__((aligned(16))) char ximg[C0M_FR * 64];        // per frame: xh[0..9], 0 x 6 | xl[0..9], 0 x 6 (bf16)
   __shared__ __attribute__((aligned(16))) char ostage[4][16 * 256];      // per wave: [16 frames][128 channels] bf16, 16-byte chunk ch of row r at ch ^ r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lc = lane & 15;
-  const int b = blockIdx.y, f0 = blockIdx.x * C0M_FR;
+  const int b = blockIdx.y;
   const float* xb = x + (size_t)b * T;
-  for (int i = threadIdx.x; i < C0M_NS; i += 256) {
-    const int sidx = f0 * ST0 + i;
-    xs[i] = (sidx < T) ? xb[sidx] : 0.f;
-  }
+  // A workgroup walks C0M_SUB consecutive blocks of 128 frames: the weight fragments (64 scattered loads + a hi / lo split per
+  // lane) and the GroupNorm table are set up once per C0M_SUB x 128 frames instead of once per 128 -- the set-up was a third of a
+  // workgroup's life (20 us for ~7 us of main-loop issue).  The samples of the next block are fetched while this one is computed.
+  auto load_xs = [&](int f0) {
+    for (int i = threadIdx.x; i < C0M_NS; i += 256) {
+      const int sidx = f0 * ST0 + i;
+      xs[i] = (sidx < T) ? xb[sidx] : 0.f;
+    }
+  };
+  load_xs(blockIdx.x * C0M_SUB * C0M_FR);
   for (int c = threadIdx.x; c < C; c += 256) {
     const float mu = (float)sums[((size_t)b * C + c) * 2], rs = (float)sums[((size_t)b * C + c) * 2 + 1];
     const float a = rs * gamma[c];
@@ -200,6 +209,11 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     }
   }
   __syncthreads();
+  char* const ost = ostage[wave];
+  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  for (int sub = 0; sub < C0M_SUB; ++sub) {
+  const int f0 = (blockIdx.x * C0M_SUB + sub) * C0M_FR;
+  if (f0 >= T0) break;  // uniform
   {  // [xh | xl] rows: thread = (frame, half)
     const int f = threadIdx.x >> 1, half = threadIdx.x & 1;
     bf16x8 r0, r1;
@@ -216,9 +230,18 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     *reinterpret_cast<bf16x8*>(ximg + f * 64 + half * 32) = r0;
     *reinterpret_cast<bf16x8*>(ximg + f * 64 + half * 32 + 16) = r1;
   }
-  __syncthreads();
-  char* const ost = ostage[wave];
-  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  __syncthreads();  // the frame rows are built: xs is free for the next block's samples, which land under this block's arithmetic
+  // (into registers now, into xs behind the main loop: a store to LDS here would wait for the loads on the spot)
+  constexpr int C0M_XPT = (C0M_NS + 255) / 256;
+  float nx[C0M_XPT];
+  const bool more = sub + 1 < C0M_SUB && f0 + C0M_FR < T0;
+  if (more) {
+#pragma unroll
+    for (int u = 0; u < C0M_XPT; ++u) {
+      const int i = threadIdx.x + 256 * u, sidx = (f0 + C0M_FR) * ST0 + i;
+      nx[u] = (i < C0M_NS && sidx < T) ? xb[sidx] : 0.f;
+    }
+  }
   for (int ft = 0; ft < C0M_FR / 16; ++ft) {
     if (f0 + 16 * ft >= T0) break;  // uniform
     // B operands: column = frame 16 ft + lc, k = 8 g + j of the frame's 64-byte row
@@ -284,6 +307,13 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
       const int frame = f0 + 16 * ft + r;
       if (frame < T0) *reinterpret_cast<f32x4*>(out + ((size_t)b * T0 + frame) * C + 128 * wave + 8 * lc) = v;
     }
+  }
+  if (more) {
+#pragma unroll
+    for (int u = 0; u < C0M_XPT; ++u)
+      if (threadIdx.x + 256 * u < C0M_NS) xs[threadIdx.x + 256 * u] = nx[u];
+  }
+  __syncthreads();  // every wave is done with this block's frame rows (and sees the next block's samples)
   }
 }
 
@@ -815,7 +845,7 @@ int k_conv0_gn_gelu_t(const float* x, const float* w, const float* gamma, const 
   static const bool no_mfma = SSAK_DEV_ENV("SSAK_CONV0_VALU") != nullptr;  // development: the VALU apply pass
   if constexpr (sizeof(OT) == 2) {
     if (C == 512 && !no_mfma) {
-      conv0_mfma_kernel<<<dim3(ssak_cdiv(T0, C0M_FR), B), 256, 0, st>>>(x, w, gamma, beta, (bf16*)out, sums, T, T0);
+      conv0_mfma_kernel<<<dim3(ssak_cdiv(T0, C0M_FR * C0M_SUB), B), 256, 0, st>>>(x, w, gamma, beta, (bf16*)out, sums, T, T0);
       SSAK_LAUNCH_CHECK();
       return SSAK_OK;
     }

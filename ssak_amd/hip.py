@@ -13,7 +13,7 @@ import torch
 
 _DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssak_hip.so")
 _LIB_PATH = os.environ.get("SSAK_HIP_LIB") or _DEFAULT_LIB  # (the override names another build OF THE SAME ABI: A/B runs, instrumented builds)
-ABI_VERSION = 500  # ssak_version() of the library this binding's struct layouts and signatures were written for
+ABI_VERSION = 510  # ssak_version() of the library this binding's struct layouts and signatures were written for
 
 
 class GemmDesc(C.Structure):
