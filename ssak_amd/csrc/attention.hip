@@ -135,6 +135,35 @@ __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_
   }
 }
 
+// The same staging with the per-lane offsets computed ONCE and the tile's first row carried by the buffer descriptor: per tile the
+// address work is scalar (base += row0 rows, records -= the same) -- dma_tile() spends an add, a compare and a select per instruction
+// and tile on the VALU (12 per key tile in the forward / dQ kernels, 12 in dK / dV), in kernels whose time IS their VALU count.  Rows
+// beyond the tensor fall outside the shrunken descriptor and come back as zeros, as before.
+struct DmaOff {
+  uint32_t o[2];
+};
+__device__ __forceinline__ DmaOff dma_offsets(uint32_t col_byte, long ld_bytes, int image, int wave, int lane) {
+  DmaOff d;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int S = (wave * 2 + j) * 64 + lane;
+    const int r = S >> 3, pc = S & 7;
+    const int c = image == 2 ? (pc ^ dual_swz(r)) : image == 1 ? (pc ^ (r & 6)) : (pc ^ ((r >> 1) & 7));
+    d.o[j] = (uint32_t)((long)r * ld_bytes + col_byte + c * 16);
+  }
+  return d;
+}
+// descriptor of rows [row0, nrows) of a [nrows, ld_bytes] tensor (row0 uniform: scalar arithmetic)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_rows(const void* base, long ld_bytes, int row0, int nrows) {
+  const long skip = (long)row0 * ld_bytes;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + skip), 0, (int)((long)max(nrows - row0, 0) * ld_bytes), 0x00020000);
+}
+__device__ __forceinline__ void dma_tile_at(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const DmaOff& d, int wave) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + (wave * 2 + j) * 1024), 16, d.o[j], 0, 0, 0);
+}
+
 // row-read fragment: rows 16*sub + (lane&15), k = 32*kk + 8*(lane>>4) + j
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int sub, int kk, int lane) {
   const int r = 16 * sub + (lane & 15);
@@ -299,9 +328,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) oacc[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const DmaOff koff = dma_offsets(kcol, ld * 2, 0, wave, lane), voff = dma_offsets(vcol, ld * 2, 1, wave, lane);
   if (nkt > 0) {
-    dma_tile(rsrc, smem, kcol, ld * 2, 0, F, 0, wave, lane);
-    dma_tile(rsrc, smem + TILE_BYTES, vcol, ld * 2, 0, F, 1, wave, lane);
+    dma_tile_at(rsrc, smem, koff, wave);
+    dma_tile_at(rsrc, smem + TILE_BYTES, voff, wave);
   }
   const int g = lane >> 4;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -309,8 +339,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
     if (kt + 1 < nkt) {
-      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES, kcol, ld * 2, (kt + 1) * KT, F, 0, wave, lane);
-      dma_tile(rsrc, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, vcol, ld * 2, (kt + 1) * KT, F, 1, wave, lane);
+      const __amdgpu_buffer_rsrc_t rn = rsrc_rows(base, ld * 2, (kt + 1) * KT, F);
+      dma_tile_at(rn, smem + (cur ^ 1) * 2 * TILE_BYTES, koff, wave);
+      dma_tile_at(rn, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, voff, wave);
     }
     const char* kt_lds = smem + cur * 2 * TILE_BYTES;
     const char* vt_lds = kt_lds + TILE_BYTES;
@@ -451,7 +482,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   const bf16* base = p.qkv + (long)b * F * ld;
   const int kl = p.klens ? min(max(p.klens[b], 0), F) : F;
   const int nkt = (kl + KT - 1) / KT;
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
   const uint32_t kcol = (uint32_t)((H + h * HD) * 2), vcol = (uint32_t)((2 * H + h * HD) * 2);
   const int g = lane >> 4;
   int qrow[NQS];
@@ -492,10 +522,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     for (int i = 0; i < 4; ++i) dq[qs][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const uint32_t* cmt = reinterpret_cast<const uint32_t*>(smem + 2 * 2 * TILE_BYTES);  // [nkt * 64] key multipliers (DROP)
   if (DROP) fill_colmul(reinterpret_cast<uint32_t*>(smem + 2 * 2 * TILE_BYTES), nkt * KT);
+  const DmaOff koff = dma_offsets(kcol, ld * 2, 2, wave, lane), voff = dma_offsets(vcol, ld * 2, 2, wave, lane);
   auto issue = [&](int kt, int stage) {
     char* s0 = smem + stage * 2 * TILE_BYTES;
-    dma_tile(rsrc, s0, kcol, ld * 2, kt * KT, F, 2, wave, lane);
-    dma_tile(rsrc, s0 + TILE_BYTES, vcol, ld * 2, kt * KT, F, 2, wave, lane);
+    const __amdgpu_buffer_rsrc_t rn = rsrc_rows(base, ld * 2, kt * KT, F);
+    dma_tile_at(rn, s0, koff, wave);
+    dma_tile_at(rn, s0 + TILE_BYTES, voff, wave);
   };
   if (nkt > 0) issue(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -548,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         for (int qs = 0; qs < NQS; ++qs) {
           // P'' = exp2(s * c2 - lsc) = P * scale / (1 - p); dS = P'' (keep ? dP : 0 - delta (1 - p)).  Rows without any valid
           // key have lse = -inf -> lsc = +inf -> P'' = 0.  Packed fp32 over the key pair.
-          const f32x2 c2v = {c2, c2}, lscv = {-lse2[qs], -lse2[qs]}, dlv = {dl[qs], dl[qs]};
+          const f32x2 c2v = {c2, c2}, lscv = {-lse2[qs], -lse2[qs]}, ndlv = {-dl[qs], -dl[qs]};
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -560,7 +592,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
               }
               const f32x2 a = (f32x2){s[qs][kh][r2], s[qs][kh][r2 + 1]} * c2v + lscv;
               const f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-              const f32x2 ds2 = pv * (d - dlv);
+              // P'' (d - delta') as fma(P'', d, -P'' delta'): two packed instructions per key pair (the subtraction compiled to one
+              // v_sub_f32 per element: the selected values do not sit in register pairs)
+              const f32x2 ds2 = __builtin_elementwise_fma(pv, d, pv * ndlv);
               s[qs][kh][r2] = ds2[0];
               s[qs][kh][r2 + 1] = ds2[1];
             }
@@ -619,8 +653,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
   const bf16* base = p.qkv + (long)b * F * ld;
   const int kl = p.klens ? min(max(p.klens[b], 0), F) : F;
   const int nqt = (F + KT - 1) / KT;
-  __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((long)F * ld * 2), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dctx + (long)b * F * H), 0, (int)((long)F * H * 2), 0x00020000);
   const uint32_t qcol = (uint32_t)(h * HD * 2);
   const int g = lane >> 4;
   float* stat = reinterpret_cast<float*>(smem + 2 * 2 * TILE_BYTES);  // [stage][lse * log2 e KT | delta KT | dropout row seed KT]
@@ -659,10 +691,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
       dk[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dv[ks][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+  const DmaOff qoff = dma_offsets(qcol, ld * 2, 2, wave, lane), dooff = dma_offsets(qcol, (long)H * 2, 2, wave, lane);
+  const bf16* const do_base = p.dctx + (long)b * F * H;
   auto issue = [&](int qt, int stage) {
     char* s0 = smem + stage * 2 * TILE_BYTES;
-    dma_tile(rs_qkv, s0, qcol, ld * 2, qt * KT, F, 2, wave, lane);
-    dma_tile(rs_do, s0 + TILE_BYTES, qcol, (long)H * 2, qt * KT, F, 2, wave, lane);
+    dma_tile_at(rsrc_rows(base, ld * 2, qt * KT, F), s0, qoff, wave);
+    dma_tile_at(rsrc_rows(do_base, (long)H * 2, qt * KT, F), s0 + TILE_BYTES, dooff, wave);
   };
   // Per-query statistics of a tile (log-sum-exp, delta, dropout row key; threads 0..63 hold one query each) travel TWO tiles ahead
   // in registers: loaded in front of a tile's LDS-DMA, written to LDS one iteration later.  Loaded behind the DMA and consumed at
@@ -739,21 +773,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
 #pragma unroll
           for (int r = 0; r < 4; r += 2) {  // packed fp32 over the row pair
             const int ql = 16 * (2 * t2 + qh) + 4 * g + r;  // query inside the tile
-            const f32x2 c2v = {c2, c2}, lscv = {-lse_s[ql], -lse_s[ql + 1]}, dlv = {dl_s[ql], dl_s[ql + 1]};
+            const f32x2 c2v = {c2, c2}, lscv = {-lse_s[ql], -lse_s[ql + 1]}, ndlv = {-dl_s[ql], -dl_s[ql + 1]};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
               const f32x2 a = (f32x2){s[ks][qh][r], s[ks][qh][r + 1]} * c2v + lscv;
               const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};  // P * scale / (1 - p)
-              f32x2 dpv = {dp[ks][qh][r], dp[ks][qh][r + 1]}, pd = pr;
+              const f32x2 dpv = {dp[ks][qh][r], dp[ks][qh][r + 1]};
+              f32x2 pd = pr;
               if (DROP) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                  const bool k = drop_keep(rk[r + e], cmk[ks], thi);
-                  dpv[e] = k ? dpv[e] : 0.f;
-                  pd[e] = k ? pd[e] : 0.f;
-                }
+                for (int e = 0; e < 2; ++e) pd[e] = drop_keep(rk[r + e], cmk[ks], thi) ? pd[e] : 0.f;
               }
-              const f32x2 ds2 = pr * (dpv - dlv);  // dS (softmax scale included)
+              // dS = P'' (keep dP - delta') = Pd dP - P'' delta' (softmax scale included): ONE select per element (on P''), the mask
+              // reaches dP through the product -- two selects and a packed subtraction before
+              const f32x2 ds2 = __builtin_elementwise_fma(pd, dpv, pr * ndlv);
               s[ks][qh][r] = pd[0];                 // Pd * scale
               s[ks][qh][r + 1] = pd[1];
               dp[ks][qh][r] = ds2[0];
