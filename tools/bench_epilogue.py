@@ -32,3 +32,5 @@ run("bias+gelu+preact", bias=bias, epilogue=h.EPI_GELU, aux_out=pre)
 run("bias+gelu+preact+dropout", bias=bias, epilogue=h.EPI_GELU, aux_out=pre, drop_p=0.1, drop_seed=1, drop_stream=2)
 run("gelugrad(aux)+dropout", epilogue=h.EPI_MUL_GELU_GRAD, aux_in=pre, drop_p=0.1, drop_seed=1, drop_stream=2)
 run("gelugrad(aux)", epilogue=h.EPI_MUL_GELU_GRAD, aux_in=pre)
+codes = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+run("FFN-up: bias+gelu+gelu' codes+dropout", bias=bias, epilogue=h.EPI_GELU_SAVE_GRAD, aux_out=codes, drop_p=0.1, drop_seed=1, drop_stream=2)
