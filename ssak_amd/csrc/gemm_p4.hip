@@ -39,17 +39,6 @@
 namespace {
 
 constexpr int P4_THREADS = 256;
-// development aid (-DP4_STAMPS, tools/p4_stamps.py): shader-clock stamps per workgroup and tile -- 0 tile start, 1 first K tile's operands
-// in registers, 2 K loop done, 3 epilogue issued
-#ifdef P4_STAMPS
-__device__ unsigned long long g_p4_stamps[256][8][4];
-#define P4_STAMP(i)                                                                                    \
-  do {                                                                                                 \
-    if (threadIdx.x == 0 && p4_round < 8 && blockIdx.x < 256) g_p4_stamps[blockIdx.x][p4_round][i] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define P4_STAMP(i)
-#endif
 // LDS: SA stages of A (32 NI rows x 128 B) | two stages of B (256 rows x 128 B) | two bias slots of 1 KiB per wave (128 fp32 from
 // lanes 0-31; the other lanes' LDS-DMA writes zeros)
 
@@ -295,12 +284,8 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
     __syncthreads();
   }
   P4Tile cur = decode(min(t_first, ntiles - 1));
-#ifdef P4_STAMPS
-  int p4_round = 0;
-#endif
   for (int t = t_first; t < ntiles;) {
     const P4Tile c = cur;
-    P4_STAMP(0);
     const uint32_t bias_lds = bias_lds0 + par * 4096;
     const bool was_primed = primed;
     if (!primed) {
@@ -328,7 +313,6 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
       static_for<8>([&fb0, b0](auto j) __attribute__((always_inline)) { P4_READ(fb0[j], b0, j * 2048); });
       static_for<NI>([&fa0, a0](auto i) __attribute__((always_inline)) { P4_READ(fa0[i], a0, i * 2048); });
     }
-    P4_STAMP(1);
     uint32_t a_cur = fo_a[1] + s_sa, b_cur = fo_b[1] + s_sb;
     // the next output tile: the tail of this one stages its first K tiles
     int t_next = t + (int)gridDim.x;  // (ticket order: known from K tile 3 on, pre())
@@ -395,7 +379,6 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
     pre();
     ktile(F{}, F{}, T{}, s_sa, s_sb, a_cur, b_cur, koff_a, koff_b, false, bias_lds_next, ra, rb, rbias, nullptr, ticket);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are read by compiler-generated code
-    P4_STAMP(2);
     primed = stage_next;
     if constexpr (EPI == SSAK_EPI_MUL_AUX) {
       // the factor codes of both halves in flight before any arithmetic (the fragment registers are free now)
@@ -411,10 +394,6 @@ __global__ __launch_bounds__(P4_THREADS) void gemm_p4_kernel(const GemmParams p)
         gemm_epilogue_direct<NI, EPI>(p, acc[h], bias_regs[h], c.bm0, c.bn0, wr * 16 * NI, wc * 128 + 64 * h, lane, c.z, c.z1, c.z2, 0);
     }
     if (!primed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dummies (and whatever the epilogue left) before LDS is re-staged
-    P4_STAMP(3);
-#ifdef P4_STAMPS
-    ++p4_round;
-#endif
     t = t_next;
     par ^= 1;
   }
@@ -523,15 +502,6 @@ bool ssak_gemm_p4_supports(const void* params, int bm, int a_km, int b_km) {
   if (p.out_f32 && p.epilogue != SSAK_EPI_NONE) return false;
   return true;
 }
-
-#ifdef P4_STAMPS
-extern "C" int ssak_debug_p4_stamps(unsigned long long* out_host) {
-  SSAK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_p4_stamps), sizeof(g_p4_stamps)));
-  unsigned long long zero[8 * 4] = {};
-  for (int b = 0; b < 256; ++b) SSAK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p4_stamps), zero, sizeof(zero), (size_t)b * sizeof(zero)));
-  return SSAK_OK;
-}
-#endif
 
 int ssak_gemm_p4_launch(const void* params, int bm, int b_km, hipStream_t st) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);

@@ -1,4 +1,4 @@
-"""Where a tile of the four-wave GEMM spends its time: a library built with -DP4_STAMPS (make OBJ=build/obj_st LIB=tools/ab_stamps.so
+"""Where a tile of the four-wave GEMM spends its time: a library built from tools/probes/p4_stamps.patch.txt (git apply it, then make OBJ=build/obj_st LIB=tools/ab_stamps.so
 EXTRA=-DP4_STAMPS) records the shader clock at the tile's start, when its first K tile's fragments are read, after the K loop and after the
 epilogue, per workgroup and tile.  usage: SSAK_HIP_LIB=$PWD/tools/ab_stamps.so PYTHONPATH=. python tools/p4_stamps.py"""
 import ctypes
