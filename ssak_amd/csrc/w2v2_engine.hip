@@ -595,7 +595,8 @@ struct WgradQueue {
   // pairs the k-th announcement of every rank in one collective, and LayerDrop decisions differ between ranks, so a
   // dropped layer's (zero) range must not overtake the kept layers still waiting here
   long ann_off[64];
-  long ann_last[64];  // the layer's last product (sequence number), -1: nothing to wait for (a dropped layer)
+  long ann_cnt[64];   // elements of the range (a layer's four matrices; the lm_head matrix)
+  long ann_last[64];  // the range's last product (sequence number), -1: nothing to wait for (a dropped layer)
   int n_ann = 0;
   static int tiles_of(const ssak_gemm_desc& g) { return ssak_cdiv(g.M, 256) * ssak_cdiv(g.N, 256); }
   bool uses_set(int s) const {
@@ -1308,15 +1309,15 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       dlog = const_cast<float*>(dlogits);  // the CTC gradient is consumed in fp32 as it is
     else
       TRY(k_cast_f32_bf16(dlogits, dlog, (long)M * V, st));
-    const AT* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(e->xin[c.num_layers]);
-    TRY(GemmX<EXACT>(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true).run_wgrad(st, slab, p.slab_bytes));
+    // (the lm_head weight gradient -- V x H, K = M: three tiles -- rides in the first grouped weight-gradient launch below instead of
+    // running alone as a split-K product with its slab reduction: queued once the queue exists)
     TRY(k_colsum_t<AT>(dlog, V, M, V, Gd + e->p_lm_b, st, FP(p.lnpart), cs_floats));
   }
   auto announce = [&](long off, long cnt) {
     if (e->on_ready && cnt > 0) e->on_ready(off, cnt, e->on_ready_user);
   };
   const long layer_span = (e->lp[0].w2 + (long)H * I) - e->lp[0].wqkv;  // wqkv|wo|w1|w2 of one layer are contiguous
-  announce(e->p_lm_w, (long)V * H);
+  if (!dlogits) announce(e->p_lm_w, (long)V * H);  // (hidden-state interface: the head's gradient stays zero, its range is complete)
   AT* gA = BF(p.dA);  // gradient w.r.t. the current layer output = gA (+ gB)
   AT* gB = nullptr;
   if (dhidden)
@@ -1382,9 +1383,13 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
   auto flush_gemms = [&]() -> int {
     TRY(wq.flush(st, slab, p.slab_bytes));
     int done = 0;
-    while (done < wq.n_ann && wq.ann_last[done] < wq.launched) announce(wq.ann_off[done++], layer_span);
+    while (done < wq.n_ann && wq.ann_last[done] < wq.launched) {
+      announce(wq.ann_off[done], wq.ann_cnt[done]);
+      ++done;
+    }
     for (int i = done; i < wq.n_ann; ++i) {
       wq.ann_off[i - done] = wq.ann_off[i];
+      wq.ann_cnt[i - done] = wq.ann_cnt[i];
       wq.ann_last[i - done] = wq.ann_last[i];
     }
     wq.n_ann -= done;
@@ -1402,6 +1407,14 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     return SSAK_OK;
   };
   SinkGuard sink_guard(&sink);
+  if (dlogits) {
+    // lm_head weight gradient: first in the queue, so its range is the first announced (the order every rank agrees on)
+    const AT* xl = (c.final_dropout > 0.f) ? BF(p.xf) : BF(e->xin[c.num_layers]);
+    TRY(wq_push(GemmX<EXACT>(V, H, M).a(dlog, V, true).b(xl, H, true).c(Gd + e->p_lm_w, H, true), -1));
+    wq.ann_off[wq.n_ann] = e->p_lm_w;
+    wq.ann_cnt[wq.n_ann] = (long)V * H;
+    wq.ann_last[wq.n_ann++] = wq.pushed - 1;
+  }
   for (int l = c.num_layers - 1; l >= 0; --l) {
     const LayerP& L = e->lp[l];
     const LayerBuf& lb = p.lb[l];
@@ -1414,6 +1427,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
       // zeros (memset above), still part of the all-reduce; behind any kept layer whose gradients are still queued
       if (wq.n_ann > 0) {
         wq.ann_off[wq.n_ann] = L.wqkv;
+        wq.ann_cnt[wq.n_ann] = layer_span;
         wq.ann_last[wq.n_ann++] = -1;
       } else {
         announce(L.wqkv, layer_span);
@@ -1502,6 +1516,7 @@ static int backward_impl(ssak_w2v2* e, const float* dlogits, const bf16* dhidden
     if (!qkv_fused_floats) TRY(k_colsum_t<AT>(dqkv, 3 * H, M, 3 * H, Gd + L.bqkv, st, qkv_part, (size_t)64 * 3 * H));
     TRY(GemmX<EXACT>(M, H, 3 * H).a(dqkv, 3 * H).b_wt(EXACT ? nullptr : e->wt(l, 0), 3 * H, W + L.wqkv, H).bfrag(e->wt(l, 0) ? nullptr : e->frag(l, 3)).c(dX, H).run(st));
     wq.ann_off[wq.n_ann] = L.wqkv;
+    wq.ann_cnt[wq.n_ann] = layer_span;
     wq.ann_last[wq.n_ann++] = wq.pushed - 1;  // announced once the qkv product -- the layer's last -- has been launched
     ++wq.layers;
     if (wgrad_all() ? (wq.layers % p.wgrad_sets == 0) : false)
